@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by IMPORTING the reference (/root/reference) on CPU.
+
+Runs only in the build container (the reference does not travel to the GPU box).
+Inputs come from pb_llm_amd.synth (deterministic, torch-free) so tests regenerate
+them bit-exactly; only outputs of the reference are stored, as small .npz
+fixtures under tests/golden/.
+
+Shims: `import quant` calls .cuda() at class-definition time
+(quant/quantizer.py:33-34) -> Tensor.cuda becomes identity; gptq.py:176,194 call
+torch.cuda.synchronize / empty_cache -> no-ops.
+
+usage: python tools/gen_goldens.py [--only G1,G4] [--out tests/golden]
+"""
+import argparse
+import contextlib
+import hashlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from pb_llm_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.cuda.synchronize = lambda *a, **k: None
+torch.cuda.empty_cache = lambda *a, **k: None
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "gptq_pb"))
+import quant  # noqa: E402  (reference)
+from gptq import LowHighGPT  # noqa: E402  (reference)
+from low_quant import LowQuantizer  # noqa: E402
+from high_quant import HighQuantizer  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def save(out, name, **arrs):
+    path = os.path.join(out, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# --------------------------------------------------------------------------- #
+def g1_g2(out):
+    """BinaryLinear / XnorBinaryLinear 768x768 + bias, x [2,5,768] fp32."""
+    W = synth.llm_weight(768, 768, seed=1)
+    W[3, 5] = 0.0  # three-valued sign
+    b = synth.normal((768,), 1, 3, 0.1)
+    x = synth.normal((2, 5, 768), 1, 5, 1.0)
+    m = quant.BinaryLinear(T(W), T(b))
+    y1 = m(T(x)).detach().numpy()
+    m0 = quant.BinaryLinear(T(W), None)
+    y1nb = m0(T(x)).detach().numpy()
+    m2 = quant.XnorBinaryLinear(T(W), T(b))
+    y2 = m2(T(x)).detach().numpy()
+    w2 = m2.quant_weight().detach().numpy()
+    save(out, "g1_binary_linear", y=y1, y_nobias=y1nb)
+    save(out, "g2_xnor_binary_linear", y=y2, alpha=np.abs(w2).max(1), w_sha=np.array(sha(w2)))
+
+
+def g3(out):
+    """weight_quant_8bit quirks: rounded zero point, uint8 wrap, constant row."""
+    W = synth.normal((8, 64), 3, 0, 0.02)
+    W[1] = W[1] - 0.7            # min < -0.5 -> zero point -1
+    W[2] = np.abs(W[2]) + 0.6    # min > 0.5  -> zero point +1
+    W[3] = 0.25                  # constant row: range 0 -> inf/nan path
+    W[4] = W[4] * 40.0           # wide row, zp = round(min) far from 0
+    W[5, :] = np.linspace(-0.5, 0.5, 64, dtype=np.float32)  # ties at .5
+    res = {}
+    for tag, dt in (("f32", torch.float32), ("f16", torch.float16)):
+        w = T(W).to(dt)
+        with np.errstate(all="ignore"):
+            sim = quant.weight_quant_8bit(w.clone(), simulated=True)
+            codes = quant.weight_quant_8bit(w.clone(), simulated=False)
+        res["sim_" + tag] = sim.float().numpy()
+        res["codes_" + tag] = codes.numpy()
+    save(out, "g3_weight_quant_8bit", W=W, **res)
+
+
+def g4(out):
+    """BinaryXnorExceptOutliersLinear 768x768 f=0.1 (QAT layer), fp32 and fp16 weights."""
+    W = synth.llm_weight(768, 768, seed=4, heavy_tail=True)
+    W[7, 9] = 0.0
+    b = synth.normal((768,), 4, 3, 0.1)
+    x = synth.normal((3, 768), 4, 5, 1.0)
+    res = {}
+    for tag, dt in (("f32", torch.float32), ("f16", torch.float16)):
+        m = quant.BinaryXnorExceptOutliersLinear(T(W).to(dt), T(b).to(dt), 0.1)
+        m.eval()
+        with quiet():
+            m.gen_outlier_mask()
+        res[f"mask_{tag}"] = np.packbits(m.outlier_mask.numpy())
+        res[f"binary_scale_{tag}"] = m.binary_scale.float().numpy()
+        res[f"w_hat_{tag}"] = m.weight.data.float().numpy().astype(np.float32 if tag == "f32" else np.float16)
+        res[f"outlier_nbits_{tag}"] = np.array(m.outlier_nbits)
+        xt = T(x).to(dt)
+        with torch.no_grad():
+            res[f"y_eval_{tag}"] = m(xt).float().numpy()
+            lin = m.to_regular_linear()
+            res[f"regular_equal_{tag}"] = np.array(bool(torch.equal(lin(xt), m(xt))))
+            res[f"w_sim_sha_{tag}"] = np.array(sha(lin.weight.data.float().numpy()))
+            m.train()
+            res[f"y_train_{tag}"] = m(xt).float().numpy()
+            res[f"binary_scale_after_train_{tag}"] = m.binary_scale.float().numpy()
+            m.eval()
+            res[f"y_eval2_{tag}"] = m(xt).float().numpy()
+        # outlier_scale != 1
+        m2 = quant.BinaryXnorExceptOutliersLinear(T(W).to(dt), None, 0.1, outlier_scale=0.5)
+        m2.eval()
+        with quiet(), torch.no_grad():
+            res[f"y_oscale_{tag}"] = m2(xt).float().numpy()
+    save(out, "g4_pb_qat_linear", **res)
+
+
+def run_ptq(W16, Xcal, low_frac, metric, groupsize, disable_gptq, high_bit=8, want_hdiag=True):
+    """Drive the reference PTQ objects exactly as gptq_pb/run.py:127-169 does."""
+    N, K = W16.shape
+    layer = nn.Linear(K, N, bias=False)
+    layer.weight.data = T(W16).clone()  # fp16, like a hub checkpoint
+    layer.global_name = "golden/layer"
+    lq = LowQuantizer(layer.weight, method="xnor", groupsize=groupsize)
+    hq = HighQuantizer(high_bit, perchannel=True, sym=False, mse=False)
+    g = LowHighGPT(layer, lq, hq, salient_metric=metric, disable_gptq=disable_gptq)
+    for s in range(Xcal.shape[0]):
+        g.add_batch(T(Xcal[s:s + 1]), None)
+    stash = {}
+    orig_chol = torch.linalg.cholesky
+
+    def chol(A, *a, **k):
+        r = orig_chol(A, *a, **k)
+        if k.get("upper", False):
+            stash["U"] = r.clone()
+        return r
+
+    torch.linalg.cholesky = chol
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "outputs"))
+        os.chdir(td)
+        try:
+            with quiet():
+                info = g.fasterquant(low_frac, blocksize=128, percdamp=0.01)
+            mask = torch.load(os.path.join(td, "outputs/mask",
+                                           f"mask_{low_frac}_golden_layer.pkl")).numpy()
+        finally:
+            os.chdir(cwd)
+            torch.linalg.cholesky = orig_chol
+    r = dict(mask=mask, W_fq=layer.weight.data.numpy().copy(), mean=lq.mean.numpy().copy(),
+             scale=lq.scale.numpy().copy(), hscale=hq.scale.numpy().copy(),
+             hzero=hq.zero.numpy().copy(), loss=np.array(info["error"]))
+    if want_hdiag:
+        r["hinv_diag"] = torch.diag(stash["U"]).numpy().copy()
+    return r
+
+
+def g5(out):
+    """PTQ 768x768 (OPT-125m q_proj shape): {magnitude,hessian} x {gs -1,128} x {RTN,GPTQ}."""
+    W16 = synth.llm_weight(768, 768, seed=5, heavy_tail=True).astype(np.float16)
+    Xcal = synth.calib_inputs(4, 256, 768, seed=5)
+    x1 = synth.activations((1, 768), 5, 21)
+    x32 = synth.activations((32, 768), 5, 22)
+    for metric in ("magnitude", "hessian"):
+        for gs in (-1, 128):
+            for rtn in (True, False):
+                for lf in ((0.9, 0.95) if (metric == "hessian" and gs == -1 and rtn) else (0.9,)):
+                    r = run_ptq(W16, Xcal, lf, metric, gs, rtn)
+                    Wfq = T(r["W_fq"])
+                    y1 = F.linear(T(x1), Wfq).numpy()
+                    y32 = F.linear(T(x32), Wfq).numpy()
+                    y32_f32 = F.linear(T(x32).float(), Wfq.float()).numpy()
+                    tag = f"g5_ptq_{metric}_gs{gs if gs > 0 else 'all'}_{'rtn' if rtn else 'gptq'}_lf{lf}"
+                    save(out, tag, mask=np.packbits(r["mask"]), W_fq=r["W_fq"], mean=r["mean"],
+                         scale=r["scale"], hscale=r["hscale"], hzero=r["hzero"], loss=r["loss"],
+                         hinv_diag=r["hinv_diag"], y1=y1, y32=y32, y32_f32=y32_f32)
+
+
+def big_rtn(out, tag, N, K, low_frac, M, seed):
+    """Large shapes: outputs only + hashes (regenerated by the oracle, which g5 validates)."""
+    W16 = synth.llm_weight(N, K, seed=seed).astype(np.float16)
+    Xcal = synth.calib_inputs(1, 8, K, seed=seed)  # H is unused by magnitude+RTN but must be PD
+    r = run_ptq(W16, Xcal, low_frac, "magnitude", -1, True, want_hdiag=False)
+    x = synth.activations((M, K), seed, 21)
+    y = F.linear(T(x), T(r["W_fq"])).numpy()
+    y_f32 = F.linear(T(x).float(), T(r["W_fq"]).float()).numpy()
+    nnz_row = (~r["mask"]).sum(1).astype(np.int32)
+    save(out, tag, y=y, y_f32=y_f32, nnz_row=nnz_row, W_fq_sha=np.array(sha(r["W_fq"])),
+         mask_sha=np.array(sha(np.packbits(r["mask"]))), hscale=r["hscale"], hzero=r["hzero"],
+         mean=r["mean"], scale=r["scale"])
+
+
+def g6(out):
+    big_rtn(out, "g6_llama7b_qproj_4096_lf0.9", 4096, 4096, 0.9, 1, seed=6)
+
+
+def g7(out):
+    big_rtn(out, "g7_llama13b_ffn_13824x5120_lf0.8", 13824, 5120, 0.8, 32, seed=7)
+    big_rtn(out, "g7_llama13b_ffn_5120x13824_lf0.8", 5120, 13824, 0.8, 32, seed=8)
+
+
+ALL = dict(G1=g1_g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    sel = [s for s in a.only.split(",") if s] or list(ALL)
+    for k in sel:
+        print(k)
+        ALL[k](a.out)
