@@ -1,0 +1,178 @@
+/*
+ * pbl.h -- C ABI of libpbl.so: MI355X (gfx950) partially-binarized linear layer.
+ *
+ * This is the drop-in boundary for ONE hot path of hahnyuan/PB-LLM: the forward of
+ *   quant.BinaryLinear                     (quant/quantizer.py:75-86)
+ *   quant.XnorBinaryLinear                 (quant/quantizer.py:172-193)
+ *   quant.BinaryXnorExceptOutliersLinear   (quant/outlier_quantizer.py:33-123)
+ *   nn.Linear holding GPTQ-PB fake-quant weights (gptq_pb/gptq.py:155,180-184)
+ * all of which the reference evaluates as  F.linear(x, w_sim, bias)  over a dense
+ * simulated weight.  The reference is pure Python with no FFI; the Python module
+ * layer in pb_llm_amd/quant.py mirrors its classes and calls these entry points
+ * through ctypes (INTEGRATION.md shows the binding).
+ *
+ * Conventions: plain pointers and sizes, no torch types.  Device pointers are
+ * BORROWED (the caller owns all memory); nothing here allocates, frees or
+ * synchronises device memory; kernels are asynchronous on the given hipStream_t
+ * and are hipGraph-capturable.  Every function returns a pbl_status (0 = ok).
+ * No exceptions cross the ABI.  Reentrant; no global mutable state.
+ *
+ * ---------------------------------------------------------------------------
+ * Unified math:  for output row r
+ *   y_r = sum_j v_rj * x_j + b_r,
+ *   v_rj = hi_{r,g(j)} if bit_rj else lo_{r,g(j)}          (dense 1-bit plane)
+ *          except at "salient" positions, where v_rj = sscale_r * (q_rj - szero_r)
+ *          (uint8 code q, per-row affine = HighQuantizer's scale*(q-zero)), and at rare "exception" positions,
+ *          where v_rj is an explicit fp32 value.
+ * hi/lo are the two values the binarized weights of a row(-group) take:
+ *   BinaryLinear: (+1,-1);  Xnor: (+a_r,-a_r);  QAT PB layer: (+a,-a) per tensor;
+ *   GPTQ-PB: (mu+alpha, mu-alpha) per row and column group.
+ *
+ * ---------------------------------------------------------------------------
+ * Packed format "PBL1" (one blob per layer, identical on host and device):
+ *
+ *   [pbl_blob_header 80 B][rb_off: u32[NRB+1], units of 16 B, padded to 16 B]
+ *   [record 0][record 1]...[record NRB-1]        NRB = ceil(N/16)
+ *
+ * A record holds one ROW-BLOCK of 16 output rows and is the unit of work of one
+ * wavefront.  P = ceil(K/512) column panels.  Record layout (all 16-B aligned):
+ *   +0    pbl_rec_header (16 B): nfull, ntail, nexc, off_sal (bytes from record start)
+ *   +16   rowinfo[16]  (8 B each): u16 start, u16 nfull, u16 tailidx, u8 ntail, u8 0
+ *   +144  params[16]   (16 B each): f32 hi, lo, sscale, szero     (group 0 / G==1)
+ *   +400  [G>1 only]   ghl[16][G] (8 B each): f32 hi, lo per column group
+ *   +T    tiles[P]     1 KiB each: the sign plane of 16 rows x 512 columns
+ *   +off_sal: col0[nch_pad] (u16, nch = nfull+ntail, padded to x8), delta[nch][16] (u8),
+ *             code[nch][16] (u8), tailcnt[ntail_pad16] (u8), exc[nexc] (pbl_exception, 8 B)
+ *
+ * Sign-plane tile p: lane l (0..63) owns 4 dwords at byte ((p*64+l)*4+i)*4, i=0..3.
+ *   dword i covers columns c = 512p + 128i + 2l + e, e in {0,1}.
+ *   bit b of the dword: e = b>>4; pos = b&15; row-in-block rho = pos>=8 ? pos-8 : pos+8.
+ *   (Rows 8..15 are read after one `<< 8`, so every row sits on one of the fp16
+ *    bit positions 8..15 and is unpacked to a two-valued fp16 constant by ONE
+ *    v_and(_or)_b32 -- no per-weight shift; see DESIGN.md "bit classes".)
+ *   bit = 1 <=> the weight takes value hi (salient/exception positions store 1).
+ *
+ * Salient entries of a row are sorted by column and cut greedily into chunks of up
+ *   to 16: a chunk closes after 16 entries or when the next column step exceeds 255.
+ *   Chunk c: col0[c] = column of entry 0; delta[c][k] = column step from entry k-1
+ *   to k (delta[c][0] = 0); code[c][k] = q.  Chunks with exactly 16 entries are
+ *   "full"; the others are "tail" chunks and carry their count in tailcnt[].
+ *   Chunk order within a record: full chunks of row 0, row 1, ... row 15 (indices
+ *   0..nfull-1), then the tail chunks of row 0, row 1, ... (indices nfull..nch-1).
+ *   rowinfo[r]: full chunks [start, start+nfull), tail chunks
+ *   [hdr.nfull + tailidx, hdr.nfull + tailidx + ntail).
+ */
+#ifndef PBL_H_
+#define PBL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBL_MAGIC 0x314C4250u /* "PBL1" */
+#define PBL_VERSION 1
+#define PBL_ROWS_PER_BLOCK 16
+#define PBL_PANEL_COLS 512
+#define PBL_CHUNK 16
+#define PBL_MAX_TOKENS_PER_LAUNCH 4 /* M handled per weight pass by the GEMV kernel */
+
+typedef enum {
+    PBL_OK = 0,
+    PBL_ERR_INVALID_ARG = -1,
+    PBL_ERR_BAD_BLOB = -2,
+    PBL_ERR_UNSUPPORTED = -3,
+    PBL_ERR_MISALIGNED = -4,
+    PBL_ERR_CAPACITY = -5,
+    PBL_ERR_LAUNCH = -6,
+    PBL_ERR_NOT_REPRESENTABLE = -7
+} pbl_status;
+
+/* flags in pbl_blob_header.flags */
+#define PBL_FLAG_HAS_GROUPS 0x1u /* G > 1: per-(row,group) hi/lo in ghl */
+
+typedef struct {
+    uint32_t magic, version;
+    uint32_t N, K;          /* out_features, in_features */
+    uint32_t P;             /* column panels = ceil(K/512) */
+    uint32_t G;             /* column groups (1 = whole row); groupsize = K/G, multiple of 128 */
+    uint32_t NRB;           /* row blocks = ceil(N/16) */
+    uint32_t flags;
+    uint32_t max_nch;       /* max chunks in any record (LDS sizing) */
+    uint32_t max_nexc;      /* max exceptions in any record */
+    uint64_t nnz;           /* salient code entries, total */
+    uint64_t nexc;          /* exception entries, total */
+    uint64_t blob_bytes;    /* total size of the blob */
+    uint32_t rb_off_pos;    /* byte offset of rb_off[] from blob start (= sizeof header = 80) */
+    uint32_t reserved[3];
+} pbl_blob_header;
+
+typedef struct { uint32_t nfull, ntail, nexc, off_sal; } pbl_rec_header;
+typedef struct { uint16_t start, nfull, tailidx; uint8_t ntail, pad; } pbl_rowinfo;
+typedef struct { float hi, lo, sscale, szero; } pbl_rowparams;
+typedef struct { uint16_t col; uint16_t row; float value; } pbl_exception;
+
+/* A layer as the kernels see it.  `blob` is a DEVICE pointer to a PBL1 blob
+ * (16-B aligned); the scalar fields replicate its header so no device read is
+ * needed on the host.  `bias` (device, fp32 [N]) may be NULL. */
+typedef struct {
+    const void*  blob;
+    const float* bias;
+    uint32_t N, K, P, G, NRB, flags, max_nch, max_nexc;
+} pbl_layer;
+
+const char* pbl_status_string(int status);
+int pbl_version(void);
+
+/* ---------------- host-side packer (CPU; replaces nothing in the reference: the
+ * reference stores 1-bit weights as dense fp16, gptq_pb/gptq.py:180-184) ---------- */
+
+/* Pack a dense simulated weight W [N,K] (fp32, row-major, torch nn.Linear layout)
+ * given the two binarized values of every (row, group): hi, lo [N*G]; and the
+ * per-row affine of the salient codes: sscale, szero [N] (may be NULL when the layer
+ * has no salient weights).  An element equal to hi (lo) becomes bit 1 (0); any
+ * other element becomes a uint8 code entry if  fl32(sscale*(q-szero)) == W  for an
+ * integer q in [0,255], else an fp32 exception entry.  So unpack(pack(W)) == W
+ * bit-exactly for ANY input; off-grid values only cost bytes (8 B each).  If out == NULL only *out_bytes is computed.
+ * sal_mask (u8 [N*K], may be NULL): when given, positions with sal_mask != 0 are
+ * forced into the code/exception list even if they equal hi or lo. */
+int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
+                       const float* hi, const float* lo,
+                       const float* sscale, const float* szero,
+                       const uint8_t* sal_mask,
+                       void* out, size_t out_capacity, size_t* out_bytes);
+
+/* Validate a host blob and fill a pbl_layer (blob/bias pointers are left NULL). */
+int pbl_blob_describe(const void* host_blob, size_t bytes, pbl_layer* out);
+
+/* Reconstruct the dense simulated weight (fp32 [N,K]) from a host blob
+ * (to_regular_linear, quant/outlier_quantizer.py:108-114). */
+int pbl_unpack_dense_f32(const void* host_blob, size_t bytes, float* W_out);
+
+/* ---------------- device entry points ------------------------------------------- */
+
+/* Bytes of dynamic LDS the GEMV kernel needs for this layer at m tokens per pass
+ * (informational; the launchers compute it themselves). */
+size_t pbl_gemv_lds_bytes(const pbl_layer* layer, int m);
+
+/* y[M,N] = x[M,K] @ W_sim^T + bias.  x, y: device fp16, row-major, contiguous
+ * (replaces F.linear(x, w_sim, bias): quant/outlier_quantizer.py:105,
+ * quant/quantizer.py:86,193).  M >= 1; weights are streamed once per
+ * PBL_MAX_TOKENS_PER_LAUNCH tokens.  y_f32 != 0: y is fp32 instead of fp16.
+ * stream: hipStream_t (as void*). */
+int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream);
+
+/* L independent layers in ONE launch (decode-time fused QKV / gate+up, and the
+ * stream benchmark of SURVEY.md 8(d)).  layers_dev: DEVICE array of L pbl_layer;
+ * x_dev / y_dev: DEVICE arrays of L pointers (fp16 [M,K_l] / fp16 [M,N_l]);
+ * max_NRB, max_lds: maxima over the group (host knows them).  M <= 4. */
+int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, void* const* y_dev,
+                         int L, int M, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch,
+                         uint32_t max_nexc, int any_groups, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBL_H_ */

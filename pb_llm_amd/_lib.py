@@ -1,0 +1,75 @@
+"""ctypes binding of libpbl.so (C ABI in include/pbl.h).
+
+There is deliberately NO fallback: if the shared library is missing the import
+of anything that computes raises, so a GPU test can never pass on a silent CPU
+path.  Build it with `python -c "import __graft_entry__ as g; g.build()"`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpbl.so")
+
+PBL_MAX_TOKENS_PER_LAUNCH = 4
+
+
+class PblLayer(C.Structure):
+    """struct pbl_layer (include/pbl.h)."""
+    _fields_ = [("blob", C.c_void_p), ("bias", C.c_void_p),
+                ("N", C.c_uint32), ("K", C.c_uint32), ("P", C.c_uint32), ("G", C.c_uint32),
+                ("NRB", C.c_uint32), ("flags", C.c_uint32), ("max_nch", C.c_uint32),
+                ("max_nexc", C.c_uint32)]
+
+
+class PblBlobHeader(C.Structure):
+    _fields_ = [("magic", C.c_uint32), ("version", C.c_uint32), ("N", C.c_uint32), ("K", C.c_uint32),
+                ("P", C.c_uint32), ("G", C.c_uint32), ("NRB", C.c_uint32), ("flags", C.c_uint32),
+                ("max_nch", C.c_uint32), ("max_nexc", C.c_uint32), ("nnz", C.c_uint64),
+                ("nexc", C.c_uint64), ("blob_bytes", C.c_uint64), ("rb_off_pos", C.c_uint32),
+                ("reserved", C.c_uint32 * 3)]
+
+
+class PblError(RuntimeError):
+    pass
+
+
+_lib = None
+
+EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_blob_describe",
+           "pbl_unpack_dense_f32", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemv_f16_grouped"]
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PblError(f"{LIB_PATH} not found: the HIP extension is not built "
+                       "(run __graft_entry__.build()); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
+    L.pbl_status_string.restype = C.c_char_p
+    L.pbl_status_string.argtypes = [C.c_int]
+    L.pbl_version.restype = C.c_int
+    L.pbl_pack_dense_f32.restype = C.c_int
+    L.pbl_pack_dense_f32.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
+    L.pbl_blob_describe.restype = C.c_int
+    L.pbl_blob_describe.argtypes = [vp, sz, C.POINTER(PblLayer)]
+    L.pbl_unpack_dense_f32.restype = C.c_int
+    L.pbl_unpack_dense_f32.argtypes = [vp, sz, vp]
+    L.pbl_gemv_lds_bytes.restype = sz
+    L.pbl_gemv_lds_bytes.argtypes = [C.POINTER(PblLayer), C.c_int]
+    L.pbl_linear_f16.restype = C.c_int
+    L.pbl_linear_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
+    L.pbl_gemv_f16_grouped.restype = C.c_int
+    L.pbl_gemv_f16_grouped.argtypes = [vp, vp, vp, C.c_int, C.c_int, u32, u32, u32, u32, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().pbl_status_string(status).decode()
+        raise PblError(f"libpbl {what}: {msg} ({status})")

@@ -1,0 +1,304 @@
+// pbl_host.cpp -- host side of libpbl.so: PBL1 packer / unpacker / blob validation.
+//
+// The reference has no packed format (1-bit weights live as dense fp16,
+// gptq_pb/gptq.py:180-184; its intended storage is only *accounted* in
+// quant/outlier_quantizer.py:116-122).  This file defines ours; the layout is
+// documented in include/pbl.h and DESIGN.md.
+#include "../../include/pbl.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+inline size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
+
+// Kernel-form dequant used for the representability check and by the unpacker:
+// the value HighQuantizer produces, scale * (q - zero) (gptq_pb/high_quant.py:6-8).
+inline float dequant(float sscale, float szero, int q) { return sscale * (float(q) - szero); }
+
+struct Entry { uint16_t col; uint8_t code; };
+
+struct RecBuild {
+    std::vector<uint16_t> col0_full, col0_tail;
+    std::vector<uint8_t> delta_full, code_full, delta_tail, code_tail, tailcnt;
+    std::vector<pbl_exception> exc;
+    pbl_rowinfo ri[16];
+    void clear() {
+        col0_full.clear(); col0_tail.clear(); delta_full.clear(); code_full.clear();
+        delta_tail.clear(); code_tail.clear(); tailcnt.clear(); exc.clear();
+        std::memset(ri, 0, sizeof(ri));
+    }
+};
+
+// Bit index inside dword i of a lane for (row-in-block rho, element e).
+inline int bit_index(int rho, int e) {
+    int pos = rho < 8 ? rho + 8 : rho - 8;
+    return e * 16 + pos;
+}
+
+size_t record_fixed_bytes(uint32_t P, uint32_t G) {
+    size_t s = sizeof(pbl_rec_header) + 16 * sizeof(pbl_rowinfo) + 16 * sizeof(pbl_rowparams);
+    if (G > 1) s += size_t(16) * G * 8;
+    s = align16(s);
+    return s + size_t(P) * 1024;
+}
+
+size_t record_sal_bytes(size_t nch, size_t ntail, size_t nexc) {
+    size_t s = align16(nch * 2);       // col0
+    s += nch * 16 * 2;                 // delta + code
+    s += align16(ntail);               // tailcnt
+    s += nexc * sizeof(pbl_exception);
+    return align16(s);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pbl_status_string(int s) {
+    switch (s) {
+        case PBL_OK: return "ok";
+        case PBL_ERR_INVALID_ARG: return "invalid argument";
+        case PBL_ERR_BAD_BLOB: return "not a valid PBL1 blob";
+        case PBL_ERR_UNSUPPORTED: return "unsupported shape or option";
+        case PBL_ERR_MISALIGNED: return "pointer not 16-byte aligned";
+        case PBL_ERR_CAPACITY: return "output buffer too small";
+        case PBL_ERR_LAUNCH: return "kernel launch failed";
+        case PBL_ERR_NOT_REPRESENTABLE: return "value not representable in the packed format";
+        default: return "unknown status";
+    }
+}
+
+int pbl_version(void) { return PBL_VERSION; }
+
+int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
+                       const float* hi, const float* lo, const float* sscale, const float* szero,
+                       const uint8_t* sal_mask, void* out, size_t cap, size_t* out_bytes) {
+    if (!W || !hi || !lo || !out_bytes || N == 0 || K == 0 || G == 0) return PBL_ERR_INVALID_ARG;
+    if (K > 32767 || N > (1u << 24)) return PBL_ERR_UNSUPPORTED;
+    if (G > 1 && (K % G != 0 || (K / G) % 128 != 0)) return PBL_ERR_UNSUPPORTED;
+    const uint32_t gs = K / G;
+    const uint32_t P = (K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS;
+    const uint32_t NRB = (N + 15) / 16;
+
+    const size_t rboff_pos = sizeof(pbl_blob_header);
+    const size_t rec0 = align16(rboff_pos + size_t(NRB + 1) * 4);
+    const size_t fixed = record_fixed_bytes(P, G);
+    const size_t tiles_off = fixed - size_t(P) * 1024;
+
+    uint8_t* blob = static_cast<uint8_t*>(out);
+    std::vector<uint32_t> rb_off(NRB + 1);
+    size_t cur = rec0;
+    uint64_t nnz = 0, nexc_total = 0;
+    uint32_t max_nch = 0, max_nexc = 0;
+    RecBuild rb;
+    std::vector<Entry> ents;
+    std::vector<uint32_t> tile(size_t(P) * 256);
+
+    for (uint32_t b = 0; b < NRB; ++b) {
+        rb.clear();
+        std::fill(tile.begin(), tile.end(), 0u);
+        pbl_rowparams params[16];
+        std::memset(params, 0, sizeof(params));
+        std::vector<float> ghl;
+        if (G > 1) ghl.assign(size_t(16) * G * 2, 0.f);
+
+        for (int rho = 0; rho < 16; ++rho) {
+            const uint32_t r = b * 16 + rho;
+            rb.ri[rho].start = uint16_t(rb.col0_full.size());
+            rb.ri[rho].tailidx = uint16_t(rb.col0_tail.size());
+            if (r >= N) continue;
+            const float* w = W + size_t(r) * K;
+            const float ss = sscale ? sscale[r] : 0.f, sz = szero ? szero[r] : 0.f;
+            params[rho] = {hi[size_t(r) * G], lo[size_t(r) * G], ss, sz};
+            if (G > 1)
+                for (uint32_t g = 0; g < G; ++g) {
+                    ghl[(size_t(rho) * G + g) * 2 + 0] = hi[size_t(r) * G + g];
+                    ghl[(size_t(rho) * G + g) * 2 + 1] = lo[size_t(r) * G + g];
+                }
+            ents.clear();
+            for (uint32_t c = 0; c < K; ++c) {
+                const float v = w[c];
+                const uint32_t g = c / gs;
+                const float h = hi[size_t(r) * G + g], l = lo[size_t(r) * G + g];
+                const bool forced = sal_mask && sal_mask[size_t(r) * K + c];
+                int bit;
+                if (!forced && v == h) bit = 1;
+                else if (!forced && v == l) bit = 0;
+                else {
+                    bit = 1;  // sparse entries correct against `hi`
+                    bool coded = false;
+                    if (sscale && ss != 0.f && std::isfinite(v)) {
+                        float qf = std::nearbyint(v / ss + sz);
+                        for (int dq = 0; dq <= 2 && !coded; ++dq) {
+                            int q = int(qf) + (dq == 0 ? 0 : (dq == 1 ? 1 : -1));
+                            if (q >= 0 && q <= 255 && dequant(ss, sz, q) == v) {
+                                ents.push_back({uint16_t(c), uint8_t(q)});
+                                coded = true;
+                            }
+                        }
+                    }
+                    if (!coded) rb.exc.push_back({uint16_t(c), uint16_t(rho), v});
+                }
+                if (bit) {
+                    const uint32_t p = c / 512, cc = c % 512, i = cc / 128, l2 = (cc % 128) / 2, e = cc & 1;
+                    tile[(size_t(p) * 64 + l2) * 4 + i] |= 1u << bit_index(rho, int(e));
+                }
+            }
+            nnz += ents.size();
+            // greedy chunking: close at 16 entries or when the next step exceeds 255
+            size_t i = 0;
+            uint16_t nfull = 0, ntail = 0;
+            while (i < ents.size()) {
+                size_t j = i + 1;
+                while (j < ents.size() && j - i < 16 && ents[j].col - ents[j - 1].col <= 255) ++j;
+                const size_t cnt = j - i;
+                uint8_t d[16] = {0}, q[16] = {0};
+                for (size_t k = 0; k < cnt; ++k) {
+                    d[k] = k ? uint8_t(ents[i + k].col - ents[i + k - 1].col) : 0;
+                    q[k] = ents[i + k].code;
+                }
+                if (cnt == 16) {
+                    rb.col0_full.push_back(ents[i].col);
+                    rb.delta_full.insert(rb.delta_full.end(), d, d + 16);
+                    rb.code_full.insert(rb.code_full.end(), q, q + 16);
+                    ++nfull;
+                } else {
+                    rb.col0_tail.push_back(ents[i].col);
+                    rb.delta_tail.insert(rb.delta_tail.end(), d, d + 16);
+                    rb.code_tail.insert(rb.code_tail.end(), q, q + 16);
+                    rb.tailcnt.push_back(uint8_t(cnt));
+                    ++ntail;
+                }
+                i = j;
+            }
+            if (ntail > 255) return PBL_ERR_UNSUPPORTED;
+            rb.ri[rho].nfull = nfull;
+            rb.ri[rho].ntail = uint8_t(ntail);
+        }
+
+        const size_t nfull = rb.col0_full.size(), ntail = rb.col0_tail.size(), nch = nfull + ntail;
+        if (nch > 65535) return PBL_ERR_UNSUPPORTED;
+        const size_t rec_bytes = fixed + record_sal_bytes(nch, ntail, rb.exc.size());
+        rb_off[b] = uint32_t(cur / 16);
+        max_nch = std::max<uint32_t>(max_nch, uint32_t(nch));
+        max_nexc = std::max<uint32_t>(max_nexc, uint32_t(rb.exc.size()));
+        nexc_total += rb.exc.size();
+        if (blob) {
+            if (cur + rec_bytes > cap) return PBL_ERR_CAPACITY;
+            uint8_t* rec = blob + cur;
+            std::memset(rec, 0, rec_bytes);
+            pbl_rec_header h = {uint32_t(nfull), uint32_t(ntail), uint32_t(rb.exc.size()), uint32_t(fixed)};
+            std::memcpy(rec, &h, sizeof(h));
+            std::memcpy(rec + 16, rb.ri, sizeof(rb.ri));
+            std::memcpy(rec + 16 + 128, params, sizeof(params));
+            if (G > 1) std::memcpy(rec + 400, ghl.data(), ghl.size() * 4);
+            std::memcpy(rec + tiles_off, tile.data(), tile.size() * 4);
+            uint8_t* s = rec + fixed;
+            uint16_t* col0 = reinterpret_cast<uint16_t*>(s);
+            for (size_t k = 0; k < nfull; ++k) col0[k] = rb.col0_full[k];
+            for (size_t k = 0; k < ntail; ++k) col0[nfull + k] = rb.col0_tail[k];
+            s += align16(nch * 2);
+            if (nfull) std::memcpy(s, rb.delta_full.data(), nfull * 16);
+            if (ntail) std::memcpy(s + nfull * 16, rb.delta_tail.data(), ntail * 16);
+            s += nch * 16;
+            if (nfull) std::memcpy(s, rb.code_full.data(), nfull * 16);
+            if (ntail) std::memcpy(s + nfull * 16, rb.code_tail.data(), ntail * 16);
+            s += nch * 16;
+            if (ntail) std::memcpy(s, rb.tailcnt.data(), ntail);
+            s += align16(ntail);
+            if (!rb.exc.empty()) std::memcpy(s, rb.exc.data(), rb.exc.size() * sizeof(pbl_exception));
+        }
+        cur += rec_bytes;
+    }
+    rb_off[NRB] = uint32_t(cur / 16);
+    *out_bytes = cur;
+    if (blob) {
+        if (cur > cap) return PBL_ERR_CAPACITY;
+        pbl_blob_header h;
+        std::memset(&h, 0, sizeof(h));
+        h.magic = PBL_MAGIC; h.version = PBL_VERSION; h.N = N; h.K = K; h.P = P; h.G = G; h.NRB = NRB;
+        h.flags = G > 1 ? PBL_FLAG_HAS_GROUPS : 0;
+        h.max_nch = max_nch; h.max_nexc = max_nexc; h.nnz = nnz; h.nexc = nexc_total;
+        h.blob_bytes = cur; h.rb_off_pos = uint32_t(rboff_pos);
+        std::memcpy(blob, &h, sizeof(h));
+        std::memset(blob + rboff_pos, 0, rec0 - rboff_pos);
+        std::memcpy(blob + rboff_pos, rb_off.data(), rb_off.size() * 4);
+    }
+    return PBL_OK;
+}
+
+int pbl_blob_describe(const void* host_blob, size_t bytes, pbl_layer* out) {
+    if (!host_blob || !out || bytes < sizeof(pbl_blob_header)) return PBL_ERR_INVALID_ARG;
+    pbl_blob_header h;
+    std::memcpy(&h, host_blob, sizeof(h));
+    if (h.magic != PBL_MAGIC || h.version != PBL_VERSION || h.blob_bytes != bytes) return PBL_ERR_BAD_BLOB;
+    if (h.P != (h.K + 511) / 512 || h.NRB != (h.N + 15) / 16 || h.G == 0) return PBL_ERR_BAD_BLOB;
+    out->blob = nullptr; out->bias = nullptr;
+    out->N = h.N; out->K = h.K; out->P = h.P; out->G = h.G; out->NRB = h.NRB; out->flags = h.flags;
+    out->max_nch = h.max_nch; out->max_nexc = h.max_nexc;
+    return PBL_OK;
+}
+
+int pbl_unpack_dense_f32(const void* host_blob, size_t bytes, float* Wout) {
+    pbl_layer L;
+    int st = pbl_blob_describe(host_blob, bytes, &L);
+    if (st != PBL_OK) return st;
+    if (!Wout) return PBL_ERR_INVALID_ARG;
+    const uint8_t* blob = static_cast<const uint8_t*>(host_blob);
+    pbl_blob_header h;
+    std::memcpy(&h, blob, sizeof(h));
+    const uint32_t* rb_off = reinterpret_cast<const uint32_t*>(blob + h.rb_off_pos);
+    const uint32_t N = L.N, K = L.K, G = L.G, P = L.P, gs = K / G;
+    const size_t fixed = record_fixed_bytes(P, G), tiles_off = fixed - size_t(P) * 1024;
+    for (uint32_t b = 0; b < L.NRB; ++b) {
+        const uint8_t* rec = blob + size_t(rb_off[b]) * 16;
+        pbl_rec_header rh;
+        std::memcpy(&rh, rec, sizeof(rh));
+        const pbl_rowinfo* ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16);
+        const pbl_rowparams* pr = reinterpret_cast<const pbl_rowparams*>(rec + 144);
+        const float* ghl = reinterpret_cast<const float*>(rec + 400);
+        const uint32_t* tile = reinterpret_cast<const uint32_t*>(rec + tiles_off);
+        const size_t nch = size_t(rh.nfull) + rh.ntail;
+        const uint8_t* s = rec + rh.off_sal;
+        const uint16_t* col0 = reinterpret_cast<const uint16_t*>(s);
+        const uint8_t* delta = s + align16(nch * 2);
+        const uint8_t* code = delta + nch * 16;
+        const uint8_t* tailcnt = code + nch * 16;
+        const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(tailcnt + align16(rh.ntail));
+        for (int rho = 0; rho < 16; ++rho) {
+            const uint32_t r = b * 16 + rho;
+            if (r >= N) continue;
+            float* w = Wout + size_t(r) * K;
+            for (uint32_t c = 0; c < K; ++c) {
+                const uint32_t p = c / 512, cc = c % 512, i = cc / 128, l2 = (cc % 128) / 2, e = cc & 1;
+                const uint32_t word = tile[(size_t(p) * 64 + l2) * 4 + i];
+                const int bit = (word >> bit_index(rho, int(e))) & 1;
+                const uint32_t g = c / gs;
+                const float hv = G > 1 ? ghl[(size_t(rho) * G + g) * 2] : pr[rho].hi;
+                const float lv = G > 1 ? ghl[(size_t(rho) * G + g) * 2 + 1] : pr[rho].lo;
+                w[c] = bit ? hv : lv;
+            }
+            auto apply = [&](size_t ch, int cnt) {
+                uint32_t col = col0[ch];
+                for (int k = 0; k < cnt; ++k) {
+                    col += delta[ch * 16 + k];
+                    if (col < K) w[col] = dequant(pr[rho].sscale, pr[rho].szero, code[ch * 16 + k]);
+                }
+            };
+            for (uint32_t k = 0; k < ri[rho].nfull; ++k) apply(size_t(ri[rho].start) + k, 16);
+            for (uint32_t k = 0; k < ri[rho].ntail; ++k)
+                apply(size_t(rh.nfull) + ri[rho].tailidx + k, tailcnt[ri[rho].tailidx + k]);
+        }
+        for (uint32_t k = 0; k < rh.nexc; ++k) {
+            const uint32_t r = b * 16 + exc[k].row;
+            if (r < N && exc[k].col < K) Wout[size_t(r) * K + exc[k].col] = exc[k].value;
+        }
+    }
+    return PBL_OK;
+}
+
+}  // extern "C"

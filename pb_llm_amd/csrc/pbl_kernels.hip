@@ -1,0 +1,401 @@
+// pbl_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of libpbl.so.
+//
+// One kernel family: the partially-binarized GEMV
+//     y[m, r] = sum_j v_rj * x[m, j] + bias_r            (m <= 4 tokens per pass)
+// over the PBL1 packed format (include/pbl.h).  It replaces the reference's
+//     w_sim = where(mask, W*outlier_scale, sign(W)*binary_scale); F.linear(x, w_sim, b)
+// (quant/outlier_quantizer.py:83-106) and the stock nn.Linear forward over GPTQ-PB
+// fake-quant weights (gptq_pb/gptq.py:180-184).
+//
+// Work decomposition: ONE WAVEFRONT (64 lanes) owns ONE RECORD = 16 output rows.
+//   phase 0  the workgroup stages x (fp16) into LDS, zero padded
+//   phase 1  sign plane: per 512-column panel one coalesced 1 KiB global_load_dwordx4
+//            per wave; lane l holds x for ITS columns in 4 VGPRs (half2), unpacks a
+//            pair of weights to a two-valued fp16 constant with ONE v_and(_or)_b32
+//            ("bit classes") and accumulates with v_dot2_f32_f16
+//   phase 2  salient list: lane-per-chunk (16 delta-coded columns + 16 uint8 codes,
+//            coalesced 16 B/lane loads), x gathered from LDS
+//   phase 3  transpose-reduce the 16 row accumulators across the wave, combine
+//            with the per-chunk partials in fixed order (deterministic), store y.
+// HBM-bound by design: every weight byte is read exactly once, x comes from L2/LDS.
+// No inter-workgroup communication, so no XCD-placement dependence.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pbl.h"
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define PBL_WAVE 64
+
+namespace {
+
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), c, false);
+}
+
+__device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, PBL_WAVE); }
+
+// Bit classes 8..15 of an fp16 half-word: pair mask M and OR-constant C such that
+// (w & M) | C is an fp16x2 holding {lo_c, lo_c + d_c} per element.  The signed
+// sum over a lane's columns is  D = A_c * acc - B_c * Xl  (Xl = plain sum of x).
+//   c=8 : {1,1.25}  c=9 : {1,1.5}  c=10..14 : {0, 2^-14, 2^-13, 2^-11, 2^-7, 2}  c=15 : {1,-1}
+template <int CI> struct BitClass;
+#define PBL_CLASS(ci, m, c) \
+    template <> struct BitClass<ci> { static constexpr uint32_t M = m, C = c; };
+PBL_CLASS(0, 0x01000100u, 0x3C003C00u)
+PBL_CLASS(1, 0x02000200u, 0x3C003C00u)
+PBL_CLASS(2, 0x04000400u, 0u)
+PBL_CLASS(3, 0x08000800u, 0u)
+PBL_CLASS(4, 0x10001000u, 0u)
+PBL_CLASS(5, 0x20002000u, 0u)
+PBL_CLASS(6, 0x40004000u, 0u)
+PBL_CLASS(7, 0x80008000u, 0x3C003C00u)
+#undef PBL_CLASS
+
+__device__ __forceinline__ void class_consts(int ci, float& A, float& B) {
+    const float a[8] = {8.f, 4.f, 32768.f, 16384.f, 4096.f, 256.f, 1.f, -1.f};
+    const float b[8] = {9.f, 5.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.f};
+    A = a[0]; B = b[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { A = ci == k ? a[k] : A; B = ci == k ? b[k] : B; }
+}
+
+template <int MB, int CI>
+__device__ __forceinline__ void class_step(uint32_t w, uint32_t ws, const uint32_t (&xr)[MB],
+                                           float (&acc)[MB][16]) {
+    const uint32_t t0 = (w & BitClass<CI>::M) | BitClass<CI>::C;
+    const uint32_t t1 = (ws & BitClass<CI>::M) | BitClass<CI>::C;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        acc[m][CI] = dot2(t0, xr[m], acc[m][CI]);
+        acc[m][8 + CI] = dot2(t1, xr[m], acc[m][8 + CI]);
+    }
+}
+
+template <int MB>
+__device__ __forceinline__ void word_step(uint32_t w, const uint32_t (&xr)[MB], float (&acc)[MB][16],
+                                          float (&xl)[MB]) {
+    const uint32_t ws = w << 8;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) xl[m] = dot2(0x3C003C00u, xr[m], xl[m]);
+    class_step<MB, 0>(w, ws, xr, acc);
+    class_step<MB, 1>(w, ws, xr, acc);
+    class_step<MB, 2>(w, ws, xr, acc);
+    class_step<MB, 3>(w, ws, xr, acc);
+    class_step<MB, 4>(w, ws, xr, acc);
+    class_step<MB, 5>(w, ws, xr, acc);
+    class_step<MB, 6>(w, ws, xr, acc);
+    class_step<MB, 7>(w, ws, xr, acc);
+}
+
+// 16 per-lane accumulators -> lane l holds the wave total of row
+//   rho(l) = 8*bit5(l) + 4*bit4(l) + 2*bit3(l) + bit2(l)   (4 lanes per row).
+__device__ __forceinline__ float transpose_reduce16(const float (&a)[16], int lane) {
+    float v[8], u[4], t[2];
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float send = b5 ? a[j] : a[j + 8], keep = b5 ? a[j + 8] : a[j];
+        v[j] = keep + shfl_xor(send, 32);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float send = b4 ? v[j] : v[j + 4], keep = b4 ? v[j + 4] : v[j];
+        u[j] = keep + shfl_xor(send, 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float send = b3 ? u[j] : u[j + 2], keep = b3 ? u[j + 2] : u[j];
+        t[j] = keep + shfl_xor(send, 8);
+    }
+    const float send = b2 ? t[0] : t[1], keep = b2 ? t[1] : t[0];
+    float s = keep + shfl_xor(send, 4);
+    s += shfl_xor(s, 1);
+    s += shfl_xor(s, 2);
+    return s;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+    return v;
+}
+
+struct GemvArgs {
+    pbl_layer layer;      // single-layer launch: by value
+    const _Float16* x;    // [M, K]
+    void* y;              // [M, N] fp16 or fp32
+    // grouped launch: device arrays
+    const pbl_layer* layers;
+    const void* const* xs;
+    void* const* ys;
+    int M;                // tokens in this pass (== MB)
+    int y_f32;
+    int grouped;
+};
+
+// One salient chunk (lane-private): 16 delta-coded columns + 16 codes.
+template <int MB, bool PRED>
+__device__ __forceinline__ void chunk_accumulate(const _Float16* xs, int xstride, uint32_t col0,
+                                                 const u32x4& d4, const u32x4& q4, int cnt, int zpos,
+                                                 float (&Q)[MB], float (&S)[MB]) {
+    uint32_t col = col0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t dw = d4[k >> 2], qw = q4[k >> 2];
+        col += (dw >> (8 * (k & 3))) & 0xFFu;
+        const uint32_t a = PRED ? (k < cnt ? col : uint32_t(zpos)) : col;
+        const float qf = float((qw >> (8 * (k & 3))) & 0xFFu);
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const float xv = float(xs[m * xstride + a]);
+            Q[m] = fmaf(qf, xv, Q[m]);
+            S[m] += xv;
+        }
+    }
+}
+
+template <int MB, int WPB>
+__global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    pbl_layer L;
+    const _Float16* xg;
+    void* yg;
+    if (args.grouped) {
+        L = args.layers[blockIdx.y];
+        xg = static_cast<const _Float16*>(args.xs[blockIdx.y]);
+        yg = args.ys[blockIdx.y];
+    } else {
+        L = args.layer; xg = args.x; yg = args.y;
+    }
+    const uint32_t rb0 = blockIdx.x * WPB;
+    if (rb0 >= L.NRB) return;  // whole workgroup exits together (grouped launches over-provision)
+
+    const int K = int(L.K), P = int(L.P);
+    const int Kp = P * PBL_PANEL_COLS;
+    const int xstride = Kp + 8;            // halves per token in LDS; [K, Kp+8) is zero
+    _Float16* xs = reinterpret_cast<_Float16*>(smem);
+    float2* part_all = reinterpret_cast<float2*>(smem + ((size_t(MB) * xstride * 2 + 15) & ~size_t(15)));
+
+    // ---- phase 0: stage x ---------------------------------------------------------
+    {
+        const int nthr = WPB * PBL_WAVE;
+        if ((K & 7) == 0 && (reinterpret_cast<uintptr_t>(xg) & 15) == 0) {
+            const int nv = K >> 3;
+            for (int m = 0; m < MB; ++m) {
+                const u32x4* src = reinterpret_cast<const u32x4*>(xg + size_t(m) * K);
+                u32x4* dst = reinterpret_cast<u32x4*>(xs + m * xstride);
+                for (int i = tid; i < nv; i += nthr) dst[i] = src[i];
+            }
+        } else {
+            for (int m = 0; m < MB; ++m)
+                for (int i = tid; i < K; i += nthr) xs[m * xstride + i] = xg[size_t(m) * K + i];
+        }
+        for (int m = 0; m < MB; ++m)
+            for (int i = K + tid; i < xstride; i += nthr) xs[m * xstride + i] = _Float16(0);
+    }
+    __syncthreads();
+
+    const uint32_t rb = rb0 + wave;
+    if (rb >= L.NRB) return;  // no barriers below this point
+
+    const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
+    const uint32_t* rb_off = reinterpret_cast<const uint32_t*>(blob + sizeof(pbl_blob_header));
+    const uint8_t* rec = blob + size_t(__builtin_amdgcn_readfirstlane(rb_off[rb])) * 16;
+    const pbl_rec_header rh = *reinterpret_cast<const pbl_rec_header*>(rec);
+    const int nfull = __builtin_amdgcn_readfirstlane(rh.nfull);
+    const int ntail = __builtin_amdgcn_readfirstlane(rh.ntail);
+    const int nexc = __builtin_amdgcn_readfirstlane(rh.nexc);
+    const uint32_t off_sal = __builtin_amdgcn_readfirstlane(rh.off_sal);
+    const int nch = nfull + ntail;
+    const uint32_t tiles_off = off_sal - uint32_t(P) * 1024u;
+
+    // ---- phase 1: sign plane ------------------------------------------------------
+    float acc[MB][16];
+    float xl[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        xl[m] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    }
+    {
+        const u32x4* tiles = reinterpret_cast<const u32x4*>(rec + tiles_off) + lane;
+        u32x4 cur = __builtin_nontemporal_load(tiles);
+        for (int p = 0; p < P; ++p) {
+            u32x4 nxt = cur;
+            if (p + 1 < P) nxt = __builtin_nontemporal_load(tiles + (p + 1) * 64);
+            const uint32_t* xw = reinterpret_cast<const uint32_t*>(xs + p * PBL_PANEL_COLS) + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint32_t xr[MB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) xr[m] = xw[(m * xstride) / 2 + i * 64];
+                word_step<MB>(cur[i], xr, acc, xl);
+            }
+            cur = nxt;
+        }
+    }
+
+    // ---- phase 2: salient chunks --------------------------------------------------
+    float2* part = part_all + size_t(wave) * L.max_nch * MB;
+    {
+        const uint8_t* s = rec + off_sal;
+        const uint16_t* col0p = reinterpret_cast<const uint16_t*>(s);
+        const u32x4* deltap = reinterpret_cast<const u32x4*>(s + ((size_t(nch) * 2 + 15) & ~size_t(15)));
+        const u32x4* codep = deltap + nch;
+        const uint8_t* tailcnt = reinterpret_cast<const uint8_t*>(codep + nch);
+        for (int base = 0; base < nch; base += PBL_WAVE) {
+            const int c = base + lane;
+            const bool valid = c < nch;
+            const int cc = valid ? c : nch - 1;
+            const uint32_t c0 = col0p[cc];
+            const u32x4 d4 = __builtin_nontemporal_load(deltap + cc);
+            const u32x4 q4 = __builtin_nontemporal_load(codep + cc);
+            float Q[MB], S[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { Q[m] = 0.f; S[m] = 0.f; }
+            if (base + PBL_WAVE <= nfull) {
+                chunk_accumulate<MB, false>(xs, xstride, c0, d4, q4, 16, Kp, Q, S);
+            } else {
+                int cnt = 16;
+                if (cc >= nfull) cnt = tailcnt[cc - nfull];
+                if (!valid) cnt = 0;
+                chunk_accumulate<MB, true>(xs, xstride, c0, d4, q4, cnt, Kp, Q, S);
+            }
+            if (valid) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m) part[size_t(m) * L.max_nch + c] = make_float2(Q[m], S[m]);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 3: reduce, combine, store -------------------------------------------
+    const int rho = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    const int sub = lane & 3;
+    const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16)[rho];
+    const pbl_rowparams pr = reinterpret_cast<const pbl_rowparams*>(rec + 144)[rho];
+    float A, B;
+    class_consts(rho & 7, A, B);
+    const float alpha = 0.5f * (pr.hi - pr.lo), mu = 0.5f * (pr.hi + pr.lo);
+    const uint32_t row = rb * 16 + rho;
+    const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(
+        rec + off_sal + ((size_t(nch) * 2 + 15) & ~size_t(15)) + size_t(nch) * 32 + ((size_t(ntail) + 15) & ~size_t(15)));
+
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        const float X = wave_sum(xl[m]);
+        const float accsum = transpose_reduce16(acc[m], lane);
+        float Q = 0.f, S = 0.f;
+        const float2* pm = part + size_t(m) * L.max_nch;
+        for (int k = sub; k < int(ri.nfull); k += 4) {
+            const float2 v = pm[ri.start + k];
+            Q += v.x; S += v.y;
+        }
+        for (int k = sub; k < int(ri.ntail); k += 4) {
+            const float2 v = pm[nfull + ri.tailidx + k];
+            Q += v.x; S += v.y;
+        }
+        Q += shfl_xor(Q, 1); S += shfl_xor(S, 1);
+        Q += shfl_xor(Q, 2); S += shfl_xor(S, 2);
+        float e = 0.f;
+        for (int k = 0; k < nexc; ++k) {
+            const pbl_exception ex = exc[k];
+            if (ex.row == rho) e += (ex.value - pr.hi) * float(xs[m * xstride + ex.col]);
+        }
+        const float D = A * accsum - B * X;
+        float yv = alpha * D + mu * X + (pr.sscale * (Q - pr.szero * S) - pr.hi * S) + e;
+        if (L.bias && row < L.N) yv += L.bias[row];
+        if (sub == 0 && row < L.N) {
+            if (args.y_f32) static_cast<float*>(yg)[size_t(m) * L.N + row] = yv;
+            else static_cast<_Float16*>(yg)[size_t(m) * L.N + row] = _Float16(yv);
+        }
+    }
+}
+
+size_t lds_bytes(uint32_t P, uint32_t max_nch, int mb, int wpb) {
+    const size_t xstride = size_t(P) * PBL_PANEL_COLS + 8;
+    size_t s = (size_t(mb) * xstride * 2 + 15) & ~size_t(15);
+    s += size_t(wpb) * max_nch * mb * sizeof(float2);
+    return s + 16;
+}
+
+template <int MB, int WPB>
+int launch(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    auto k = pbl_gemv_kernel<MB, WPB>;
+    if (lds > 64 * 1024) {
+        if (lds > 160 * 1024) return PBL_ERR_UNSUPPORTED;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(lds)) != hipSuccess)
+            return PBL_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(WPB * PBL_WAVE), lds, st, a);
+    return hipGetLastError() == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+template <int WPB>
+int launch_mb(int mb, const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    switch (mb) {
+        case 1: return launch<1, WPB>(a, grid, lds, st);
+        case 2: return launch<2, WPB>(a, grid, lds, st);
+        case 3: return launch<3, WPB>(a, grid, lds, st);
+        case 4: return launch<4, WPB>(a, grid, lds, st);
+        default: return PBL_ERR_INVALID_ARG;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pbl_gemv_lds_bytes(const pbl_layer* layer, int m) {
+    if (!layer || m < 1 || m > PBL_MAX_TOKENS_PER_LAUNCH) return 0;
+    return lds_bytes(layer->P, layer->max_nch, m, 4);
+}
+
+int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream) {
+    if (!layer || !layer->blob || !x || !y || M < 1) return PBL_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
+    if (layer->G != 1) return PBL_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // wide workgroups only when there are enough records to still fill 256 CUs
+    const int wpb = layer->NRB >= 1024 ? 4 : 1;
+    const size_t esz = y_f32 ? 4 : 2;
+    for (int m0 = 0; m0 < M; m0 += PBL_MAX_TOKENS_PER_LAUNCH) {
+        const int mb = M - m0 < PBL_MAX_TOKENS_PER_LAUNCH ? M - m0 : PBL_MAX_TOKENS_PER_LAUNCH;
+        GemvArgs a{};
+        a.layer = *layer;
+        a.x = static_cast<const _Float16*>(x) + size_t(m0) * layer->K;
+        a.y = static_cast<char*>(y) + size_t(m0) * layer->N * esz;
+        a.M = mb; a.y_f32 = y_f32; a.grouped = 0;
+        const dim3 grid((layer->NRB + wpb - 1) / wpb, 1, 1);
+        const size_t lds = lds_bytes(layer->P, layer->max_nch, mb, wpb);
+        const int rc = wpb == 4 ? launch_mb<4>(mb, a, grid, lds, st) : launch_mb<1>(mb, a, grid, lds, st);
+        if (rc != PBL_OK) return rc;
+    }
+    return PBL_OK;
+}
+
+int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, void* const* y_dev, int Lc,
+                         int M, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch, uint32_t max_nexc,
+                         int any_groups, void* stream) {
+    (void)max_nexc;
+    if (!layers_dev || !x_dev || !y_dev || Lc < 1 || M < 1 || M > PBL_MAX_TOKENS_PER_LAUNCH)
+        return PBL_ERR_INVALID_ARG;
+    if (any_groups || Lc > 65535) return PBL_ERR_UNSUPPORTED;
+    GemvArgs a{};
+    a.layers = layers_dev; a.xs = x_dev; a.ys = y_dev; a.M = M; a.y_f32 = 0; a.grouped = 1;
+    const int wpb = 4;
+    const uint32_t P = (max_K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS;
+    const dim3 grid((max_NRB + wpb - 1) / wpb, Lc, 1);
+    return launch_mb<4>(M, a, grid, lds_bytes(P, max_nch, M, wpb), static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

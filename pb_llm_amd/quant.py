@@ -1,0 +1,389 @@
+"""nn.Linear-compatible modules with the reference's names and constructors, backed
+by the MI355X HIP kernel (libpbl.so) instead of a dense simulated weight.
+
+Mirrors /root/reference/quant/{quantizer,outlier_quantizer}.py:
+    BinaryInterface                         quant/quantizer.py:70-72
+    BinaryLinear(weight, bias)              quant/quantizer.py:75-86
+    XnorBinaryLinear(weight, bias)          quant/quantizer.py:172-193
+    BinaryXnorExceptOutliersLinear(weight, bias, outlier_fraction, outlier_scale=1,
+                                   train_outlier=False)   quant/outlier_quantizer.py:33-123
+    BinaryXnorExceptOutliersLinearHessian   quant/outlier_quantizer.py:126-143
+and adds PBLinear.from_dense / from_quantizers for GPTQ-PB fake-quant weights
+(gptq_pb/gptq.py:155,180-184).  Forward is inference-only (no autograd); there is
+no CPU fallback: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .packing import PackedWeight, infer_code_grid, infer_levels, pack_dense
+
+
+class BinaryInterface:
+    """Marker base (quant/quantizer.py:70-72)."""
+
+    def get_save_weight_dict(self):
+        return {"weight": self.weight.data.half().cpu(), "bias": self.bias}
+
+
+def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: torch.Tensor) -> torch.Tensor:
+    """y = F.linear(x, w_sim, bias) through libpbl (pbl_linear_f16).  x [..., K] on
+    the GPU, fp16 (native) or fp32/bf16 (split into two fp16 terms, fp32 output)."""
+    if not x.is_cuda:
+        raise _lib.PblError("PB linear forward needs a GPU tensor: the HIP kernel is the only compute path")
+    if x.shape[-1] != packed.K:
+        raise ValueError(f"in_features mismatch: x has {x.shape[-1]}, layer has {packed.K}")
+    if packed.blob.device != x.device:
+        raise _lib.PblError("packed weight and input are on different devices")
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, packed.K)
+    M = x2.shape[0]
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    layer = packed.layer_struct(bias_f32)
+    L = _lib.lib()
+    if M == 0:
+        return x.new_zeros(*lead, packed.N)
+    if x.dtype == torch.float16:
+        xc = x2.contiguous()
+        y = torch.empty(M, packed.N, dtype=torch.float16, device=x.device)
+        _lib.check(L.pbl_linear_f16(C.byref(layer), xc.data_ptr(), y.data_ptr(), M, 0, stream), "linear")
+        return y.reshape(*lead, packed.N)
+    # fp32 / bf16 activations: x = x_hi + x_lo with both terms fp16; the kernel is
+    # linear in x, so y = W x_hi + W x_lo accumulated in fp32 (bias added once).
+    xf = x2.float()
+    x_hi = xf.half()
+    x_lo = (xf - x_hi.float()).half()
+    xx = torch.cat([x_hi, x_lo], 0).contiguous()
+    y = torch.empty(2 * M, packed.N, dtype=torch.float32, device=x.device)
+    layer_nb = packed.layer_struct(None)
+    _lib.check(L.pbl_linear_f16(C.byref(layer_nb), xx.data_ptr(), y.data_ptr(), 2 * M, 1, stream), "linear")
+    out = y[:M] + y[M:]
+    if bias_f32 is not None:
+        out = out + bias_f32
+    return out.to(x.dtype).reshape(*lead, packed.N)
+
+
+class PBLinear(nn.Module, BinaryInterface):
+    """Packed partially-binarized linear layer.  Holds the PBL1 blob as a buffer so
+    .to(device) / state_dict() work; `weight` is a dense view materialised on demand."""
+
+    def __init__(self, packed: PackedWeight, bias: torch.Tensor | None = None, dtype=torch.float16):
+        super().__init__()
+        self.in_features, self.out_features = packed.K, packed.N
+        self._meta = packed
+        self.register_buffer("pbl_blob", packed.blob)
+        self.register_buffer("pbl_bias", bias.detach().float().clone() if bias is not None else None)
+        self.weight_dtype = dtype
+        self.global_name = None
+
+    # -- construction ---------------------------------------------------------------
+    @classmethod
+    def from_dense(cls, W_fq: torch.Tensor, bias=None, low_mask=None, groupsize: int = -1,
+                   high_scale=None, high_zero=None):
+        """From a dense fake-quant weight as gptq_pb writes it back (gptq.py:180-184).
+        low_mask (True = binarized, gptq.py:92,99) and the HighQuantizer scale/zero are
+        optional: without them the structure is inferred from the values."""
+        Wn = W_fq.detach().cpu().float().numpy()
+        lm = low_mask.detach().cpu().numpy().astype(bool) if isinstance(low_mask, torch.Tensor) else low_mask
+        hi, lo = infer_levels(Wn, groupsize, lm)
+        if high_scale is not None:
+            ss = np.asarray(high_scale.detach().cpu().numpy() if isinstance(high_scale, torch.Tensor) else high_scale,
+                            np.float32).reshape(-1)
+            sz = np.asarray(high_zero.detach().cpu().numpy() if isinstance(high_zero, torch.Tensor) else high_zero,
+                            np.float32).reshape(-1)
+        else:
+            ss, sz = infer_code_grid(Wn, hi, lo, groupsize)
+        sal = (~lm).astype(np.uint8) if lm is not None else None
+        return cls(pack_dense(Wn, hi, lo, ss, sz, sal), bias, W_fq.dtype)
+
+    @classmethod
+    def from_quantizers(cls, W: torch.Tensor, low_mask: torch.Tensor, mean, scale, hscale, hzero,
+                        bias=None, groupsize: int = -1, maxq: int = 255, dtype=torch.float16):
+        """From the PTQ quantizer state (LowQuantizer.mean/scale [G,N,1],
+        HighQuantizer.scale/zero [N,1]) and the ORIGINAL weights: composes
+        q = q_high*~mask + q_low*mask (gptq.py:119-127) and packs it."""
+        Wf = W.detach().cpu().float()
+        N, K = Wf.shape
+        gs = K if groupsize == -1 else groupsize
+        G = (K + gs - 1) // gs
+        mean = torch.as_tensor(mean).float().reshape(G, N, 1)
+        scale = torch.as_tensor(scale).float().reshape(G, N, 1)
+        hs = torch.as_tensor(hscale).float().reshape(N, 1)
+        hz = torch.as_tensor(hzero).float().reshape(N, 1)
+        lm = low_mask.cpu().bool()
+        out = torch.empty_like(Wf)
+        hi = torch.empty(N, G)
+        lo = torch.empty(N, G)
+        for g in range(G):
+            sl = slice(g * gs, min((g + 1) * gs, K))
+            w = Wf[:, sl]
+            q_high = hs * (torch.clamp(torch.round(w / hs) + hz, 0, maxq) - hz)
+            q_low = torch.sign(w - mean[g]) * scale[g] + mean[g]
+            out[:, sl] = q_high * ~lm[:, sl] + q_low * lm[:, sl]
+            hi[:, g] = (scale[g] + mean[g]).reshape(-1)
+            lo[:, g] = (-scale[g] + mean[g]).reshape(-1)
+        if dtype == torch.float16:  # the reference stores the result in the checkpoint dtype
+            out, hi, lo = out.half().float(), hi.half().float(), lo.half().float()
+        packed = pack_dense(out.numpy(), hi.numpy(), lo.numpy(), hs.reshape(-1).numpy(), hz.reshape(-1).numpy(),
+                            (~lm).numpy().astype(np.uint8))
+        return cls(packed, bias, dtype)
+
+    # -- nn.Linear surface ----------------------------------------------------------
+    @property
+    def packed(self) -> PackedWeight:
+        m = self._meta
+        if m.blob is not self.pbl_blob:  # the buffer moved (.to / .cuda / load_state_dict)
+            m = PackedWeight(self.pbl_blob, m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch, m.max_nexc, m.nnz, m.nexc)
+            self._meta = m
+        return m
+
+    @property
+    def weight(self) -> torch.Tensor:
+        return self.packed.unpack().to(self.weight_dtype)
+
+    @property
+    def bias(self):
+        return self.pbl_bias
+
+    def forward(self, x):
+        return pb_linear_forward(self.packed, self.pbl_bias, x)
+
+    def to_regular_linear(self) -> nn.Linear:
+        lin = nn.Linear(self.in_features, self.out_features, bias=self.pbl_bias is not None)
+        lin.weight.data = self.weight
+        if self.pbl_bias is not None:
+            lin.bias.data = self.pbl_bias.to(self.weight_dtype).cpu()
+        return lin
+
+    def extra_repr(self):
+        p = self._meta
+        return (f"in_features={p.K}, out_features={p.N}, bias={self.pbl_bias is not None}, groups={p.G}, "
+                f"salient={p.nnz} ({p.nnz / (p.N * p.K):.3%}), exceptions={p.nexc}, packed_bytes={p.nbytes}")
+
+
+def _pack_sign_like(w_sim: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor) -> PackedWeight:
+    """Fully binarized variants: anything that is neither level (sign(0) == 0) is a
+    code entry with value 0 (sscale=1, szero=0, q=0)."""
+    N = w_sim.shape[0]
+    return pack_dense(w_sim, hi.reshape(N, 1), lo.reshape(N, 1), np.ones(N, np.float32), np.zeros(N, np.float32))
+
+
+class _DenseBacked(nn.Module, BinaryInterface):
+    """Shared plumbing: keeps the reference's `weight`/`bias` Parameters and packs lazily."""
+
+    def _pack(self) -> PackedWeight:
+        raise NotImplementedError
+
+    def _packed_on(self, device) -> PackedWeight:
+        p = getattr(self, "_packed", None)
+        if p is None:
+            p = self._pack()
+        if p.blob.device != device:
+            p = p.to(device)
+        self._packed = p
+        return p
+
+    def invalidate(self):
+        self._packed = None
+
+    def _bias_f32(self, device):
+        return self.bias.detach().float().to(device) if self.bias is not None else None
+
+    def forward(self, x):
+        return pb_linear_forward(self._packed_on(x.device), self._bias_f32(x.device), x)
+
+
+class BinaryLinear(_DenseBacked):
+    """y = x sign(W)^T + b (quant/quantizer.py:75-86).  fp32 Parameters like the reference."""
+
+    def __init__(self, weight, bias) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(weight.to(torch.float32).data)
+        self.bias = nn.Parameter(bias.to(torch.float32).data) if bias is not None else None
+        self._packed = None
+
+    def quant_weight(self):
+        return self.weight.detach().sign()
+
+    def _pack(self):
+        w = self.quant_weight().cpu()
+        one = torch.ones(w.shape[0])
+        return _pack_sign_like(w, one, -one)
+
+
+class XnorBinaryLinear(_DenseBacked):
+    """w = sign(W - rowmean) * mean|W - rowmean| (quant/quantizer.py:172-193)."""
+
+    def __init__(self, weight, bias) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(weight.to(torch.float32).data)
+        self.bias = nn.Parameter(bias.to(torch.float32).data) if bias is not None else None
+        self._packed = None
+
+    def quant_weight(self, outlier_mask=None):
+        w = self.weight.detach()
+        w = w - w.mean(-1).view(-1, 1)
+        if outlier_mask is not None:
+            w = w * (~outlier_mask)
+        scaling_factor = w.abs().mean(-1).view(-1, 1)
+        return w.sign() * scaling_factor
+
+    def _pack(self):
+        w = self.weight.detach().cpu()
+        wc = w - w.mean(-1).view(-1, 1)
+        alpha = wc.abs().mean(-1)
+        return _pack_sign_like(wc.sign() * alpha.view(-1, 1), alpha, -alpha)
+
+
+def weight_quant_8bit(w, simulated=True):
+    """Same contract as quant/outlier_quantizer.py:10-29 (rounded zero point, wrapping
+    uint8 cast); host-side setup code, not on the hot path."""
+    raw_type = w.dtype
+    w_range = (torch.max(w, dim=-1, keepdim=True)[0] - torch.min(w, dim=-1, keepdim=True)[0]).type(torch.float32)
+    w_zero_point = torch.round(torch.min(w, dim=-1, keepdim=True)[0])
+    w_q = torch.round((w - w_zero_point) / w_range * 255).type(torch.uint8)
+    if simulated:
+        return (w_q * (w_range / 255) + w_zero_point).to(raw_type)
+    return w_q
+
+
+class BinaryXnorExceptOutliersLinear(_DenseBacked):
+    """The QAT partially-binarized layer (quant/outlier_quantizer.py:33-123)."""
+
+    def __init__(self, weight, bias, outlier_fraction, outlier_scale=1, train_outlier=False) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(weight.data)
+        self.bias = nn.Parameter(bias.data) if bias is not None else None
+        self.printed = False
+        self.outlier_mask = None
+        self.outlier_scale = outlier_scale
+        self.outlier_fraction = outlier_fraction
+        self.binary_scale = None
+        self.train_outlier = train_outlier
+        self.outlier_nbits = None
+        self.global_name = None
+        self._packed = None
+        self._codes = None
+
+    def _apply(self, fn, *a, **k):
+        # outlier_mask / binary_scale are plain attributes in the reference (created on
+        # the weight's device); keep them with the module when it is moved.
+        super()._apply(fn, *a, **k)
+        for name in ("outlier_mask", "binary_scale", "_code_scale", "_code_zp"):
+            t = getattr(self, name, None)
+            if isinstance(t, torch.Tensor):
+                moved = fn(t)
+                if name == "outlier_mask":
+                    moved = moved.bool() if moved.dtype != torch.bool else moved
+                setattr(self, name, moved)
+        return self
+
+    def gen_outlier_mask(self):
+        with torch.no_grad():
+            w = self.weight
+            w_flat = w.view(-1)
+            lower = torch.kthvalue(w_flat, int(w_flat.numel() * self.outlier_fraction / 2))[0]
+            upper = torch.kthvalue(w_flat, int(w_flat.numel() * (1 - self.outlier_fraction / 2)))[0]
+            self.outlier_mask = ((w < lower) | (w > upper)).detach()
+            self.binary_scale = w[~self.outlier_mask].abs().mean(-1).view(-1, 1).detach()
+            self._quantize_weights_8bit()
+            self.calc_memory_consumption()
+            self.invalidate()
+
+    def _quantize_weights_8bit(self):
+        w = self.weight.data
+        rng = (w.max(-1, keepdim=True)[0] - w.min(-1, keepdim=True)[0]).type(torch.float32)
+        zp = torch.round(w.min(-1, keepdim=True)[0])
+        self._code_scale = (rng / 255).reshape(-1)
+        self._code_zp = zp.float().reshape(-1)
+        self.weight.data = weight_quant_8bit(w)
+
+    def binarize_except_outliers(self):
+        """Dense simulated weight -- kept for to_regular_linear / parity checks only;
+        forward() does not build it."""
+        if self.outlier_mask is None:
+            self.gen_outlier_mask()
+        if self.training:
+            self._refresh_scale()
+        w = self.weight.detach()
+        return torch.where(self.outlier_mask, w * self.outlier_scale, w.sign() * self.binary_scale)
+
+    def _refresh_scale(self):
+        new = self.weight.detach()[~self.outlier_mask].abs().mean(-1).view(-1, 1)
+        if self.binary_scale is None or not torch.equal(new, self.binary_scale):
+            self.binary_scale = new
+            self.invalidate()
+
+    def _pack(self):
+        w_sim = self.binarize_except_outliers().float().cpu()
+        N = w_sim.shape[0]
+        a = self.binary_scale.float().cpu().reshape(1).expand(N)
+        # salient value = outlier_scale * (code*(range/255) + zp) = sscale*(q - szero)
+        ss = (self._code_scale.float().cpu() * float(self.outlier_scale)).numpy()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            sz = np.where(self._code_scale.cpu().numpy() != 0,
+                          -self._code_zp.cpu().numpy() / self._code_scale.cpu().numpy(), 0.0).astype(np.float32)
+        return pack_dense(w_sim, a.reshape(N, 1), (-a).reshape(N, 1), ss, sz,
+                          self.outlier_mask.cpu().numpy().astype(np.uint8))
+
+    def forward(self, x):
+        if self.outlier_mask is None:
+            self.gen_outlier_mask()
+        if self.training:
+            self._refresh_scale()
+        return super().forward(x)
+
+    def to_regular_linear(self):
+        w = self.binarize_except_outliers()
+        linear = nn.Linear(w.shape[1], w.shape[0], bias=self.bias is not None)
+        linear.weight.data = w
+        if self.bias is not None:
+            linear.bias.data = self.bias
+        return linear
+
+    def calc_memory_consumption(self):
+        """Reference accounting (8-bit index + 8-bit value + row pointers per masked
+        nonzero code, quant/outlier_quantizer.py:116-122)."""
+        w = weight_quant_8bit(self.weight.data, simulated=False)
+        w_outlier = w * self.outlier_mask
+        nnz = int(torch.count_nonzero(w_outlier))
+        self.outlier_nbits = (nnz * 8 + nnz * 8 + (w.shape[0] + 1) * 8) / w.numel()
+
+
+class BinaryXnorExceptOutliersLinearHessian(BinaryXnorExceptOutliersLinear):
+    """Loads the low-mask gptq_pb dumped (gptq.py:108-114); falls back to magnitude when
+    the file is missing (quant/outlier_quantizer.py:126-143).  Like the reference, the
+    loaded-mask branch leaves binary_scale unset until a train() forward computes it."""
+
+    def gen_outlier_mask(self):
+        with torch.no_grad():
+            w = self.weight
+            low_frac = 1 - self.outlier_fraction
+            path = f"gptq_pb/outputs/mask/mask_{low_frac}_{self.global_name.replace('/', '_')}.pkl"
+            if not os.path.exists(path):
+                return super().gen_outlier_mask()
+            mask = torch.load(path)
+            self.outlier_mask = ~mask.to(w.device)
+            self._quantize_weights_8bit()
+            self.calc_memory_consumption()
+            self.invalidate()
+
+
+def replace_linear_with_pb(root: nn.Module, factory, skip=("lm_head",)):
+    """Swap every nn.Linear under `root` for factory(module) by attribute replacement,
+    the way qat/run_qat.py:45-66 and utils.py:97-124 do; sets global_name."""
+    names = {name: m for name, m in root.named_modules()}
+    for name, m in names.items():
+        if isinstance(m, nn.Linear) and not any(s in name for s in skip):
+            ind = name.rfind(".")
+            father = names[""] if ind == -1 else names[name[:ind]]
+            q = factory(m)
+            q.global_name = name
+            setattr(father, name[ind + 1:], q)
+    return root

@@ -1,0 +1,62 @@
+"""Launch helpers above the C ABI: a group of independent PB linears in ONE kernel
+launch (fused QKV / gate+up at decode time; the L-layer stream benchmark of
+SURVEY.md 8(d)).  Device-resident descriptor tables are built once and reused, so
+a launch is a single pbl_gemv_f16_grouped call and is hipGraph-capturable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .packing import PackedWeight
+
+
+class GroupedGemv:
+    """y_l = x_l @ W_l^T (+ b_l) for l in 0..L-1, all in one launch.  M <= 4 tokens."""
+
+    def __init__(self, packed: list[PackedWeight], biases: list[torch.Tensor | None] | None = None,
+                 M: int = 1, device="cuda", shared_x: bool = False):
+        if not packed:
+            raise ValueError("empty group")
+        if not 1 <= M <= _lib.PBL_MAX_TOKENS_PER_LAUNCH:
+            raise ValueError("grouped launch handles 1..4 tokens")
+        self.device = torch.device(device)
+        self.M = M
+        self.packed = [p if p.blob.device == self.device else p.to(self.device) for p in packed]
+        biases = biases or [None] * len(packed)
+        self.biases = [b.detach().float().to(self.device) if b is not None else None for b in biases]
+        if shared_x and len({p.K for p in self.packed}) != 1:
+            raise ValueError("shared_x needs equal in_features")
+        Kmax = max(p.K for p in self.packed)
+        if shared_x:
+            xs = torch.zeros(M, Kmax, dtype=torch.float16, device=self.device)
+            self.x = [xs] * len(self.packed)
+        else:
+            self.x = [torch.zeros(M, p.K, dtype=torch.float16, device=self.device) for p in self.packed]
+        self.y = [torch.empty(M, p.N, dtype=torch.float16, device=self.device) for p in self.packed]
+        structs = (_lib.PblLayer * len(self.packed))(*[p.layer_struct(b) for p, b in zip(self.packed, self.biases)])
+        raw = np.frombuffer(bytes(structs), dtype=np.uint8).copy()
+        self._layers_dev = torch.from_numpy(raw).to(self.device)
+        self._x_ptrs = torch.tensor([t.data_ptr() for t in self.x], dtype=torch.int64, device=self.device)
+        self._y_ptrs = torch.tensor([t.data_ptr() for t in self.y], dtype=torch.int64, device=self.device)
+        self.max_NRB = max(p.NRB for p in self.packed)
+        self.max_K = Kmax
+        self.max_nch = max(p.max_nch for p in self.packed)
+        self.max_nexc = max(p.max_nexc for p in self.packed)
+        self.any_groups = int(any(p.G > 1 for p in self.packed))
+
+    def algorithmic_bytes(self) -> int:
+        return sum(p.algorithmic_bytes(self.M, b is not None) for p, b in zip(self.packed, self.biases))
+
+    def packed_bytes(self) -> int:
+        return sum(p.nbytes for p in self.packed)
+
+    def launch(self, stream: torch.cuda.Stream | None = None) -> list[torch.Tensor]:
+        st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        _lib.check(_lib.lib().pbl_gemv_f16_grouped(
+            self._layers_dev.data_ptr(), self._x_ptrs.data_ptr(), self._y_ptrs.data_ptr(), len(self.packed),
+            self.M, self.max_NRB, self.max_K, self.max_nch, self.max_nexc, self.any_groups, st), "grouped gemv")
+        return self.y

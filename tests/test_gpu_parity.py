@@ -1,0 +1,286 @@
+"""-m gpu: parity of the HIP PB-linear (through the C ABI, libpbl.so) against the
+oracle and against the golden vectors produced by the reference.
+
+Tolerance (BASELINE.json north_star):  max|y - ref| <= 1e-3 * max|ref|
+and allclose(rtol=1e-3, atol=1e-3*rms(ref)), ref = float64 F.linear on the same
+operands; the goldens (reference torch CPU outputs) are held to the same bar.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pb_oracle as O
+from pb_llm_amd import _lib, synth
+from pb_llm_amd import quant as Q
+from pb_llm_amd.packing import pack_dense
+from pb_llm_amd.runtime import GroupedGemv
+from conftest import golden
+from test_oracle_golden import g5_inputs, g5_name
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available()
+
+
+def T(a, dev=DEV):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def assert_parity(y, ref, tol=1e-3):
+    y = y.detach().float().cpu().numpy() if isinstance(y, torch.Tensor) else y
+    rel, ratio = O.parity_errors(y, ref)
+    assert rel < tol and ratio < 1.0, f"rel_max={rel:.3e} allclose_ratio={ratio:.3f}"
+
+
+# ---------------------------------------------------------------- G1 / G2
+def test_g1_binary_linear_gpu():
+    W = synth.llm_weight(768, 768, seed=1); W[3, 5] = 0.0
+    b = synth.normal((768,), 1, 3, 0.1)
+    x = synth.normal((2, 5, 768), 1, 5, 1.0)
+    g = golden("g1_binary_linear")
+    m = Q.BinaryLinear(torch.from_numpy(W), torch.from_numpy(b)).to(DEV)
+    y = m(T(x))
+    assert y.shape == (2, 5, 768) and y.dtype == torch.float32
+    assert_parity(y, g["y"], 2e-5)                       # fp32 module: split-x path
+    assert_parity(y, O.binary_linear_forward(x, W, b), 2e-5)
+    m0 = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV)
+    assert_parity(m0(T(x)), g["y_nobias"], 2e-5)
+    assert_parity(m0(T(x).half()), O.binary_linear_forward(x.astype(np.float16), W, None))
+
+
+def test_g2_xnor_binary_linear_gpu():
+    W = synth.llm_weight(768, 768, seed=1); W[3, 5] = 0.0
+    b = synth.normal((768,), 1, 3, 0.1)
+    x = synth.normal((2, 5, 768), 1, 5, 1.0)
+    g = golden("g2_xnor_binary_linear")
+    m = Q.XnorBinaryLinear(torch.from_numpy(W), torch.from_numpy(b)).to(DEV)
+    assert_parity(m(T(x)), g["y"], 2e-5)
+
+
+# ---------------------------------------------------------------- G4 (QAT layer)
+@pytest.mark.parametrize("tag,dt", [("f32", torch.float32), ("f16", torch.float16)])
+def test_g4_qat_layer_gpu(tag, dt):
+    W = synth.llm_weight(768, 768, seed=4, heavy_tail=True); W[7, 9] = 0.0
+    b = synth.normal((768,), 4, 3, 0.1)
+    x = synth.normal((3, 768), 4, 5, 1.0)
+    g = golden("g4_pb_qat_linear")
+    m = Q.BinaryXnorExceptOutliersLinear(torch.from_numpy(W).to(dt), torch.from_numpy(b).to(dt), 0.1)
+    m.eval()
+    m.gen_outlier_mask()
+    np.testing.assert_array_equal(np.packbits(m.outlier_mask.numpy()), g[f"mask_{tag}"])
+    assert abs(m.outlier_nbits - float(g[f"outlier_nbits_{tag}"])) < 1e-12
+    np.testing.assert_array_equal(m.weight.data.float().numpy(), g[f"w_hat_{tag}"].astype(np.float32))
+    m = m.to(DEV)
+    xt = T(x).to(dt)
+    tol = 1e-4 if tag == "f32" else 1e-3
+    with torch.no_grad():
+        y = m(xt)
+        assert y.dtype == dt
+        assert_parity(y, g[f"y_eval_{tag}"], tol)
+        ref = O.pb_qat_forward(x.astype(np.float32 if tag == "f32" else np.float16), g[f"w_hat_{tag}"],
+                               np.unpackbits(g[f"mask_{tag}"])[:768 * 768].astype(bool).reshape(768, 768),
+                               m.binary_scale.cpu().numpy().astype(g[f"w_hat_{tag}"].dtype), b.astype(g[f"w_hat_{tag}"].dtype))
+        assert_parity(y, ref, tol)
+        # to_regular_linear: same math as a dense layer
+        lin = m.to_regular_linear().to(DEV)
+        assert_parity(lin(xt), g[f"y_eval_{tag}"], tol)
+        # one train() forward refreshes binary_scale and it persists into eval()
+        m.train()
+        assert_parity(m(xt), g[f"y_train_{tag}"], tol)
+        np.testing.assert_allclose(m.binary_scale.float().cpu().numpy(), g[f"binary_scale_after_train_{tag}"],
+                                   rtol=3e-6 if tag == "f32" else 1e-3)
+        m.eval()
+        assert_parity(m(xt), g[f"y_eval2_{tag}"], tol)
+        m2 = Q.BinaryXnorExceptOutliersLinear(torch.from_numpy(W).to(dt), None, 0.1, outlier_scale=0.5).to(DEV)
+        m2.eval()
+        assert_parity(m2(xt), g[f"y_oscale_{tag}"], tol)
+
+
+# ---------------------------------------------------------------- G5 (PTQ)
+@pytest.mark.parametrize("metric,gs,rtn,lf", [("magnitude", -1, True, 0.9), ("magnitude", -1, False, 0.9),
+                                               ("hessian", -1, True, 0.9), ("hessian", -1, True, 0.95),
+                                               ("hessian", -1, False, 0.9)])
+def test_g5_ptq_from_dense_checkpoint_gpu(metric, gs, rtn, lf):
+    """The reference's own fake-quant fp16 weights, packed from the dense matrix +
+    the mask file gptq_pb dumps; forward vs the reference's fp16 F.linear output."""
+    _, _, x1, x32 = g5_inputs()
+    g = golden(g5_name(metric, gs, rtn, lf))
+    mask = np.unpackbits(g["mask"])[:768 * 768].astype(bool).reshape(768, 768)
+    layer = Q.PBLinear.from_dense(torch.from_numpy(g["W_fq"]), None, torch.from_numpy(mask), gs,
+                                  g["hscale"], g["hzero"]).to(DEV)
+    np.testing.assert_array_equal(layer.weight.numpy(), g["W_fq"])   # exact repack of the checkpoint
+    for x, key in ((x1, "y1"), (x32, "y32")):
+        y = layer(T(x))
+        assert_parity(y, O.dense_linear(x, g["W_fq"]))
+        assert_parity(y, g[key])
+    assert_parity(layer(T(x32).float()), g["y32_f32"], 2e-5)
+
+
+def test_g5_from_quantizers_matches_from_dense():
+    W16, _, x1, _ = g5_inputs()
+    g = golden(g5_name("magnitude", -1, True, 0.9))
+    mask = np.unpackbits(g["mask"])[:768 * 768].astype(bool).reshape(768, 768)
+    a = Q.PBLinear.from_quantizers(torch.from_numpy(W16), torch.from_numpy(mask), g["mean"], g["scale"],
+                                   g["hscale"], g["hzero"], dtype=torch.float16)
+    mism = np.count_nonzero(a.weight.numpy() != g["W_fq"])
+    assert mism <= 8
+    assert_parity(a.to(DEV)(T(x1)), g["y1"])
+
+
+# ---------------------------------------------------------------- G6 (llama-7b q_proj, the headline shape)
+@pytest.fixture(scope="module")
+def llama7b_qproj():
+    W = synth.llm_weight(4096, 4096, seed=6)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    return W, mask, r
+
+
+def test_g6_llama7b_qproj_gemv(llama7b_qproj):
+    W, mask, r = llama7b_qproj
+    g = golden("g6_llama7b_qproj_4096_lf0.9")
+    x = synth.activations((1, 4096), 6, 21)
+    # (a) exact structure (fp32 W_fq with its quantizer state): no exceptions
+    hi = r["scale"][0] + r["mean"][0]
+    lo = -r["scale"][0] + r["mean"][0]
+    p = pack_dense(r["W_fq"], hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8))
+    assert p.nexc == 0 and p.nnz == int((~mask).sum())
+    layer = Q.PBLinear(p.to(DEV), None)
+    y = layer(T(x))
+    assert_parity(y, O.dense_linear(x, r["W_fq"]))
+    assert_parity(y, g["y"])          # the reference's fp16 forward on its fp16 weights
+    assert_parity(y, g["y_f32"])
+    # determinism: bitwise identical across launches
+    assert torch.equal(y, layer(T(x)))
+    # traffic accounting
+    assert p.algorithmic_bytes(1) == 4096 * 4096 // 8 + 2 * p.nnz + 4 * 4096 + 8 * 4096 + 4 * 4097 + 4 * 4096
+    assert p.nbytes < 1.12 * p.algorithmic_bytes(1)
+
+
+# ---------------------------------------------------------------- shapes, batches, edge cases
+@pytest.mark.parametrize("N,K,M,bias", [(16, 512, 1, False), (40, 1000, 3, True), (33, 520, 5, True),
+                                         (768, 3072, 2, True), (3072, 768, 9, False), (100, 8, 1, False),
+                                         (17, 77, 4, True), (11008, 4096, 1, False), (4096, 11008, 2, False)])
+def test_shapes_and_batches(N, K, M, bias):
+    W = synth.llm_weight(N, K, seed=N + K, heavy_tail=True)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    b = synth.normal((N,), 2, 3, 0.1) if bias else None
+    x = synth.activations((M, K), N, 21)
+    layer = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]), torch.from_numpy(b) if bias else None,
+                                  torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+    assert layer.packed.nexc == 0
+    y = layer(T(x))
+    assert y.shape == (M, N)
+    assert_parity(y, O.dense_linear(x, r["W_fq"], b))
+
+
+def test_empty_batch_and_leading_dims():
+    W = synth.llm_weight(32, 512, seed=9)
+    s = np.sign(W).astype(np.float32)
+    m = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV)
+    assert m(torch.zeros(0, 512, device=DEV)).shape == (0, 32)
+    x = synth.normal((2, 3, 4, 512), 9, 1)
+    assert_parity(m(T(x)), O.dense_linear(x, s), 2e-5)
+
+
+def test_exceptions_and_dense_salient_rows():
+    N, K = 32, 2048
+    rng = np.random.default_rng(1)
+    W = np.where(rng.random((N, K)) < 0.5, 0.25, -0.125).astype(np.float32)
+    ss = np.full(N, 0.01, np.float32); sz = np.full(N, 100.0, np.float32)
+    W[1, :] = ss[1] * (rng.integers(0, 256, K).astype(np.float32) - 100)   # fully salient row
+    W[0, [3, 900, 901, 2000]] = ss[0] * (np.array([7, 250, 0, 255], np.float32) - 100)
+    for k in range(40):
+        W[rng.integers(2, N), rng.integers(0, K)] = rng.standard_normal()  # off-grid -> exceptions
+    hi = np.full((N, 1), 0.25, np.float32); lo = np.full((N, 1), -0.125, np.float32)
+    p = pack_dense(W, hi, lo, ss, sz)
+    assert p.nexc >= 30
+    x = synth.activations((2, K), 3, 21)
+    y = Q.PBLinear(p.to(DEV), None)(T(x))
+    assert_parity(y, O.dense_linear(x, W))
+
+
+def test_large_activations_and_zero_x():
+    W = synth.llm_weight(64, 1024, seed=12)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    layer = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]), None, torch.from_numpy(mask), -1,
+                                  r["hscale"], r["hzero"]).to(DEV)
+    x = synth.activations((2, 1024), 5, 21).astype(np.float32)
+    x[0, ::97] *= 300.0                     # massive-activation channels
+    x16 = x.astype(np.float16)
+    assert_parity(layer(T(x16)), O.dense_linear(x16, r["W_fq"]))
+    z = torch.zeros(1, 1024, dtype=torch.float16, device=DEV)
+    assert torch.count_nonzero(layer(z)) == 0
+
+
+# ---------------------------------------------------------------- properties at full size
+def test_linearity_and_row_independence_full_size(llama7b_qproj):
+    W, mask, r = llama7b_qproj
+    p = pack_dense(r["W_fq"], r["scale"][0] + r["mean"][0], -r["scale"][0] + r["mean"][0], r["hscale"],
+                   r["hzero"], (~mask).astype(np.uint8))
+    layer = Q.PBLinear(p.to(DEV), None)
+    xa = T(synth.activations((1, 4096), 1, 21)).float()
+    xb = T(synth.activations((1, 4096), 2, 21)).float()
+    ya, yb, yab = layer(xa), layer(xb), layer(xa + 2 * xb)
+    assert_parity(yab, (ya + 2 * yb).cpu().numpy().astype(np.float64), 2e-5)
+    # M=4 batch equals four M=1 calls bit-for-bit (same accumulation order per token)
+    x4 = T(synth.activations((4, 4096), 3, 21))
+    y4 = layer(x4)
+    for m in range(4):
+        assert torch.equal(y4[m:m + 1], layer(x4[m:m + 1]))
+
+
+def test_llama13b_ffn_shapes_m32():
+    """BASELINE config 4 shapes (low_frac 0.8, M=32) vs the reference's own output."""
+    for tag, N, K, seed in (("g7_llama13b_ffn_13824x5120_lf0.8", 13824, 5120, 7),
+                            ("g7_llama13b_ffn_5120x13824_lf0.8", 5120, 13824, 8)):
+        g = golden(tag)
+        W = synth.llm_weight(N, K, seed=seed)
+        mask = O.ptq_low_mask(W, 0.8, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        p = pack_dense(r["W_fq"], r["scale"][0] + r["mean"][0], -r["scale"][0] + r["mean"][0], r["hscale"],
+                       r["hzero"], (~mask).astype(np.uint8))
+        assert p.nexc == 0
+        x = synth.activations((32, K), seed, 21)
+        y = Q.PBLinear(p.to(DEV), None)(T(x))
+        assert_parity(y, g["y_f32"])
+        assert_parity(y, g["y"], 2e-3)   # reference fp16-weight output (weights rounded to fp16 there)
+
+
+# ---------------------------------------------------------------- grouped launch
+def test_grouped_launch_matches_individual():
+    shapes = [(4096, 4096), (4096, 4096), (1024, 4096), (768, 768), (11008, 4096)]
+    packed, xs, refs = [], [], []
+    for i, (N, K) in enumerate(shapes):
+        W = synth.llm_weight(N, K, seed=20 + i)
+        mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        packed.append(pack_dense(r["W_fq"], r["scale"][0] + r["mean"][0], -r["scale"][0] + r["mean"][0],
+                                 r["hscale"], r["hzero"], (~mask).astype(np.uint8)))
+        xs.append(synth.activations((2, K), 30 + i, 21))
+        refs.append(O.dense_linear(xs[-1], r["W_fq"]))
+    grp = GroupedGemv(packed, None, M=2, device=DEV)
+    for t, x in zip(grp.x, xs):
+        t.copy_(T(x))
+    ys = grp.launch()
+    torch.cuda.synchronize()
+    for p, x, y, ref in zip(grp.packed, xs, ys, refs):
+        assert_parity(y, ref)
+        assert torch.equal(y, Q.PBLinear(p, None)(T(x)))   # same kernel, same bits
+
+
+def test_misuse_raises():
+    W = synth.llm_weight(16, 512, seed=1)
+    m = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 100, device=DEV))
+    with pytest.raises(_lib.PblError):
+        m(torch.zeros(1, 512))
