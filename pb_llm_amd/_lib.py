@@ -45,6 +45,9 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so; load it first so libpbl.so binds to the SAME
+    # HIP runtime instance (streams / device pointers are per-runtime).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise PblError(f"{LIB_PATH} not found: the HIP extension is not built "
                        "(run __graft_entry__.build()); there is no CPU fallback")

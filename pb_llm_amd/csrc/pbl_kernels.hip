@@ -286,7 +286,9 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
     class_consts(rho & 7, A, B);
     const float alpha = 0.5f * (pr.hi - pr.lo), mu = 0.5f * (pr.hi + pr.lo);
     const uint32_t row = rb * 16 + rho;
-    const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(
+    // exceptions are read as ONE aligned 64-bit word each: a scalar load of the fp32
+    // field off a 2-byte-aligned base silently drops the low address bits on gfx950
+    const uint2* exc = reinterpret_cast<const uint2*>(
         rec + off_sal + ((size_t(nch) * 2 + 15) & ~size_t(15)) + size_t(nch) * 32 + ((size_t(ntail) + 15) & ~size_t(15)));
 
 #pragma unroll
@@ -307,8 +309,9 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
         Q += shfl_xor(Q, 2); S += shfl_xor(S, 2);
         float e = 0.f;
         for (int k = 0; k < nexc; ++k) {
-            const pbl_exception ex = exc[k];
-            if (ex.row == rho) e += (ex.value - pr.hi) * float(xs[m * xstride + ex.col]);
+            const uint2 ex = exc[k];  // {col | row << 16, value}
+            if (int(ex.x >> 16) == rho)
+                e += (__builtin_bit_cast(float, ex.y) - pr.hi) * float(xs[m * xstride + (ex.x & 0xFFFFu)]);
         }
         const float D = A * accsum - B * X;
         float yv = alpha * D + mu * X + (pr.sscale * (Q - pr.szero * S) - pr.hi * S) + e;
@@ -336,8 +339,10 @@ int launch(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
                                 int(lds)) != hipSuccess)
             return PBL_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(k, grid, dim3(WPB * PBL_WAVE), lds, st, a);
-    return hipGetLastError() == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+    GemvArgs args = a;
+    void* argv[] = {&args};
+    return hipLaunchKernel(reinterpret_cast<const void*>(k), grid, dim3(WPB * PBL_WAVE), argv, lds, st) == hipSuccess
+               ? PBL_OK : PBL_ERR_LAUNCH;
 }
 
 template <int WPB>
@@ -368,8 +373,12 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
     // wide workgroups only when there are enough records to still fill 256 CUs
     const int wpb = layer->NRB >= 1024 ? 4 : 1;
     const size_t esz = y_f32 ? 4 : 2;
-    for (int m0 = 0; m0 < M; m0 += PBL_MAX_TOKENS_PER_LAUNCH) {
-        const int mb = M - m0 < PBL_MAX_TOKENS_PER_LAUNCH ? M - m0 : PBL_MAX_TOKENS_PER_LAUNCH;
+    // tokens per weight pass: as many as fit a 96 KiB LDS budget (x tile + chunk partials),
+    // so that K = 13824 layers still run several workgroups per CU
+    int mb_max = PBL_MAX_TOKENS_PER_LAUNCH;
+    while (mb_max > 1 && lds_bytes(layer->P, layer->max_nch, mb_max, wpb) > 96 * 1024) --mb_max;
+    for (int m0 = 0; m0 < M; m0 += mb_max) {
+        const int mb = M - m0 < mb_max ? M - m0 : mb_max;
         GemvArgs a{};
         a.layer = *layer;
         a.x = static_cast<const _Float16*>(x) + size_t(m0) * layer->K;

@@ -247,7 +247,9 @@ def weight_quant_8bit(w, simulated=True):
     raw_type = w.dtype
     w_range = (torch.max(w, dim=-1, keepdim=True)[0] - torch.min(w, dim=-1, keepdim=True)[0]).type(torch.float32)
     w_zero_point = torch.round(torch.min(w, dim=-1, keepdim=True)[0])
-    w_q = torch.round((w - w_zero_point) / w_range * 255).type(torch.uint8)
+    # `.type(torch.uint8)` on a float tensor wraps mod 256 on the reference's CPU/CUDA
+    # builds (conversion through int64); ROCm saturates instead, so wrap explicitly.
+    w_q = torch.round((w - w_zero_point) / w_range * 255).to(torch.int64).bitwise_and(255).to(torch.uint8)
     if simulated:
         return (w_q * (w_range / 255) + w_zero_point).to(raw_type)
     return w_q
