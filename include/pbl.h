@@ -53,9 +53,9 @@
  *   bit = 1 <=> the weight takes value hi (salient/exception positions store 1).
  *
  * Salient entries of a row are sorted by column and cut greedily into chunks of up
- *   to 16: a chunk closes after 16 entries or when the next column step exceeds 255.
- *   Chunk c: col0[c] = column of entry 0; delta[c][k] = column step from entry k-1
- *   to k (delta[c][0] = 0); code[c][k] = q.  Chunks with exactly 16 entries are
+ *   to 16: a chunk closes after 16 entries or when the next column step exceeds 127.
+ *   Chunk c: col0[c] = column of entry 0; delta[c][k] = 2 * (column step from entry
+ *   k-1 to k), i.e. the BYTE step in an fp16 x vector (delta[c][0] = 0); code[c][k] = q.  Chunks with exactly 16 entries are
  *   "full"; the others are "tail" chunks and carry their count in tailcnt[].
  *   Chunk order within a record: full chunks of row 0, row 1, ... row 15 (indices
  *   0..nfull-1), then the tail chunks of row 0, row 1, ... (indices nfull..nch-1).
@@ -77,6 +77,7 @@ extern "C" {
 #define PBL_ROWS_PER_BLOCK 16
 #define PBL_PANEL_COLS 512
 #define PBL_CHUNK 16
+#define PBL_MAX_GAP 127 /* largest column step inside a chunk (stored doubled in a u8) */
 #define PBL_MAX_TOKENS_PER_LAUNCH 4 /* M handled per weight pass by the GEMV kernel */
 
 typedef enum {

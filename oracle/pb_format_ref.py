@@ -79,7 +79,8 @@ def decode(blob: np.ndarray) -> np.ndarray:
         tailcnt = rec[s: s + ntail].astype(np.int64)
         s += _a16(ntail)
         exc = rec[s: s + 8 * nexc].view(np.dtype([("col", "<u2"), ("row", "<u2"), ("value", "<f4")]))
-        cols = col0[:, None] + np.cumsum(delta, axis=1)
+        assert not (delta & 1).any(), "deltas are stored doubled"
+        cols = col0[:, None] + np.cumsum(delta // 2, axis=1)
         for rho in range(16):
             ri = rowinfo[rho]
             ss, sz = np.float32(params[rho, 2]), np.float32(params[rho, 3])

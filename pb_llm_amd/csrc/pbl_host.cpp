@@ -149,16 +149,16 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
                 }
             }
             nnz += ents.size();
-            // greedy chunking: close at 16 entries or when the next step exceeds 255
+            // greedy chunking: close at 16 entries or when the next column step exceeds PBL_MAX_GAP
             size_t i = 0;
             uint16_t nfull = 0, ntail = 0;
             while (i < ents.size()) {
                 size_t j = i + 1;
-                while (j < ents.size() && j - i < 16 && ents[j].col - ents[j - 1].col <= 255) ++j;
+                while (j < ents.size() && j - i < 16 && ents[j].col - ents[j - 1].col <= PBL_MAX_GAP) ++j;
                 const size_t cnt = j - i;
                 uint8_t d[16] = {0}, q[16] = {0};
                 for (size_t k = 0; k < cnt; ++k) {
-                    d[k] = k ? uint8_t(ents[i + k].col - ents[i + k - 1].col) : 0;
+                    d[k] = k ? uint8_t(2 * (ents[i + k].col - ents[i + k - 1].col)) : 0;  // byte step in the fp16 x tile
                     q[k] = ents[i + k].code;
                 }
                 if (cnt == 16) {
@@ -285,7 +285,7 @@ int pbl_unpack_dense_f32(const void* host_blob, size_t bytes, float* Wout) {
             auto apply = [&](size_t ch, int cnt) {
                 uint32_t col = col0[ch];
                 for (int k = 0; k < cnt; ++k) {
-                    col += delta[ch * 16 + k];
+                    col += delta[ch * 16 + k] / 2u;
                     if (col < K) w[col] = dequant(pr[rho].sscale, pr[rho].szero, code[ch * 16 + k]);
                 }
             };

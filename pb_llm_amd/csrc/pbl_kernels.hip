@@ -62,11 +62,24 @@ __device__ __forceinline__ void class_consts(int ci, float& A, float& B) {
     for (int k = 1; k < 8; ++k) { A = ci == k ? a[k] : A; B = ci == k ? b[k] : B; }
 }
 
+// (w & M) | C in one VALU op.  hipcc splits it into v_and + v_or because VOP3 takes no
+// literal on gfx9; with M in an SGPR and C in a VGPR it is a single v_and_or_b32.
+template <int CI>
+__device__ __forceinline__ uint32_t unpack_pair(uint32_t w, uint32_t c_one) {
+    if constexpr (BitClass<CI>::C == 0u) {
+        return w & BitClass<CI>::M;
+    } else {
+        uint32_t t;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(t) : "v"(w), "s"(BitClass<CI>::M), "v"(c_one));
+        return t;
+    }
+}
+
 template <int MB, int CI>
-__device__ __forceinline__ void class_step(uint32_t w, uint32_t ws, const uint32_t (&xr)[MB],
+__device__ __forceinline__ void class_step(uint32_t w, uint32_t ws, uint32_t c_one, const uint32_t (&xr)[MB],
                                            float (&acc)[MB][16]) {
-    const uint32_t t0 = (w & BitClass<CI>::M) | BitClass<CI>::C;
-    const uint32_t t1 = (ws & BitClass<CI>::M) | BitClass<CI>::C;
+    const uint32_t t0 = unpack_pair<CI>(w, c_one);
+    const uint32_t t1 = unpack_pair<CI>(ws, c_one);
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
         acc[m][CI] = dot2(t0, xr[m], acc[m][CI]);
@@ -75,52 +88,78 @@ __device__ __forceinline__ void class_step(uint32_t w, uint32_t ws, const uint32
 }
 
 template <int MB>
-__device__ __forceinline__ void word_step(uint32_t w, const uint32_t (&xr)[MB], float (&acc)[MB][16],
-                                          float (&xl)[MB]) {
+__device__ __forceinline__ void word_step(uint32_t w, uint32_t c_one, const uint32_t (&xr)[MB],
+                                          float (&acc)[MB][16], float (&xl)[MB]) {
     const uint32_t ws = w << 8;
 #pragma unroll
-    for (int m = 0; m < MB; ++m) xl[m] = dot2(0x3C003C00u, xr[m], xl[m]);
-    class_step<MB, 0>(w, ws, xr, acc);
-    class_step<MB, 1>(w, ws, xr, acc);
-    class_step<MB, 2>(w, ws, xr, acc);
-    class_step<MB, 3>(w, ws, xr, acc);
-    class_step<MB, 4>(w, ws, xr, acc);
-    class_step<MB, 5>(w, ws, xr, acc);
-    class_step<MB, 6>(w, ws, xr, acc);
-    class_step<MB, 7>(w, ws, xr, acc);
+    for (int m = 0; m < MB; ++m) xl[m] = dot2(c_one, xr[m], xl[m]);
+    class_step<MB, 0>(w, ws, c_one, xr, acc);
+    class_step<MB, 1>(w, ws, c_one, xr, acc);
+    class_step<MB, 2>(w, ws, c_one, xr, acc);
+    class_step<MB, 3>(w, ws, c_one, xr, acc);
+    class_step<MB, 4>(w, ws, c_one, xr, acc);
+    class_step<MB, 5>(w, ws, c_one, xr, acc);
+    class_step<MB, 6>(w, ws, c_one, xr, acc);
+    class_step<MB, 7>(w, ws, c_one, xr, acc);
+}
+
+// DPP / permlane helpers (wave64, gfx950).
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROW_ROR8 = 0x128,
+              DPP_ROW_MIRROR = 0x140;
+
+// v_permlane{32,16}_swap exchange halves / odd-even rows of TWO registers in place.  The
+// __builtin forms mis-pair their two results under hipcc 7.2 here (the second result is
+// read from the first register), so the swap is issued from inline asm; "s_nop 1" covers
+// the VALU-write -> permlane-read hazard, which the compiler does not pad inside asm.
+// sum of a over the two 32-lane halves -> lanes 0..31 get a's total, lanes 32..63 b's
+__device__ __forceinline__ float fold32(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// same across the odd/even 16-lane rows: even rows get a's total, odd rows get b's
+__device__ __forceinline__ float fold16(float a, float b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
 }
 
 // 16 per-lane accumulators -> lane l holds the wave total of row
 //   rho(l) = 8*bit5(l) + 4*bit4(l) + 2*bit3(l) + bit2(l)   (4 lanes per row).
 __device__ __forceinline__ float transpose_reduce16(const float (&a)[16], int lane) {
     float v[8], u[4], t[2];
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+    const bool b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float send = b5 ? a[j] : a[j + 8], keep = b5 ? a[j + 8] : a[j];
-        v[j] = keep + shfl_xor(send, 32);
-    }
+    for (int j = 0; j < 8; ++j) v[j] = fold32(a[j], a[j + 8]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float send = b4 ? v[j] : v[j + 4], keep = b4 ? v[j + 4] : v[j];
-        u[j] = keep + shfl_xor(send, 16);
-    }
+    for (int j = 0; j < 4; ++j) u[j] = fold16(v[j], v[j + 4]);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const float send = b3 ? u[j] : u[j + 2], keep = b3 ? u[j + 2] : u[j];
-        t[j] = keep + shfl_xor(send, 8);
+        t[j] = keep + dpp<DPP_ROW_ROR8>(send);
     }
     const float send = b2 ? t[0] : t[1], keep = b2 ? t[1] : t[0];
-    float s = keep + shfl_xor(send, 4);
-    s += shfl_xor(s, 1);
-    s += shfl_xor(s, 2);
+    float s = keep + dpp<DPP_HALF_MIRROR>(send);  // partner 7-i: opposite bit2, bijective on bits 0..1
+    s += dpp<DPP_QUAD_XOR1>(s);
+    s += dpp<DPP_QUAD_XOR2>(s);
     return s;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
-    return v;
+    v += dpp<DPP_QUAD_XOR1>(v);
+    v += dpp<DPP_QUAD_XOR2>(v);
+    v += dpp<DPP_HALF_MIRROR>(v);
+    v += dpp<DPP_ROW_MIRROR>(v);
+    v = fold16(v, v);
+    return fold32(v, v);
+}
+
+// sum over the 4 lanes that share a row (lane bits 0..1)
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp<DPP_QUAD_XOR1>(v);
+    return v + dpp<DPP_QUAD_XOR2>(v);
 }
 
 struct GemvArgs {
@@ -136,23 +175,61 @@ struct GemvArgs {
     int grouped;
 };
 
-// One salient chunk (lane-private): 16 delta-coded columns + 16 codes.
+// Gather 16 fp16 values from LDS byte addresses a[0..15] into 8 packed half2 registers
+// (entry 2p in the low half, 2p+1 in the high half).  All 16 loads are in flight and
+// waited for once inside the statement (guide 5.7 form (i)); hipcc's own schedule waits
+// per load.  d16/d16_hi loads cannot build the pair: with SRAM-ECC (always on here) they
+// ZERO the other half of the destination instead of preserving it, so the halves are
+// merged with one v_lshl_or_b32 per pair.
+__device__ __forceinline__ void gather16(const uint32_t (&a)[16], uint32_t (&x)[8]) {
+    uint32_t t[16];
+    asm volatile(
+        "ds_read_u16 %0, %16\n\tds_read_u16 %1, %17\n\tds_read_u16 %2, %18\n\tds_read_u16 %3, %19\n\t"
+        "ds_read_u16 %4, %20\n\tds_read_u16 %5, %21\n\tds_read_u16 %6, %22\n\tds_read_u16 %7, %23\n\t"
+        "ds_read_u16 %8, %24\n\tds_read_u16 %9, %25\n\tds_read_u16 %10, %26\n\tds_read_u16 %11, %27\n\t"
+        "ds_read_u16 %12, %28\n\tds_read_u16 %13, %29\n\tds_read_u16 %14, %30\n\tds_read_u16 %15, %31\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+          "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]), "=&v"(t[15])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+          "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15])
+        : "memory");
+#pragma unroll
+    for (int p = 0; p < 8; ++p) x[p] = (t[2 * p + 1] << 16) | t[2 * p];
+}
+
+// One salient chunk (lane-private): 16 delta-coded columns + 16 uint8 codes, processed as
+// 8 pairs.  Codes become fp16 (1024+q) with ONE v_perm_b32 per pair (0x64 exponent byte),
+// so  Qb += dot2((1024+q0, 1024+q1), (x0, x1))  and  S += dot2((1,1), (x0,x1));
+// the true code sum is Qb - 1024*S.  Deltas are stored pre-doubled (byte steps into the
+// fp16 x tile), so one SDWA add per entry yields the LDS address.
 template <int MB, bool PRED>
-__device__ __forceinline__ void chunk_accumulate(const _Float16* xs, int xstride, uint32_t col0,
-                                                 const u32x4& d4, const u32x4& q4, int cnt, int zpos,
-                                                 float (&Q)[MB], float (&S)[MB]) {
-    uint32_t col = col0;
+__device__ __forceinline__ void chunk_accumulate(uint32_t xbase, uint32_t tok_stride_bytes, uint32_t col0,
+                                                 const u32x4& d4, const u32x4& q4, int cnt, uint32_t zaddr,
+                                                 uint32_t c_one, float (&Q)[MB], float (&S)[MB]) {
+    uint32_t a[16];
+    uint32_t run = xbase + 2u * col0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const uint32_t dw = d4[k >> 2], qw = q4[k >> 2];
-        col += (dw >> (8 * (k & 3))) & 0xFFu;
-        const uint32_t a = PRED ? (k < cnt ? col : uint32_t(zpos)) : col;
-        const float qf = float((qw >> (8 * (k & 3))) & 0xFFu);
+        run += (d4[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        a[k] = PRED ? (k < cnt ? run : zaddr) : run;
+    }
+    uint32_t qp[8];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const float xv = float(xs[m * xstride + a]);
-            Q[m] = fmaf(qf, xv, Q[m]);
-            S[m] += xv;
+    for (int p = 0; p < 8; ++p)
+        qp[p] = __builtin_amdgcn_perm(q4[p >> 1], 0x64646464u, (p & 1) ? 0x00070006u : 0x00050004u);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        uint32_t x[8];
+        gather16(a, x);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            Q[m] = dot2(qp[p], x[p], Q[m]);
+            S[m] = dot2(c_one, x[p], S[m]);
+        }
+        if (m + 1 < MB) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] += tok_stride_bytes;
         }
     }
 }
@@ -224,6 +301,9 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     }
+    // fp16x2 (1.0, 1.0) kept in a VGPR the compiler cannot constant-fold into a literal
+    uint32_t c_one = 0x3C003C00u;
+    asm volatile("" : "+v"(c_one));
     {
         const u32x4* tiles = reinterpret_cast<const u32x4*>(rec + tiles_off) + lane;
         u32x4 cur = __builtin_nontemporal_load(tiles);
@@ -236,7 +316,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
                 uint32_t xr[MB];
 #pragma unroll
                 for (int m = 0; m < MB; ++m) xr[m] = xw[(m * xstride) / 2 + i * 64];
-                word_step<MB>(cur[i], xr, acc, xl);
+                word_step<MB>(cur[i], c_one, xr, acc, xl);
             }
             cur = nxt;
         }
@@ -250,6 +330,9 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
         const u32x4* deltap = reinterpret_cast<const u32x4*>(s + ((size_t(nch) * 2 + 15) & ~size_t(15)));
         const u32x4* codep = deltap + nch;
         const uint8_t* tailcnt = reinterpret_cast<const uint8_t*>(codep + nch);
+        const uint32_t xbase = uint32_t(reinterpret_cast<uintptr_t>(xs));      // LDS byte offset of x
+        const uint32_t tok_stride = uint32_t(xstride) * 2u;
+        const uint32_t zaddr = xbase + 2u * uint32_t(Kp);                      // a zero slot
         for (int base = 0; base < nch; base += PBL_WAVE) {
             const int c = base + lane;
             const bool valid = c < nch;
@@ -261,16 +344,17 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
 #pragma unroll
             for (int m = 0; m < MB; ++m) { Q[m] = 0.f; S[m] = 0.f; }
             if (base + PBL_WAVE <= nfull) {
-                chunk_accumulate<MB, false>(xs, xstride, c0, d4, q4, 16, Kp, Q, S);
+                chunk_accumulate<MB, false>(xbase, tok_stride, c0, d4, q4, 16, zaddr, c_one, Q, S);
             } else {
                 int cnt = 16;
                 if (cc >= nfull) cnt = tailcnt[cc - nfull];
                 if (!valid) cnt = 0;
-                chunk_accumulate<MB, true>(xs, xstride, c0, d4, q4, cnt, Kp, Q, S);
+                chunk_accumulate<MB, true>(xbase, tok_stride, c0, d4, q4, cnt, zaddr, c_one, Q, S);
             }
             if (valid) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m) part[size_t(m) * L.max_nch + c] = make_float2(Q[m], S[m]);
+                for (int m = 0; m < MB; ++m)   // undo the 1024 code bias here, once per chunk
+                    part[size_t(m) * L.max_nch + c] = make_float2(fmaf(-1024.f, S[m], Q[m]), S[m]);
             }
         }
     }
@@ -305,8 +389,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
             const float2 v = pm[nfull + ri.tailidx + k];
             Q += v.x; S += v.y;
         }
-        Q += shfl_xor(Q, 1); S += shfl_xor(S, 1);
-        Q += shfl_xor(Q, 2); S += shfl_xor(S, 2);
+        Q = quad_sum(Q); S = quad_sum(S);
         float e = 0.f;
         for (int k = 0; k < nexc; ++k) {
             const uint2 ex = exc[k];  // {col | row << 16, value}
