@@ -75,8 +75,8 @@ def cpu_baseline(dense_layers, K, M, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--layers", type=int, default=224)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic weight sets (replicated to L blobs)")
     ap.add_argument("--N", type=int, default=4096)

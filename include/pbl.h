@@ -31,9 +31,12 @@
  * ---------------------------------------------------------------------------
  * Packed format "PBL1" (one blob per layer, identical on host and device):
  *
- *   [pbl_blob_header 80 B][rb_off: u32[NRB+1], units of 16 B, padded to 16 B]
+ *   [pbl_blob_header 80 B][rb_info: pbl_rec_info[NRB+1], 16 B each]
  *   [record 0][record 1]...[record NRB-1]        NRB = ceil(N/16)
  *
+ * rb_info[b] = {record offset in units of 16 B, nfull, ntail, nexc}: ONE 16-byte scalar load
+ * tells a wavefront where its record is and how long its salient lists are, so every
+ * load of the record can be issued at once (rb_info[NRB].off16 = end of blob).
  * A record holds one ROW-BLOCK of 16 output rows and is the unit of work of one
  * wavefront.  P = ceil(K/512) column panels.  Record layout (all 16-B aligned):
  *   +0    pbl_rec_header (16 B): nfull, ntail, nexc, off_sal (bytes from record start)
@@ -106,11 +109,12 @@ typedef struct {
     uint64_t nnz;           /* salient code entries, total */
     uint64_t nexc;          /* exception entries, total */
     uint64_t blob_bytes;    /* total size of the blob */
-    uint32_t rb_off_pos;    /* byte offset of rb_off[] from blob start (= sizeof header = 80) */
+    uint32_t rb_off_pos;    /* byte offset of rb_info[] from blob start (= sizeof header = 80) */
     uint32_t reserved[3];
 } pbl_blob_header;
 
 typedef struct { uint32_t nfull, ntail, nexc, off_sal; } pbl_rec_header;
+typedef struct { uint32_t off16, nfull, ntail, nexc; } pbl_rec_info;
 typedef struct { uint16_t start, nfull, tailidx; uint8_t ntail, pad; } pbl_rowinfo;
 typedef struct { float hi, lo, sscale, szero; } pbl_rowparams;
 typedef struct { uint16_t col; uint16_t row; float value; } pbl_exception;

@@ -34,7 +34,8 @@ def decode(blob: np.ndarray) -> np.ndarray:
     h = read_header(blob)
     N, K, P, G, NRB = h["N"], h["K"], h["P"], h["G"], h["NRB"]
     gs = K // G
-    rb_off = blob[h["rb_off_pos"]: h["rb_off_pos"] + 4 * (NRB + 1)].view(np.uint32).astype(np.int64) * 16
+    rb_info = blob[h["rb_off_pos"]: h["rb_off_pos"] + 16 * (NRB + 1)].view(np.uint32).reshape(NRB + 1, 4)
+    rb_off = rb_info[:, 0].astype(np.int64) * 16
     W = np.zeros((NRB * 16, P * 512), np.float32)
 
     # column owned by (lane l, dword i, element e) of panel p:  512p + 128i + 2l + e
@@ -46,6 +47,7 @@ def decode(blob: np.ndarray) -> np.ndarray:
     for b in range(NRB):
         rec = blob[rb_off[b]: rb_off[b + 1]]
         nfull, ntail, nexc, off_sal = struct.unpack("<4I", rec[:16].tobytes())
+        assert (nfull, ntail, nexc) == tuple(int(v) for v in rb_info[b, 1:]), "rb_info disagrees with record header"
         rowinfo = rec[16:144].view(np.dtype([("start", "<u2"), ("nfull", "<u2"), ("tailidx", "<u2"),
                                              ("ntail", "u1"), ("pad", "u1")]))
         params = rec[144:400].view(np.float32).reshape(16, 4)

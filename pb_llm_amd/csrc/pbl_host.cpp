@@ -85,12 +85,12 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
     const uint32_t NRB = (N + 15) / 16;
 
     const size_t rboff_pos = sizeof(pbl_blob_header);
-    const size_t rec0 = align16(rboff_pos + size_t(NRB + 1) * 4);
+    const size_t rec0 = align16(rboff_pos + size_t(NRB + 1) * sizeof(pbl_rec_info));
     const size_t fixed = record_fixed_bytes(P, G);
     const size_t tiles_off = fixed - size_t(P) * 1024;
 
     uint8_t* blob = static_cast<uint8_t*>(out);
-    std::vector<uint32_t> rb_off(NRB + 1);
+    std::vector<pbl_rec_info> rb_info(NRB + 1);
     size_t cur = rec0;
     uint64_t nnz = 0, nexc_total = 0;
     uint32_t max_nch = 0, max_nexc = 0;
@@ -183,7 +183,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
         const size_t nfull = rb.col0_full.size(), ntail = rb.col0_tail.size(), nch = nfull + ntail;
         if (nch > 65535) return PBL_ERR_UNSUPPORTED;
         const size_t rec_bytes = fixed + record_sal_bytes(nch, ntail, rb.exc.size());
-        rb_off[b] = uint32_t(cur / 16);
+        rb_info[b] = {uint32_t(cur / 16), uint32_t(nfull), uint32_t(ntail), uint32_t(rb.exc.size())};
         max_nch = std::max<uint32_t>(max_nch, uint32_t(nch));
         max_nexc = std::max<uint32_t>(max_nexc, uint32_t(rb.exc.size()));
         nexc_total += rb.exc.size();
@@ -214,7 +214,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
         }
         cur += rec_bytes;
     }
-    rb_off[NRB] = uint32_t(cur / 16);
+    rb_info[NRB] = {uint32_t(cur / 16), 0, 0, 0};
     *out_bytes = cur;
     if (blob) {
         if (cur > cap) return PBL_ERR_CAPACITY;
@@ -226,7 +226,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
         h.blob_bytes = cur; h.rb_off_pos = uint32_t(rboff_pos);
         std::memcpy(blob, &h, sizeof(h));
         std::memset(blob + rboff_pos, 0, rec0 - rboff_pos);
-        std::memcpy(blob + rboff_pos, rb_off.data(), rb_off.size() * 4);
+        std::memcpy(blob + rboff_pos, rb_info.data(), rb_info.size() * sizeof(pbl_rec_info));
     }
     return PBL_OK;
 }
@@ -251,11 +251,11 @@ int pbl_unpack_dense_f32(const void* host_blob, size_t bytes, float* Wout) {
     const uint8_t* blob = static_cast<const uint8_t*>(host_blob);
     pbl_blob_header h;
     std::memcpy(&h, blob, sizeof(h));
-    const uint32_t* rb_off = reinterpret_cast<const uint32_t*>(blob + h.rb_off_pos);
+    const pbl_rec_info* rb_info = reinterpret_cast<const pbl_rec_info*>(blob + h.rb_off_pos);
     const uint32_t N = L.N, K = L.K, G = L.G, P = L.P, gs = K / G;
     const size_t fixed = record_fixed_bytes(P, G), tiles_off = fixed - size_t(P) * 1024;
     for (uint32_t b = 0; b < L.NRB; ++b) {
-        const uint8_t* rec = blob + size_t(rb_off[b]) * 16;
+        const uint8_t* rec = blob + size_t(rb_info[b].off16) * 16;
         pbl_rec_header rh;
         std::memcpy(&rh, rec, sizeof(rh));
         const pbl_rowinfo* ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16);

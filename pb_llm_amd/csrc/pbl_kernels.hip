@@ -28,6 +28,11 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define PBL_WAVE 64
+// Ablation builds for performance analysis only (tools/ablate.sh): 1 = memory only
+// (loads kept live, math skipped), 2 = compute only (weight-stream loads skipped).
+#ifndef PBL_ABLATE
+#define PBL_ABLATE 0
+#endif
 
 namespace {
 
@@ -175,67 +180,69 @@ struct GemvArgs {
     int grouped;
 };
 
-// Gather 16 fp16 values from LDS byte addresses a[0..15] into 8 packed half2 registers
-// (entry 2p in the low half, 2p+1 in the high half).  All 16 loads are in flight and
-// waited for once inside the statement (guide 5.7 form (i)); hipcc's own schedule waits
-// per load.  d16/d16_hi loads cannot build the pair: with SRAM-ECC (always on here) they
-// ZERO the other half of the destination instead of preserving it, so the halves are
-// merged with one v_lshl_or_b32 per pair.
-__device__ __forceinline__ void gather16(const uint32_t (&a)[16], uint32_t (&x)[8]) {
-    uint32_t t[16];
+// Gather 8 fp16 values from LDS byte addresses a[0..7] into 4 packed half2 registers
+// (entry 2p in the low half, 2p+1 in the high half).  All loads are in flight and waited
+// for once inside the statement (guide 5.7 form (i)); hipcc's own schedule waits per load.
+// d16/d16_hi loads cannot build the pair: with SRAM-ECC (always on here) they ZERO the
+// other half of the destination instead of preserving it, so the halves are merged with
+// one v_lshl_or_b32 per pair.
+__device__ __forceinline__ void gather8(const uint32_t (&a)[8], uint32_t (&x)[4]) {
+    uint32_t t[8];
     asm volatile(
-        "ds_read_u16 %0, %16\n\tds_read_u16 %1, %17\n\tds_read_u16 %2, %18\n\tds_read_u16 %3, %19\n\t"
-        "ds_read_u16 %4, %20\n\tds_read_u16 %5, %21\n\tds_read_u16 %6, %22\n\tds_read_u16 %7, %23\n\t"
-        "ds_read_u16 %8, %24\n\tds_read_u16 %9, %25\n\tds_read_u16 %10, %26\n\tds_read_u16 %11, %27\n\t"
-        "ds_read_u16 %12, %28\n\tds_read_u16 %13, %29\n\tds_read_u16 %14, %30\n\tds_read_u16 %15, %31\n\t"
+        "ds_read_u16 %0, %8\n\tds_read_u16 %1, %9\n\tds_read_u16 %2, %10\n\tds_read_u16 %3, %11\n\t"
+        "ds_read_u16 %4, %12\n\tds_read_u16 %5, %13\n\tds_read_u16 %6, %14\n\tds_read_u16 %7, %15\n\t"
         "s_waitcnt lgkmcnt(0)"
-        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
-          "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]), "=&v"(t[15])
-        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
-          "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15])
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7])
         : "memory");
 #pragma unroll
-    for (int p = 0; p < 8; ++p) x[p] = (t[2 * p + 1] << 16) | t[2 * p];
+    for (int p = 0; p < 4; ++p) x[p] = (t[2 * p + 1] << 16) | t[2 * p];
 }
 
 // One salient chunk (lane-private): 16 delta-coded columns + 16 uint8 codes, processed as
-// 8 pairs.  Codes become fp16 (1024+q) with ONE v_perm_b32 per pair (0x64 exponent byte),
-// so  Qb += dot2((1024+q0, 1024+q1), (x0, x1))  and  S += dot2((1,1), (x0,x1));
+// two halves of 4 pairs (keeps the live register set small -> more waves per SIMD).
+// Codes become fp16 (1024+q) with ONE v_perm_b32 per pair (0x64 exponent byte), so
+//   Qb += dot2((1024+q0, 1024+q1), (x0, x1))   and   S += dot2((1,1), (x0,x1));
 // the true code sum is Qb - 1024*S.  Deltas are stored pre-doubled (byte steps into the
 // fp16 x tile), so one SDWA add per entry yields the LDS address.
 template <int MB, bool PRED>
 __device__ __forceinline__ void chunk_accumulate(uint32_t xbase, uint32_t tok_stride_bytes, uint32_t col0,
                                                  const u32x4& d4, const u32x4& q4, int cnt, uint32_t zaddr,
                                                  uint32_t c_one, float (&Q)[MB], float (&S)[MB]) {
-    uint32_t a[16];
     uint32_t run = xbase + 2u * col0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        run += (d4[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-        a[k] = PRED ? (k < cnt ? run : zaddr) : run;
-    }
-    uint32_t qp[8];
+    for (int h = 0; h < 2; ++h) {
+        uint32_t a[8];
 #pragma unroll
-    for (int p = 0; p < 8; ++p)
-        qp[p] = __builtin_amdgcn_perm(q4[p >> 1], 0x64646464u, (p & 1) ? 0x00070006u : 0x00050004u);
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-        uint32_t x[8];
-        gather16(a, x);
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            Q[m] = dot2(qp[p], x[p], Q[m]);
-            S[m] = dot2(c_one, x[p], S[m]);
+        for (int k = 0; k < 8; ++k) {
+            const int e = 8 * h + k;
+            run += (d4[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+            a[k] = PRED ? (e < cnt ? run : zaddr) : run;
         }
-        if (m + 1 < MB) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] += tok_stride_bytes;
+        for (int m = 0; m < MB; ++m) {
+            uint32_t x[4];
+            gather8(a, x);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t qp = __builtin_amdgcn_perm(q4[2 * h + (p >> 1)], 0x64646464u,
+                                                          (p & 1) ? 0x00070006u : 0x00050004u);
+                Q[m] = dot2(qp, x[p], Q[m]);
+                S[m] = dot2(c_one, x[p], S[m]);
+            }
+            if (m + 1 < MB) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a[k] += tok_stride_bytes;
+            }
         }
     }
 }
 
+#ifndef PBL_MIN_WAVES
+#define PBL_MIN_WAVES 1
+#endif
 template <int MB, int WPB>
-__global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args) {
+__global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void pbl_gemv_kernel(GemvArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,6 +266,43 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
     _Float16* xs = reinterpret_cast<_Float16*>(smem);
     float2* part_all = reinterpret_cast<float2*>(smem + ((size_t(MB) * xstride * 2 + 15) & ~size_t(15)));
 
+    // ---- record lookup + first loads, issued BEFORE x is staged so that HBM latency of
+    //      the weight stream overlaps the L2->LDS copy of x and the barrier ----------------
+    const uint32_t rb = rb0 + wave;
+    const bool active = rb < L.NRB;
+    const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
+    const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[active ? rb : rb0];
+    const uint8_t* rec = blob + size_t(__builtin_amdgcn_readfirstlane(info.x)) * 16;
+    const int nfull = __builtin_amdgcn_readfirstlane(info.y);
+    const int ntail = __builtin_amdgcn_readfirstlane(info.z);
+    const int nexc = __builtin_amdgcn_readfirstlane(info.w);
+    const int nch = nfull + ntail;
+    const uint32_t tiles_off = (L.flags & PBL_FLAG_HAS_GROUPS) ? ((400u + 128u * L.G + 15u) & ~15u) : 400u;
+    const uint32_t off_sal = tiles_off + uint32_t(P) * 1024u;
+
+    const u32x4* tiles = reinterpret_cast<const u32x4*>(rec + tiles_off) + lane;
+    const uint8_t* sal = rec + off_sal;
+    const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
+    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + ((size_t(nch) * 2 + 15) & ~size_t(15)));
+    const u32x4* codep = deltap + nch;
+    const uint8_t* tailcnt = reinterpret_cast<const uint8_t*>(codep + nch);
+
+    u32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+    uint32_t s_c0 = 0;
+    u32x4 s_d4 = {0, 0, 0, 0}, s_q4 = {0, 0, 0, 0};
+    uint32_t abl = 0;
+    (void)abl;
+    if (active && PBL_ABLATE != 2) {
+        t0 = __builtin_nontemporal_load(tiles);
+        if (P > 1) t1 = __builtin_nontemporal_load(tiles + 64);
+        if (nch > 0) {
+            const int cc = lane < nch ? lane : nch - 1;
+            s_c0 = col0p[cc];
+            s_d4 = __builtin_nontemporal_load(deltap + cc);
+            s_q4 = __builtin_nontemporal_load(codep + cc);
+        }
+    }
+
     // ---- phase 0: stage x ---------------------------------------------------------
     {
         const int nthr = WPB * PBL_WAVE;
@@ -277,22 +321,9 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
             for (int i = K + tid; i < xstride; i += nthr) xs[m * xstride + i] = _Float16(0);
     }
     __syncthreads();
+    if (!active) return;  // no barriers below this point
 
-    const uint32_t rb = rb0 + wave;
-    if (rb >= L.NRB) return;  // no barriers below this point
-
-    const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
-    const uint32_t* rb_off = reinterpret_cast<const uint32_t*>(blob + sizeof(pbl_blob_header));
-    const uint8_t* rec = blob + size_t(__builtin_amdgcn_readfirstlane(rb_off[rb])) * 16;
-    const pbl_rec_header rh = *reinterpret_cast<const pbl_rec_header*>(rec);
-    const int nfull = __builtin_amdgcn_readfirstlane(rh.nfull);
-    const int ntail = __builtin_amdgcn_readfirstlane(rh.ntail);
-    const int nexc = __builtin_amdgcn_readfirstlane(rh.nexc);
-    const uint32_t off_sal = __builtin_amdgcn_readfirstlane(rh.off_sal);
-    const int nch = nfull + ntail;
-    const uint32_t tiles_off = off_sal - uint32_t(P) * 1024u;
-
-    // ---- phase 1: sign plane ------------------------------------------------------
+    // ---- phase 1: sign plane (tile loads run two panels ahead) ------------------------
     float acc[MB][16];
     float xl[MB];
 #pragma unroll
@@ -304,32 +335,34 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
     // fp16x2 (1.0, 1.0) kept in a VGPR the compiler cannot constant-fold into a literal
     uint32_t c_one = 0x3C003C00u;
     asm volatile("" : "+v"(c_one));
-    {
-        const u32x4* tiles = reinterpret_cast<const u32x4*>(rec + tiles_off) + lane;
-        u32x4 cur = __builtin_nontemporal_load(tiles);
-        for (int p = 0; p < P; ++p) {
-            u32x4 nxt = cur;
-            if (p + 1 < P) nxt = __builtin_nontemporal_load(tiles + (p + 1) * 64);
-            const uint32_t* xw = reinterpret_cast<const uint32_t*>(xs + p * PBL_PANEL_COLS) + lane;
+    for (int p = 0; p < P; ++p) {
+        u32x4 t2 = t1;
+        if (p + 2 < P && PBL_ABLATE != 2) t2 = __builtin_nontemporal_load(tiles + (p + 2) * 64);
+        const uint32_t* xw = reinterpret_cast<const uint32_t*>(xs + p * PBL_PANEL_COLS) + lane;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                uint32_t xr[MB];
+        for (int i = 0; i < 4; ++i) {
+            uint32_t xr[MB];
 #pragma unroll
-                for (int m = 0; m < MB; ++m) xr[m] = xw[(m * xstride) / 2 + i * 64];
-                word_step<MB>(cur[i], c_one, xr, acc, xl);
-            }
-            cur = nxt;
+            for (int m = 0; m < MB; ++m) xr[m] = xw[(m * xstride) / 2 + i * 64];
+            if (PBL_ABLATE == 1) { abl ^= t0[i] ^ xr[0]; continue; }
+            word_step<MB>(t0[i] ^ (PBL_ABLATE == 2 ? uint32_t(p * 4 + i + lane) : 0u), c_one, xr, acc, xl);
         }
+        t0 = t1;
+        t1 = t2;
     }
 
-    // ---- phase 2: salient chunks --------------------------------------------------
+    // reduce the 16 row accumulators now: from here on one register per token carries the
+    // binary result (lane l holds row rho(l), see transpose_reduce16)
+    float accsum[MB], X[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        X[m] = wave_sum(xl[m]);
+        accsum[m] = transpose_reduce16(acc[m], lane);
+    }
+
+    // ---- phase 2: salient chunks (next round's loads issued before this round's math) ---
     float2* part = part_all + size_t(wave) * L.max_nch * MB;
     {
-        const uint8_t* s = rec + off_sal;
-        const uint16_t* col0p = reinterpret_cast<const uint16_t*>(s);
-        const u32x4* deltap = reinterpret_cast<const u32x4*>(s + ((size_t(nch) * 2 + 15) & ~size_t(15)));
-        const u32x4* codep = deltap + nch;
-        const uint8_t* tailcnt = reinterpret_cast<const uint8_t*>(codep + nch);
         const uint32_t xbase = uint32_t(reinterpret_cast<uintptr_t>(xs));      // LDS byte offset of x
         const uint32_t tok_stride = uint32_t(xstride) * 2u;
         const uint32_t zaddr = xbase + 2u * uint32_t(Kp);                      // a zero slot
@@ -337,13 +370,20 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
             const int c = base + lane;
             const bool valid = c < nch;
             const int cc = valid ? c : nch - 1;
-            const uint32_t c0 = col0p[cc];
-            const u32x4 d4 = __builtin_nontemporal_load(deltap + cc);
-            const u32x4 q4 = __builtin_nontemporal_load(codep + cc);
+            const uint32_t c0 = s_c0;
+            const u32x4 d4 = s_d4, q4 = s_q4;
+            if (base + PBL_WAVE < nch && PBL_ABLATE != 2) {
+                const int cn = c + PBL_WAVE < nch ? c + PBL_WAVE : nch - 1;
+                s_c0 = col0p[cn];
+                s_d4 = __builtin_nontemporal_load(deltap + cn);
+                s_q4 = __builtin_nontemporal_load(codep + cn);
+            }
             float Q[MB], S[MB];
 #pragma unroll
             for (int m = 0; m < MB; ++m) { Q[m] = 0.f; S[m] = 0.f; }
-            if (base + PBL_WAVE <= nfull) {
+            if (PBL_ABLATE == 1) {
+                abl ^= c0 ^ d4[0] ^ d4[1] ^ d4[2] ^ d4[3] ^ q4[0] ^ q4[1] ^ q4[2] ^ q4[3];
+            } else if (base + PBL_WAVE <= nfull) {
                 chunk_accumulate<MB, false>(xbase, tok_stride, c0, d4, q4, 16, zaddr, c_one, Q, S);
             } else {
                 int cnt = 16;
@@ -377,8 +417,6 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
 
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
-        const float X = wave_sum(xl[m]);
-        const float accsum = transpose_reduce16(acc[m], lane);
         float Q = 0.f, S = 0.f;
         const float2* pm = part + size_t(m) * L.max_nch;
         for (int k = sub; k < int(ri.nfull); k += 4) {
@@ -396,9 +434,12 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_kernel(GemvArgs args)
             if (int(ex.x >> 16) == rho)
                 e += (__builtin_bit_cast(float, ex.y) - pr.hi) * float(xs[m * xstride + (ex.x & 0xFFFFu)]);
         }
-        const float D = A * accsum - B * X;
-        float yv = alpha * D + mu * X + (pr.sscale * (Q - pr.szero * S) - pr.hi * S) + e;
+        // explicit fma chain: every template instantiation rounds identically (M=4 == 4 x M=1)
+        const float D = fmaf(A, accsum[m], -(B * X[m]));
+        const float sal = fmaf(pr.sscale, fmaf(-pr.szero, S, Q), -(pr.hi * S));
+        float yv = fmaf(alpha, D, fmaf(mu, X[m], sal)) + e;
         if (L.bias && row < L.N) yv += L.bias[row];
+        if (PBL_ABLATE == 1 && abl == 0x9E3779B9u) yv += 1.f;
         if (sub == 0 && row < L.N) {
             if (args.y_f32) static_cast<float*>(yg)[size_t(m) * L.N + row] = yv;
             else static_cast<_Float16*>(yg)[size_t(m) * L.N + row] = _Float16(yv);

@@ -1,52 +1,51 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 output dirs written by tools/profile.sh: per-kernel duration stats
-from the kernel trace and per-dispatch averages of every PMC counter."""
-import csv
+"""Summarise rocprofv3 output (rocpd sqlite .db) written by tools/profile.sh: per-kernel
+durations from the kernel trace and per-dispatch averages of every PMC counter."""
+import collections
 import glob
 import json
 import os
+import sqlite3
 import sys
-from collections import defaultdict
 
 
-def find(d, pat):
-    return sorted(glob.glob(os.path.join(d, "**", pat), recursive=True))
+def dbs(d):
+    return sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True))
 
 
 def kernel_stats(d):
-    rows = []
-    for f in find(d, "*kernel_trace.csv"):
-        with open(f) as fh:
-            for r in csv.DictReader(fh):
-                rows.append(r)
-    agg = defaultdict(list)
-    for r in rows:
-        try:
-            dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-        except (KeyError, ValueError):
-            continue
-        agg[r.get("Kernel_Name", "?")].append(dur)
     out = []
-    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-        v2 = sorted(v)
-        out.append(dict(kernel=k[:100], calls=len(v), total_us=sum(v) / 1e3, avg_us=sum(v) / len(v) / 1e3,
-                        med_us=v2[len(v2) // 2] / 1e3, min_us=v2[0] / 1e3, max_us=v2[-1] / 1e3))
+    for db in dbs(d):
+        cur = sqlite3.connect(db).cursor()
+        agg = collections.defaultdict(list)
+        for name, dur in cur.execute("select name, duration from kernels"):
+            agg[name].append(dur)
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            v2 = sorted(v)
+            out.append(dict(kernel=k[:90], calls=len(v), total_us=round(sum(v) / 1e3, 1), avg_us=round(sum(v) / len(v) / 1e3, 2),
+                            med_us=round(v2[len(v2) // 2] / 1e3, 2), min_us=round(v2[0] / 1e3, 2), max_us=round(v2[-1] / 1e3, 2)))
     return out
 
 
 def pmc_stats(d, want="pbl_gemv"):
-    agg = defaultdict(lambda: defaultdict(list))
-    for f in find(d, "*counter_collection.csv"):
-        with open(f) as fh:
-            for r in csv.DictReader(fh):
-                k = r.get("Kernel_Name", "?")
-                if want not in k:
-                    continue
-                try:
-                    agg[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                except (KeyError, ValueError):
-                    pass
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+    res = {}
+    for db in dbs(d):
+        cur = sqlite3.connect(db).cursor()
+        agg = collections.defaultdict(list)
+        dur = []
+        try:
+            rows = cur.execute("select counter_name, value, duration from counters_collection where kernel_name like ?",
+                               (f"%{want}%",))
+        except sqlite3.Error:
+            continue
+        for name, val, d_ in rows:
+            agg[name].append(val)
+            dur.append(d_)
+        if agg:
+            res = {k: round(sum(v) / len(v), 1) for k, v in agg.items()}
+            res["_dispatches"] = len(dur) // len(agg)
+            res["_avg_kernel_us_in_this_pass"] = round(sum(dur) / len(dur) / 1e3, 2)
+    return res
 
 
 def main():
@@ -54,23 +53,16 @@ def main():
     print(f"# rocprofv3 summary for {root}")
     tr = os.path.join(root, "trace")
     if os.path.isdir(tr):
-        print("\n## kernel trace (durations in us)")
-        for s in kernel_stats(tr)[:8]:
+        print("\n## kernel trace, un-instrumented timing (durations in us)")
+        for s in kernel_stats(tr)[:6]:
             print(json.dumps(s))
-        for f in find(tr, "*kernel_stats.csv")[:1]:
-            print(f"\n## {os.path.basename(f)} (rocprofv3 --stats)")
-            print("".join(open(f).readlines()[:8]))
     for sub in sorted(os.listdir(root)):
         p = os.path.join(root, sub)
         if sub.startswith("pmc") and os.path.isdir(p):
             st = pmc_stats(p)
             if st:
-                print(f"\n## {sub}: per-dispatch averages")
-                for k, cs in st.items():
-                    print(k, json.dumps({c: round(v, 1) for c, v in sorted(cs.items())}))
-            ks = [s for s in kernel_stats(p) if "pbl_gemv" in s["kernel"]]
-            for s in ks[:2]:
-                print("   (profiled-run duration)", json.dumps(s))
+                print(f"\n## {sub}: per-dispatch averages for pbl_gemv_kernel")
+                print(json.dumps(st))
     for log in sorted(glob.glob(os.path.join(root, "*.log"))):
         for line in open(log):
             if line.startswith("{\"metric\""):
