@@ -15,5 +15,8 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_
   --kernel-trace -d $OUT/pmc2 -o pmc -- python bench.py $ARGS > $OUT/pmc2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc3 -o pmc -- python bench.py $ARGS > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc4 -o pmc -- python bench.py $ARGS > $OUT/pmc4.log 2>&1
+if [ -x build/calib_fetch ]; then
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/calib -o pmc -- ./build/calib_fetch > $OUT/calib.log 2>&1
+fi
 python tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -63,6 +63,17 @@ def main():
             if st:
                 print(f"\n## {sub}: per-dispatch averages for pbl_gemv_kernel")
                 print(json.dumps(st))
+    cal = os.path.join(root, "calib")
+    if os.path.isdir(cal):
+        st = pmc_stats(cal, "calib_stream_read")
+        if st.get("FETCH_SIZE"):
+            true_b = 2 * (1 << 30)
+            f = true_b / (st["FETCH_SIZE"] * 1024.0)
+            print(f"\n## FETCH_SIZE calibration: 2 GiB dwordx4 nt stream read reports FETCH_SIZE={st['FETCH_SIZE']:.0f} KiB "
+                  f"-> correction factor {f:.3f}")
+            p3 = pmc_stats(os.path.join(root, "pmc3"))
+            if p3.get("FETCH_SIZE"):
+                print(f"   corrected HBM read traffic of pbl_gemv_kernel: {p3['FETCH_SIZE'] * 1024 * f / 1e6:.1f} MB per dispatch")
     for log in sorted(glob.glob(os.path.join(root, "*.log"))):
         for line in open(log):
             if line.startswith("{\"metric\""):
