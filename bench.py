@@ -85,14 +85,20 @@ def main():
     ap.add_argument("--low-frac", type=float, default=0.9)
     ap.add_argument("--mode", choices=["grouped", "graph", "eager"], default="grouped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallel", choices=["dp", "tp"], default="dp",
+                    help="dp: independent layer streams per rank (weak scaling, no collective); "
+                         "tp: every layer K-split across ranks + one RCCL all-reduce of the stacked fp32 partial "
+                         "outputs per step (strong scaling)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (any world size, incl. 1)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
     dev = torch.device(f"cuda:{local}")
@@ -104,13 +110,31 @@ def main():
     from pb_llm_amd.quant import PBLinear
     from pb_llm_amd.runtime import GroupedGemv
 
-    base = build_base_layers(a.distinct, a.N, a.K, a.low_frac, seed0=1000 + 17 * rank)
+    tp = a.parallel == "tp" and use_dist
+    base = build_base_layers(a.distinct, a.N, a.K, a.low_frac, seed0=1000 + (0 if tp else 17 * rank))
+    Kloc, c0 = a.K, 0
+    if tp:  # K-split every layer: this rank keeps columns [c0, c1)
+        from pb_llm_amd.packing import infer_levels, pack_dense
+        from pb_llm_amd.parallel import split_points, COL_ALIGN
+        c0, c1 = split_points(a.K, world, COL_ALIGN)[rank:rank + 2]
+        Kloc = c1 - c0
+        shards = []
+        for p_full, Wd in base:
+            hi, lo = infer_levels(Wd)
+            full = p_full.unpack().numpy()
+            assert np.array_equal(full, Wd)
+            # per-row levels / code grid are those of the FULL row, identical on every rank
+            from pb_llm_amd.packing import infer_code_grid
+            ss, sz = infer_code_grid(Wd, hi, lo)
+            shards.append((pack_dense(Wd[:, c0:c1], hi, lo, ss, sz), Wd))
+        base = shards
     packed = [base[i % a.distinct][0].to(dev) for i in range(a.layers)]
     # .to(dev) of a host blob allocates a fresh device buffer per call: L distinct HBM regions
     assert len({p.blob.data_ptr() for p in packed}) == a.layers
-    grp = GroupedGemv(packed, None, M=a.M, device=dev)
+    grp = GroupedGemv(packed, None, M=a.M, device=dev, out_f32=tp)
     for i, t in enumerate(grp.x):
-        t.copy_(torch.from_numpy(synth.activations((a.M, a.K), 5000 + i + 1000 * rank, 21)))
+        xi = synth.activations((a.M, a.K), 5000 + i + (0 if tp else 1000 * rank), 21)
+        t.copy_(torch.from_numpy(np.ascontiguousarray(xi[:, c0:c0 + Kloc])))
     torch.cuda.synchronize()
 
     singles = [PBLinear(p, None) for p in packed] if a.mode != "grouped" else None
@@ -118,6 +142,8 @@ def main():
     def step():
         if a.mode == "grouped":
             grp.launch()
+            if tp:
+                dist.all_reduce(grp.y_all)
         else:
             for m, x in zip(singles, grp.x):
                 m(x)
@@ -138,7 +164,7 @@ def main():
     for _ in range(a.warmup):
         run()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -148,12 +174,12 @@ def main():
         run()
     e1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_s = e0.elapsed_time(e1) * 1e-3
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([wall, dev_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_s = tt.tolist()
@@ -166,17 +192,18 @@ def main():
         achieved = b_launch / per_launch_s / 1e9
         out = {
             "metric": "PB-linear GEMV tokens/sec + achieved HBM GB/s, llama-7b 4096x4096 low_frac=0.9",
-            "value": world * a.layers * a.M * a.steps / wall,
+            "value": (1 if tp else world) * a.layers * a.M * a.steps / wall,
             "unit": "layer-tokens/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * wall / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None,
             "dtype": "f16 (x, y) / 1-bit + u8 weights, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"llama-7b q_proj {a.N}x{a.K} xnor low_frac={a.low_frac} + int8 salient, "
                                    f"bs={a.M} GEMV, stream of {a.layers} layer blobs at distinct HBM addresses "
                                    f"({a.distinct} distinct weight sets), mode={a.mode}",
                        "layers_per_step": a.layers, "tokens": a.M,
-                       "parallelism": f"dp{world} (independent layer streams, no collective)"},
+                       "parallelism": (f"tp{world} (every layer K-split, one RCCL all-reduce of [L,M,N] fp32 per step)" if tp
+                                       else f"dp{world} (independent layer streams, no collective)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "pbl_gemv_kernel<1,4>" if a.mode == "grouped" else "pbl_gemv_kernel<1,1>",
@@ -188,7 +215,7 @@ def main():
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline([b[1] for b in base], a.K, a.M)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

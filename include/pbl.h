@@ -172,10 +172,11 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
 /* L independent layers in ONE launch (decode-time fused QKV / gate+up, and the
  * stream benchmark of SURVEY.md 8(d)).  layers_dev: DEVICE array of L pbl_layer;
  * x_dev / y_dev: DEVICE arrays of L pointers (fp16 [M,K_l] / fp16 [M,N_l]);
- * max_NRB, max_lds: maxima over the group (host knows them).  M <= 4. */
+ * max_NRB, max_K, max_nch, max_nexc: maxima over the group (the host knows them).  M <= 4.
+ * y_f32 != 0: every y_l is fp32 (tensor-parallel partial sums). */
 int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, void* const* y_dev,
                          int L, int M, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch,
-                         uint32_t max_nexc, int any_groups, void* stream);
+                         uint32_t max_nexc, int any_groups, int y_f32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,7 +67,7 @@ def lib() -> C.CDLL:
     L.pbl_linear_f16.restype = C.c_int
     L.pbl_linear_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
     L.pbl_gemv_f16_grouped.restype = C.c_int
-    L.pbl_gemv_f16_grouped.argtypes = [vp, vp, vp, C.c_int, C.c_int, u32, u32, u32, u32, C.c_int, vp]
+    L.pbl_gemv_f16_grouped.argtypes = [vp, vp, vp, C.c_int, C.c_int, u32, u32, u32, u32, C.c_int, C.c_int, vp]
     _lib = L
     return L
 

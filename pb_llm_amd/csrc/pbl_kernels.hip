@@ -518,13 +518,13 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
 
 int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, void* const* y_dev, int Lc,
                          int M, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch, uint32_t max_nexc,
-                         int any_groups, void* stream) {
+                         int any_groups, int y_f32, void* stream) {
     (void)max_nexc;
     if (!layers_dev || !x_dev || !y_dev || Lc < 1 || M < 1 || M > PBL_MAX_TOKENS_PER_LAUNCH)
         return PBL_ERR_INVALID_ARG;
     if (any_groups || Lc > 65535) return PBL_ERR_UNSUPPORTED;
     GemvArgs a{};
-    a.layers = layers_dev; a.xs = x_dev; a.ys = y_dev; a.M = M; a.y_f32 = 0; a.grouped = 1;
+    a.layers = layers_dev; a.xs = x_dev; a.ys = y_dev; a.M = M; a.y_f32 = y_f32; a.grouped = 1;
     const int wpb = 4;
     const uint32_t P = (max_K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS;
     const dim3 grid((max_NRB + wpb - 1) / wpb, Lc, 1);

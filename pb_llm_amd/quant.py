@@ -32,9 +32,11 @@ class BinaryInterface:
         return {"weight": self.weight.data.half().cpu(), "bias": self.bias}
 
 
-def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: torch.Tensor) -> torch.Tensor:
+def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: torch.Tensor,
+                      out_f32: bool = False) -> torch.Tensor:
     """y = F.linear(x, w_sim, bias) through libpbl (pbl_linear_f16).  x [..., K] on
-    the GPU, fp16 (native) or fp32/bf16 (split into two fp16 terms, fp32 output)."""
+    the GPU, fp16 (native) or fp32/bf16 (split into two fp16 terms, fp32 output).
+    out_f32: return the fp32 accumulator unrounded (tensor-parallel partial sums)."""
     if not x.is_cuda:
         raise _lib.PblError("PB linear forward needs a GPU tensor: the HIP kernel is the only compute path")
     if x.shape[-1] != packed.K:
@@ -51,8 +53,8 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
         return x.new_zeros(*lead, packed.N)
     if x.dtype == torch.float16:
         xc = x2.contiguous()
-        y = torch.empty(M, packed.N, dtype=torch.float16, device=x.device)
-        _lib.check(L.pbl_linear_f16(C.byref(layer), xc.data_ptr(), y.data_ptr(), M, 0, stream), "linear")
+        y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
+        _lib.check(L.pbl_linear_f16(C.byref(layer), xc.data_ptr(), y.data_ptr(), M, int(out_f32), stream), "linear")
         return y.reshape(*lead, packed.N)
     # fp32 / bf16 activations: x = x_hi + x_lo with both terms fp16; the kernel is
     # linear in x, so y = W x_hi + W x_lo accumulated in fp32 (bias added once).
@@ -66,7 +68,7 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     out = y[:M] + y[M:]
     if bias_f32 is not None:
         out = out + bias_f32
-    return out.to(x.dtype).reshape(*lead, packed.N)
+    return (out if out_f32 else out.to(x.dtype)).reshape(*lead, packed.N)
 
 
 class PBLinear(nn.Module, BinaryInterface):

@@ -18,7 +18,7 @@ class GroupedGemv:
     """y_l = x_l @ W_l^T (+ b_l) for l in 0..L-1, all in one launch.  M <= 4 tokens."""
 
     def __init__(self, packed: list[PackedWeight], biases: list[torch.Tensor | None] | None = None,
-                 M: int = 1, device="cuda", shared_x: bool = False):
+                 M: int = 1, device="cuda", shared_x: bool = False, out_f32: bool = False):
         if not packed:
             raise ValueError("empty group")
         if not 1 <= M <= _lib.PBL_MAX_TOKENS_PER_LAUNCH:
@@ -36,7 +36,12 @@ class GroupedGemv:
             self.x = [xs] * len(self.packed)
         else:
             self.x = [torch.zeros(M, p.K, dtype=torch.float16, device=self.device) for p in self.packed]
-        self.y = [torch.empty(M, p.N, dtype=torch.float16, device=self.device) for p in self.packed]
+        # one contiguous output buffer (a single all-reduce covers the whole group when sharded)
+        self.out_f32 = out_f32
+        self.y_all = torch.empty(sum(M * p.N for p in self.packed), dtype=torch.float32 if out_f32 else torch.float16,
+                                 device=self.device)
+        offs = np.cumsum([0] + [M * p.N for p in self.packed])
+        self.y = [self.y_all[offs[i]:offs[i + 1]].view(M, p.N) for i, p in enumerate(self.packed)]
         structs = (_lib.PblLayer * len(self.packed))(*[p.layer_struct(b) for p, b in zip(self.packed, self.biases)])
         raw = np.frombuffer(bytes(structs), dtype=np.uint8).copy()
         self._layers_dev = torch.from_numpy(raw).to(self.device)
@@ -58,5 +63,6 @@ class GroupedGemv:
         st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
         _lib.check(_lib.lib().pbl_gemv_f16_grouped(
             self._layers_dev.data_ptr(), self._x_ptrs.data_ptr(), self._y_ptrs.data_ptr(), len(self.packed),
-            self.M, self.max_NRB, self.max_K, self.max_nch, self.max_nexc, self.any_groups, st), "grouped gemv")
+            self.M, self.max_NRB, self.max_K, self.max_nch, self.max_nexc, self.any_groups, int(self.out_f32), st),
+            "grouped gemv")
         return self.y
