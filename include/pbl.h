@@ -45,7 +45,8 @@
  *   +400  [G>1 only]   ghl[16][G] (8 B each): f32 hi, lo per column group
  *   +T    tiles[P]     1 KiB each: the sign plane of 16 rows x 512 columns
  *   +off_sal: col0[nch_pad] (u16, nch = nfull+ntail, padded to x8), delta[nch][16] (u8),
- *             code[nch][16] (u8), tailcnt[ntail_pad16] (u8), exc[nexc] (pbl_exception, 8 B)
+ *             code[nch][16] (u8), tailcnt[ntail_pad16] (u8), [G>1 only] crow[nch_pad16] (u8,
+ *             row-in-block of each chunk), exc[nexc] (pbl_exception, 8 B)
  *
  * Sign-plane tile p: lane l (0..63) owns 4 dwords at byte ((p*64+l)*4+i)*4, i=0..3.
  *   dword i covers columns c = 512p + 128i + 2l + e, e in {0,1}.

@@ -80,6 +80,13 @@ def decode(blob: np.ndarray) -> np.ndarray:
         s += 16 * nch
         tailcnt = rec[s: s + ntail].astype(np.int64)
         s += _a16(ntail)
+        if G > 1:
+            crow = rec[s: s + nch].astype(np.int64)
+            s += _a16(nch)
+            for rho in range(16):   # crow must agree with rowinfo
+                ri = rowinfo[rho]
+                assert (crow[int(ri["start"]): int(ri["start"]) + int(ri["nfull"])] == rho).all()
+                assert (crow[nfull + int(ri["tailidx"]): nfull + int(ri["tailidx"]) + int(ri["ntail"])] == rho).all()
         exc = rec[s: s + 8 * nexc].view(np.dtype([("col", "<u2"), ("row", "<u2"), ("value", "<f4")]))
         assert not (delta & 1).any(), "deltas are stored doubled"
         cols = col0[:, None] + np.cumsum(delta // 2, axis=1)

@@ -23,12 +23,12 @@ struct Entry { uint16_t col; uint8_t code; };
 
 struct RecBuild {
     std::vector<uint16_t> col0_full, col0_tail;
-    std::vector<uint8_t> delta_full, code_full, delta_tail, code_tail, tailcnt;
+    std::vector<uint8_t> delta_full, code_full, delta_tail, code_tail, tailcnt, crow_full, crow_tail;
     std::vector<pbl_exception> exc;
     pbl_rowinfo ri[16];
     void clear() {
         col0_full.clear(); col0_tail.clear(); delta_full.clear(); code_full.clear();
-        delta_tail.clear(); code_tail.clear(); tailcnt.clear(); exc.clear();
+        delta_tail.clear(); code_tail.clear(); tailcnt.clear(); exc.clear(); crow_full.clear(); crow_tail.clear();
         std::memset(ri, 0, sizeof(ri));
     }
 };
@@ -46,10 +46,11 @@ size_t record_fixed_bytes(uint32_t P, uint32_t G) {
     return s + size_t(P) * 1024;
 }
 
-size_t record_sal_bytes(size_t nch, size_t ntail, size_t nexc) {
+size_t record_sal_bytes(size_t nch, size_t ntail, size_t nexc, uint32_t G) {
     size_t s = align16(nch * 2);       // col0
     s += nch * 16 * 2;                 // delta + code
     s += align16(ntail);               // tailcnt
+    if (G > 1) s += align16(nch);      // crow: row-in-block of every chunk
     s += nexc * sizeof(pbl_exception);
     return align16(s);
 }
@@ -165,12 +166,14 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
                     rb.col0_full.push_back(ents[i].col);
                     rb.delta_full.insert(rb.delta_full.end(), d, d + 16);
                     rb.code_full.insert(rb.code_full.end(), q, q + 16);
+                    rb.crow_full.push_back(uint8_t(rho));
                     ++nfull;
                 } else {
                     rb.col0_tail.push_back(ents[i].col);
                     rb.delta_tail.insert(rb.delta_tail.end(), d, d + 16);
                     rb.code_tail.insert(rb.code_tail.end(), q, q + 16);
                     rb.tailcnt.push_back(uint8_t(cnt));
+                    rb.crow_tail.push_back(uint8_t(rho));
                     ++ntail;
                 }
                 i = j;
@@ -182,7 +185,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
 
         const size_t nfull = rb.col0_full.size(), ntail = rb.col0_tail.size(), nch = nfull + ntail;
         if (nch > 65535) return PBL_ERR_UNSUPPORTED;
-        const size_t rec_bytes = fixed + record_sal_bytes(nch, ntail, rb.exc.size());
+        const size_t rec_bytes = fixed + record_sal_bytes(nch, ntail, rb.exc.size(), G);
         rb_info[b] = {uint32_t(cur / 16), uint32_t(nfull), uint32_t(ntail), uint32_t(rb.exc.size())};
         max_nch = std::max<uint32_t>(max_nch, uint32_t(nch));
         max_nexc = std::max<uint32_t>(max_nexc, uint32_t(rb.exc.size()));
@@ -210,6 +213,11 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
             s += nch * 16;
             if (ntail) std::memcpy(s, rb.tailcnt.data(), ntail);
             s += align16(ntail);
+            if (G > 1) {
+                if (nfull) std::memcpy(s, rb.crow_full.data(), nfull);
+                if (ntail) std::memcpy(s + nfull, rb.crow_tail.data(), ntail);
+                s += align16(nch);
+            }
             if (!rb.exc.empty()) std::memcpy(s, rb.exc.data(), rb.exc.size() * sizeof(pbl_exception));
         }
         cur += rec_bytes;
@@ -268,7 +276,7 @@ int pbl_unpack_dense_f32(const void* host_blob, size_t bytes, float* Wout) {
         const uint8_t* delta = s + align16(nch * 2);
         const uint8_t* code = delta + nch * 16;
         const uint8_t* tailcnt = code + nch * 16;
-        const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(tailcnt + align16(rh.ntail));
+        const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(tailcnt + align16(rh.ntail) + (G > 1 ? align16(nch) : 0));
         for (int rho = 0; rho < 16; ++rho) {
             const uint32_t r = b * 16 + rho;
             if (r >= N) continue;

@@ -469,6 +469,244 @@ int launch(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
                ? PBL_OK : PBL_ERR_LAUNCH;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Column-group variant (G > 1: per-(row, group) hi/lo, gptq_pb --groupsize 128).  Same
+// record format and bit classes; the 16 accumulators are flushed into per-row totals at
+// every group boundary with per-(row,group) coefficients  ca = alpha*A_c,  cb = mu - alpha*B_c
+// kept in LDS, and the salient correction looks hi up per entry.  A correctness-first
+// kernel for the non-default configuration; the G == 1 kernel above is the tuned one.
+template <int MB, int WPB>
+__global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArgs args, int gshift) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    pbl_layer L;
+    const _Float16* xg;
+    void* yg;
+    if (args.grouped) {
+        L = args.layers[blockIdx.y];
+        xg = static_cast<const _Float16*>(args.xs[blockIdx.y]);
+        yg = args.ys[blockIdx.y];
+    } else {
+        L = args.layer; xg = args.x; yg = args.y;
+    }
+    const uint32_t rb0 = blockIdx.x * WPB;
+    if (rb0 >= L.NRB) return;
+    const int K = int(L.K), P = int(L.P), G = int(L.G);
+    const int Kp = P * PBL_PANEL_COLS, xstride = Kp + 8;
+    const int gw = (K / G) / 128;  // dwords of a lane per column group
+    _Float16* xs = reinterpret_cast<_Float16*>(smem);
+    char* after_x = smem + ((size_t(MB) * xstride * 2 + 15) & ~size_t(15));
+    float2* cacb = reinterpret_cast<float2*>(after_x) + size_t(wave) * G * 16;          // [g][rho]
+    float* hitab = reinterpret_cast<float*>(after_x + size_t(WPB) * G * 16 * 8) + size_t(wave) * G * 16;
+    char* after_tab = after_x + size_t(WPB) * G * 16 * 12;
+    float2* part = reinterpret_cast<float2*>(after_tab) + size_t(wave) * L.max_nch * MB;
+    float* partH = reinterpret_cast<float*>(after_tab + size_t(WPB) * L.max_nch * MB * 8) + size_t(wave) * L.max_nch * MB;
+
+    const uint32_t rb = rb0 + wave;
+    const bool active = rb < L.NRB;
+    const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
+    const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[active ? rb : rb0];
+    const uint8_t* rec = blob + size_t(__builtin_amdgcn_readfirstlane(info.x)) * 16;
+    const int nfull = __builtin_amdgcn_readfirstlane(info.y);
+    const int ntail = __builtin_amdgcn_readfirstlane(info.z);
+    const int nexc = __builtin_amdgcn_readfirstlane(info.w);
+    const int nch = nfull + ntail;
+    const uint32_t tiles_off = (400u + 128u * uint32_t(G) + 15u) & ~15u;
+    const uint32_t off_sal = tiles_off + uint32_t(P) * 1024u;
+
+    {   // stage x, build this wave's coefficient tables
+        const int nthr = WPB * PBL_WAVE;
+        for (int m = 0; m < MB; ++m) {
+            for (int i = tid; i < K; i += nthr) xs[m * xstride + i] = xg[size_t(m) * K + i];
+            for (int i = K + tid; i < xstride; i += nthr) xs[m * xstride + i] = _Float16(0);
+        }
+        if (active) {
+            const float2* ghl = reinterpret_cast<const float2*>(rec + 400);
+            for (int idx = lane; idx < 16 * G; idx += PBL_WAVE) {
+                const int rho = idx & 15, g = idx >> 4;
+                const float2 hl = ghl[rho * G + g];
+                float A, B;
+                class_consts(rho & 7, A, B);
+                const float al = 0.5f * (hl.x - hl.y), mu = 0.5f * (hl.x + hl.y);
+                cacb[idx] = make_float2(al * A, fmaf(-al, B, mu));
+                hitab[idx] = hl.x;
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+
+    float acc[MB][16], tot[MB][16], xl[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        xl[m] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[m][r] = 0.f; tot[m][r] = 0.f; }
+    }
+    uint32_t c_one = 0x3C003C00u;
+    asm volatile("" : "+v"(c_one));
+    const u32x4* tiles = reinterpret_cast<const u32x4*>(rec + tiles_off) + lane;
+    int wi = 0, g = 0;
+    for (int p = 0; p < P; ++p) {
+        const u32x4 t = __builtin_nontemporal_load(tiles + p * 64);
+        const uint32_t* xw = reinterpret_cast<const uint32_t*>(xs + p * PBL_PANEL_COLS) + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t xr[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) xr[m] = xw[(m * xstride) / 2 + i * 64];
+            word_step<MB>(t[i], c_one, xr, acc, xl);
+            if (++wi == gw) {
+                if (g < G) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float2 c = cacb[g * 16 + r];
+#pragma unroll
+                        for (int m = 0; m < MB; ++m)
+                            tot[m][r] = fmaf(c.y, xl[m], fmaf(c.x, acc[m][r], tot[m][r]));
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    xl[m] = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+                }
+                wi = 0;
+                ++g;
+            }
+        }
+    }
+    float T[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) T[m] = transpose_reduce16(tot[m], lane);
+
+    // salient chunks: per entry  q*x, x and hi[row][group(col)]*x
+    const uint8_t* sal = rec + off_sal;
+    const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
+    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + ((size_t(nch) * 2 + 15) & ~size_t(15)));
+    const u32x4* codep = deltap + nch;
+    const uint8_t* tailcnt = reinterpret_cast<const uint8_t*>(codep + nch);
+    const uint8_t* crow = tailcnt + ((size_t(ntail) + 15) & ~size_t(15));
+    for (int base = 0; base < nch; base += PBL_WAVE) {
+        const int c = base + lane;
+        if (c < nch) {
+            const u32x4 d4 = deltap[c], q4 = codep[c];
+            const int cnt = c >= nfull ? int(tailcnt[c - nfull]) : 16;
+            const int row = crow[c];
+            uint32_t col2 = 2u * col0p[c];
+            float Q[MB], S[MB], H[MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { Q[m] = 0.f; S[m] = 0.f; H[m] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                col2 += (d4[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                if (k < cnt) {
+                    const uint32_t col = col2 >> 1;
+                    const float qf = float((q4[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                    const float hv = hitab[(col >> gshift) * 16 + row];
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) {
+                        const float xv = float(xs[m * xstride + col]);
+                        Q[m] = fmaf(qf, xv, Q[m]);
+                        S[m] += xv;
+                        H[m] = fmaf(hv, xv, H[m]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                part[size_t(m) * L.max_nch + c] = make_float2(Q[m], S[m]);
+                partH[size_t(m) * L.max_nch + c] = H[m];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int rho = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    const int sub = lane & 3;
+    const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16)[rho];
+    const pbl_rowparams pr = reinterpret_cast<const pbl_rowparams*>(rec + 144)[rho];
+    const uint32_t row = rb * 16 + rho;
+    const uint2* exc = reinterpret_cast<const uint2*>(crow + ((size_t(nch) + 15) & ~size_t(15)));
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        float Q = 0.f, S = 0.f, H = 0.f;
+        const float2* pm = part + size_t(m) * L.max_nch;
+        const float* ph = partH + size_t(m) * L.max_nch;
+        for (int k = sub; k < int(ri.nfull); k += 4) {
+            const float2 v = pm[ri.start + k];
+            Q += v.x; S += v.y; H += ph[ri.start + k];
+        }
+        for (int k = sub; k < int(ri.ntail); k += 4) {
+            const float2 v = pm[nfull + ri.tailidx + k];
+            Q += v.x; S += v.y; H += ph[nfull + ri.tailidx + k];
+        }
+        Q = quad_sum(Q); S = quad_sum(S); H = quad_sum(H);
+        float e = 0.f;
+        for (int k = 0; k < nexc; ++k) {
+            const uint2 ex = exc[k];
+            if (int(ex.x >> 16) == rho) {
+                const uint32_t col = ex.x & 0xFFFFu;
+                e += (__builtin_bit_cast(float, ex.y) - hitab[(col >> gshift) * 16 + rho]) * float(xs[m * xstride + col]);
+            }
+        }
+        float yv = T[m] + (fmaf(pr.sscale, fmaf(-pr.szero, S, Q), -H)) + e;
+        if (L.bias && row < L.N) yv += L.bias[row];
+        if (sub == 0 && row < L.N) {
+            if (args.y_f32) static_cast<float*>(yg)[size_t(m) * L.N + row] = yv;
+            else static_cast<_Float16*>(yg)[size_t(m) * L.N + row] = _Float16(yv);
+        }
+    }
+}
+
+size_t lds_bytes_groups(uint32_t P, uint32_t G, uint32_t max_nch, int mb, int wpb) {
+    const size_t xstride = size_t(P) * PBL_PANEL_COLS + 8;
+    size_t s = (size_t(mb) * xstride * 2 + 15) & ~size_t(15);
+    s += size_t(wpb) * G * 16 * 12;
+    s += size_t(wpb) * max_nch * mb * 12;
+    return s + 16;
+}
+
+template <int MB>
+int launch_groups(const GemvArgs& a, int gshift, dim3 grid, size_t lds, hipStream_t st) {
+    auto k = pbl_gemv_groups_kernel<MB, 1>;
+    if (lds > 160 * 1024) return PBL_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
+        return PBL_ERR_LAUNCH;
+    GemvArgs args = a;
+    void* argv[] = {&args, &gshift};
+    return hipLaunchKernel(reinterpret_cast<const void*>(k), grid, dim3(PBL_WAVE), argv, lds, st) == hipSuccess
+               ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+int linear_groups(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, hipStream_t st) {
+    const uint32_t gs = layer->K / layer->G;
+    if (layer->K % layer->G || gs % 128 || (gs & (gs - 1))) return PBL_ERR_UNSUPPORTED;  // power-of-two groups
+    int gshift = 0;
+    while ((1u << gshift) < gs) ++gshift;
+    const size_t esz = y_f32 ? 4 : 2;
+    int mb_max = 2;   // two tokens per weight pass keeps the 2x16 accumulators in registers
+    while (mb_max > 1 && lds_bytes_groups(layer->P, layer->G, layer->max_nch, mb_max, 1) > 96 * 1024) --mb_max;
+    for (int m0 = 0; m0 < M; m0 += mb_max) {
+        const int mb = M - m0 < mb_max ? M - m0 : mb_max;
+        GemvArgs a{};
+        a.layer = *layer;
+        a.x = static_cast<const _Float16*>(x) + size_t(m0) * layer->K;
+        a.y = static_cast<char*>(y) + size_t(m0) * layer->N * esz;
+        a.M = mb; a.y_f32 = y_f32; a.grouped = 0;
+        const dim3 grid(layer->NRB, 1, 1);
+        const size_t lds = lds_bytes_groups(layer->P, layer->G, layer->max_nch, mb, 1);
+        const int rc = mb == 1 ? launch_groups<1>(a, gshift, grid, lds, st) : launch_groups<2>(a, gshift, grid, lds, st);
+        if (rc != PBL_OK) return rc;
+    }
+    return PBL_OK;
+}
+
 template <int WPB>
 int launch_mb(int mb, const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     switch (mb) {
@@ -492,8 +730,8 @@ size_t pbl_gemv_lds_bytes(const pbl_layer* layer, int m) {
 int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream) {
     if (!layer || !layer->blob || !x || !y || M < 1) return PBL_ERR_INVALID_ARG;
     if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
-    if (layer->G != 1) return PBL_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (layer->G != 1) return linear_groups(layer, x, y, M, y_f32, st);
     // wide workgroups only when there are enough records to still fill 256 CUs
     const int wpb = layer->NRB >= 1024 ? 4 : 1;
     const size_t esz = y_f32 ? 4 : 2;

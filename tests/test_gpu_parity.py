@@ -105,7 +105,9 @@ def test_g4_qat_layer_gpu(tag, dt):
 # ---------------------------------------------------------------- G5 (PTQ)
 @pytest.mark.parametrize("metric,gs,rtn,lf", [("magnitude", -1, True, 0.9), ("magnitude", -1, False, 0.9),
                                                ("hessian", -1, True, 0.9), ("hessian", -1, True, 0.95),
-                                               ("hessian", -1, False, 0.9)])
+                                               ("hessian", -1, False, 0.9),
+                                               ("magnitude", 128, True, 0.9), ("magnitude", 128, False, 0.9),
+                                               ("hessian", 128, True, 0.9), ("hessian", 128, False, 0.9)])
 def test_g5_ptq_from_dense_checkpoint_gpu(metric, gs, rtn, lf):
     """The reference's own fake-quant fp16 weights, packed from the dense matrix +
     the mask file gptq_pb dumps; forward vs the reference's fp16 F.linear output."""
@@ -179,6 +181,29 @@ def test_shapes_and_batches(N, K, M, bias):
     y = layer(T(x))
     assert y.shape == (M, N)
     assert_parity(y, O.dense_linear(x, r["W_fq"], b))
+
+
+@pytest.mark.parametrize("N,K,gs,M,bias", [(33, 640, 128, 1, True), (64, 1024, 256, 3, False), (16, 512, 512, 2, True),
+                                            (4096, 4096, 128, 1, False), (100, 1536, 128, 5, True)])
+def test_column_groups(N, K, gs, M, bias):
+    """per-(row, group) levels (gptq_pb --groupsize): exact structure from the oracle's RTN"""
+    W = synth.llm_weight(N, K, seed=N + K + gs, heavy_tail=True)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, gs)
+    r = O.ptq_rtn(W, mask, 8, gs)
+    G = K // gs
+    hi = (r["scale"] + r["mean"]).reshape(G, N).T
+    lo = (-r["scale"] + r["mean"]).reshape(G, N).T
+    p = pack_dense(r["W_fq"], hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8))
+    assert p.G == G and p.nexc <= 2
+    b = synth.normal((N,), 2, 3, 0.1) if bias else None
+    x = synth.activations((M, K), N, 21)
+    y = Q.PBLinear(p.to(DEV), T(b) if bias else None)(T(x))
+    assert_parity(y, O.dense_linear(x, r["W_fq"], b))
+    W2 = r["W_fq"].copy()
+    W2[min(5, N - 1), K // 2 + 3] = 0.123456   # an exception inside a later group
+    p2 = pack_dense(W2, hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8))
+    assert p2.nexc >= 1
+    assert_parity(Q.PBLinear(p2.to(DEV), None)(T(x)), O.dense_linear(x, W2))
 
 
 def test_empty_batch_and_leading_dims():
