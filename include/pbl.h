@@ -45,8 +45,8 @@
  *   +400  [G>1 only]   ghl[16][G] (8 B each): f32 hi, lo per column group
  *   +T    tiles[P]     1 KiB each: the sign plane of 16 rows x 512 columns
  *   +off_sal: col0[nch_pad] (u16, nch = nfull+ntail, padded to x8), delta[nch][16] (u8),
- *             code[nch][16] (u8), tailcnt[ntail_pad16] (u8), [G>1 only] crow[nch_pad16] (u8,
- *             row-in-block of each chunk), exc[nexc] (pbl_exception, 8 B)
+ *             code[nch][16] (u8), tailcnt[ntail_pad16] (u8), [flags & (HAS_GROUPS|SAL_F16)] crow[nch_pad16]
+ *             (u8, row-in-block of each chunk), exc[nexc] (pbl_exception, 8 B)
  *
  * Sign-plane tile p: lane l (0..63) owns 4 dwords at byte ((p*64+l)*4+i)*4, i=0..3.
  *   dword i covers columns c = 512p + 128i + 2l + e, e in {0,1}.
@@ -97,6 +97,10 @@ typedef enum {
 
 /* flags in pbl_blob_header.flags */
 #define PBL_FLAG_HAS_GROUPS 0x1u /* G > 1: per-(row,group) hi/lo in ghl */
+#define PBL_FLAG_SAL_F16 0x2u    /* salient values are fl16(sscale*(q-szero)): the layer came from an fp16
+                                    checkpoint (gptq_pb/gptq.py:182 `.to(fp16)`).  Unpack and the GEMV both
+                                    apply the fp16 rounding (v_cvt_pk_f16_f32), so the layer is reproduced
+                                    bit-exactly. */
 
 typedef struct {
     uint32_t magic, version;
@@ -147,7 +151,7 @@ int pbl_version(void);
 int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
                        const float* hi, const float* lo,
                        const float* sscale, const float* szero,
-                       const uint8_t* sal_mask,
+                       const uint8_t* sal_mask, uint32_t flags /* PBL_FLAG_SAL_F16 or 0 */,
                        void* out, size_t out_capacity, size_t* out_bytes);
 
 /* Validate a host blob and fill a pbl_layer (blob/bias pointers are left NULL). */
@@ -174,10 +178,12 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
  * stream benchmark of SURVEY.md 8(d)).  layers_dev: DEVICE array of L pbl_layer;
  * x_dev / y_dev: DEVICE arrays of L pointers (fp16 [M,K_l] / fp16 [M,N_l]);
  * max_NRB, max_K, max_nch, max_nexc: maxima over the group (the host knows them).  M <= 4.
+ * group_flags: bit 0 = some layer has column groups (unsupported here), bit 1 = some layer
+ * has PBL_FLAG_SAL_F16.
  * y_f32 != 0: every y_l is fp32 (tensor-parallel partial sums). */
 int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, void* const* y_dev,
                          int L, int M, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch,
-                         uint32_t max_nexc, int any_groups, int y_f32, void* stream);
+                         uint32_t max_nexc, int group_flags, int y_f32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -80,7 +80,7 @@ def decode(blob: np.ndarray) -> np.ndarray:
         s += 16 * nch
         tailcnt = rec[s: s + ntail].astype(np.int64)
         s += _a16(ntail)
-        if G > 1:
+        if h["flags"] & 0x3:   # HAS_GROUPS | SAL_F16: per-chunk row ids
             crow = rec[s: s + nch].astype(np.int64)
             s += _a16(nch)
             for rho in range(16):   # crow must agree with rowinfo
@@ -90,14 +90,20 @@ def decode(blob: np.ndarray) -> np.ndarray:
         exc = rec[s: s + 8 * nexc].view(np.dtype([("col", "<u2"), ("row", "<u2"), ("value", "<f4")]))
         assert not (delta & 1).any(), "deltas are stored doubled"
         cols = col0[:, None] + np.cumsum(delta // 2, axis=1)
+        sal16 = bool(h["flags"] & 0x2)   # PBL_FLAG_SAL_F16: values went through an fp16 round trip
+
+        def deq(ss, code_vals, sz):
+            v = (ss * (code_vals - sz)).astype(np.float32)
+            return v.astype(np.float16).astype(np.float32) if sal16 else v
+
         for rho in range(16):
             ri = rowinfo[rho]
             ss, sz = np.float32(params[rho, 2]), np.float32(params[rho, 3])
             for ch in range(int(ri["start"]), int(ri["start"]) + int(ri["nfull"])):
-                W[b * 16 + rho, cols[ch]] = ss * (code[ch] - sz)
+                W[b * 16 + rho, cols[ch]] = deq(ss, code[ch], sz)
             for t in range(int(ri["tailidx"]), int(ri["tailidx"]) + int(ri["ntail"])):
                 ch, n = nfull + t, tailcnt[t]
-                W[b * 16 + rho, cols[ch, :n]] = ss * (code[ch, :n] - sz)
+                W[b * 16 + rho, cols[ch, :n]] = deq(ss, code[ch, :n], sz)
         for e in exc:
             W[b * 16 + int(e["row"]), int(e["col"])] = e["value"]
     return W[:N, :K].copy()

@@ -13,6 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpbl.so")
 
 PBL_MAX_TOKENS_PER_LAUNCH = 4
+PBL_FLAG_HAS_GROUPS = 0x1
+PBL_FLAG_SAL_F16 = 0x2
 
 
 class PblLayer(C.Structure):
@@ -57,7 +59,7 @@ def lib() -> C.CDLL:
     L.pbl_status_string.argtypes = [C.c_int]
     L.pbl_version.restype = C.c_int
     L.pbl_pack_dense_f32.restype = C.c_int
-    L.pbl_pack_dense_f32.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, vp, sz, C.POINTER(sz)]
+    L.pbl_pack_dense_f32.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp, sz, C.POINTER(sz)]
     L.pbl_blob_describe.restype = C.c_int
     L.pbl_blob_describe.argtypes = [vp, sz, C.POINTER(PblLayer)]
     L.pbl_unpack_dense_f32.restype = C.c_int

@@ -18,6 +18,8 @@ inline size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
 // Kernel-form dequant used for the representability check and by the unpacker:
 // the value HighQuantizer produces, scale * (q - zero) (gptq_pb/high_quant.py:6-8).
 inline float dequant(float sscale, float szero, int q) { return sscale * (float(q) - szero); }
+// the same value after the checkpoint's fp16 round trip (round-to-nearest-even)
+inline float dequant_f16(float sscale, float szero, int q) { return float(_Float16(dequant(sscale, szero, q))); }
 
 struct Entry { uint16_t col; uint8_t code; };
 
@@ -46,11 +48,11 @@ size_t record_fixed_bytes(uint32_t P, uint32_t G) {
     return s + size_t(P) * 1024;
 }
 
-size_t record_sal_bytes(size_t nch, size_t ntail, size_t nexc, uint32_t G) {
+size_t record_sal_bytes(size_t nch, size_t ntail, size_t nexc, bool has_crow) {
     size_t s = align16(nch * 2);       // col0
     s += nch * 16 * 2;                 // delta + code
     s += align16(ntail);               // tailcnt
-    if (G > 1) s += align16(nch);      // crow: row-in-block of every chunk
+    if (has_crow) s += align16(nch);   // crow: row-in-block of every chunk
     s += nexc * sizeof(pbl_exception);
     return align16(s);
 }
@@ -77,7 +79,9 @@ int pbl_version(void) { return PBL_VERSION; }
 
 int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
                        const float* hi, const float* lo, const float* sscale, const float* szero,
-                       const uint8_t* sal_mask, void* out, size_t cap, size_t* out_bytes) {
+                       const uint8_t* sal_mask, uint32_t flags, void* out, size_t cap, size_t* out_bytes) {
+    if (flags & ~PBL_FLAG_SAL_F16) return PBL_ERR_INVALID_ARG;
+    const bool sal16 = flags & PBL_FLAG_SAL_F16;
     if (!W || !hi || !lo || !out_bytes || N == 0 || K == 0 || G == 0) return PBL_ERR_INVALID_ARG;
     if (K > 32767 || N > (1u << 24)) return PBL_ERR_UNSUPPORTED;
     if (G > 1 && (K % G != 0 || (K / G) % 128 != 0)) return PBL_ERR_UNSUPPORTED;
@@ -136,7 +140,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
                         float qf = std::nearbyint(v / ss + sz);
                         for (int dq = 0; dq <= 2 && !coded; ++dq) {
                             int q = int(qf) + (dq == 0 ? 0 : (dq == 1 ? 1 : -1));
-                            if (q >= 0 && q <= 255 && dequant(ss, sz, q) == v) {
+                            if (q >= 0 && q <= 255 && (sal16 ? dequant_f16(ss, sz, q) : dequant(ss, sz, q)) == v) {
                                 ents.push_back({uint16_t(c), uint8_t(q)});
                                 coded = true;
                             }
@@ -185,7 +189,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
 
         const size_t nfull = rb.col0_full.size(), ntail = rb.col0_tail.size(), nch = nfull + ntail;
         if (nch > 65535) return PBL_ERR_UNSUPPORTED;
-        const size_t rec_bytes = fixed + record_sal_bytes(nch, ntail, rb.exc.size(), G);
+        const size_t rec_bytes = fixed + record_sal_bytes(nch, ntail, rb.exc.size(), G > 1 || sal16);
         rb_info[b] = {uint32_t(cur / 16), uint32_t(nfull), uint32_t(ntail), uint32_t(rb.exc.size())};
         max_nch = std::max<uint32_t>(max_nch, uint32_t(nch));
         max_nexc = std::max<uint32_t>(max_nexc, uint32_t(rb.exc.size()));
@@ -213,7 +217,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
             s += nch * 16;
             if (ntail) std::memcpy(s, rb.tailcnt.data(), ntail);
             s += align16(ntail);
-            if (G > 1) {
+            if (G > 1 || sal16) {
                 if (nfull) std::memcpy(s, rb.crow_full.data(), nfull);
                 if (ntail) std::memcpy(s + nfull, rb.crow_tail.data(), ntail);
                 s += align16(nch);
@@ -229,7 +233,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
         pbl_blob_header h;
         std::memset(&h, 0, sizeof(h));
         h.magic = PBL_MAGIC; h.version = PBL_VERSION; h.N = N; h.K = K; h.P = P; h.G = G; h.NRB = NRB;
-        h.flags = G > 1 ? PBL_FLAG_HAS_GROUPS : 0;
+        h.flags = (G > 1 ? PBL_FLAG_HAS_GROUPS : 0) | (sal16 ? PBL_FLAG_SAL_F16 : 0);
         h.max_nch = max_nch; h.max_nexc = max_nexc; h.nnz = nnz; h.nexc = nexc_total;
         h.blob_bytes = cur; h.rb_off_pos = uint32_t(rboff_pos);
         std::memcpy(blob, &h, sizeof(h));
@@ -276,7 +280,7 @@ int pbl_unpack_dense_f32(const void* host_blob, size_t bytes, float* Wout) {
         const uint8_t* delta = s + align16(nch * 2);
         const uint8_t* code = delta + nch * 16;
         const uint8_t* tailcnt = code + nch * 16;
-        const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(tailcnt + align16(rh.ntail) + (G > 1 ? align16(nch) : 0));
+        const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(tailcnt + align16(rh.ntail) + ((L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16)) ? align16(nch) : 0));
         for (int rho = 0; rho < 16; ++rho) {
             const uint32_t r = b * 16 + rho;
             if (r >= N) continue;
@@ -294,7 +298,9 @@ int pbl_unpack_dense_f32(const void* host_blob, size_t bytes, float* Wout) {
                 uint32_t col = col0[ch];
                 for (int k = 0; k < cnt; ++k) {
                     col += delta[ch * 16 + k] / 2u;
-                    if (col < K) w[col] = dequant(pr[rho].sscale, pr[rho].szero, code[ch * 16 + k]);
+                    if (col < K)
+                        w[col] = (L.flags & PBL_FLAG_SAL_F16) ? dequant_f16(pr[rho].sscale, pr[rho].szero, code[ch * 16 + k])
+                                                              : dequant(pr[rho].sscale, pr[rho].szero, code[ch * 16 + k]);
                 }
             };
             for (uint32_t k = 0; k < ri[rho].nfull; ++k) apply(size_t(ri[rho].start) + k, 16);

@@ -205,10 +205,14 @@ __device__ __forceinline__ void gather8(const uint32_t (&a)[8], uint32_t (&x)[4]
 //   Qb += dot2((1024+q0, 1024+q1), (x0, x1))   and   S += dot2((1,1), (x0,x1));
 // the true code sum is Qb - 1024*S.  Deltas are stored pre-doubled (byte steps into the
 // fp16 x tile), so one SDWA add per entry yields the LDS address.
-template <int MB, bool PRED>
+//
+// SF (PBL_FLAG_SAL_F16 layers, fp16 checkpoints): the salient weight is fl16(ss*(q-sz)); it
+// is rebuilt per entry (v_cvt_f32_ubyte, v_sub, v_mul) and the pair rounded with ONE
+// v_cvt_pk_f16_f32, so Q accumulates the exact checkpoint value times x.
+template <int MB, bool PRED, bool SF>
 __device__ __forceinline__ void chunk_accumulate(uint32_t xbase, uint32_t tok_stride_bytes, uint32_t col0,
                                                  const u32x4& d4, const u32x4& q4, int cnt, uint32_t zaddr,
-                                                 uint32_t c_one, float (&Q)[MB], float (&S)[MB]) {
+                                                 uint32_t c_one, float ss, float sz, float (&Q)[MB], float (&S)[MB]) {
     uint32_t run = xbase + 2u * col0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -225,8 +229,16 @@ __device__ __forceinline__ void chunk_accumulate(uint32_t xbase, uint32_t tok_st
             gather8(a, x);
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const uint32_t qp = __builtin_amdgcn_perm(q4[2 * h + (p >> 1)], 0x64646464u,
-                                                          (p & 1) ? 0x00070006u : 0x00050004u);
+                uint32_t qp;
+                if constexpr (SF) {
+                    const uint32_t qw = q4[2 * h + (p >> 1)] >> ((p & 1) * 16);
+                    h2 w;
+                    w.x = _Float16(ss * (float(qw & 0xFFu) - sz));
+                    w.y = _Float16(ss * (float((qw >> 8) & 0xFFu) - sz));
+                    qp = __builtin_bit_cast(uint32_t, w);
+                } else {
+                    qp = __builtin_amdgcn_perm(q4[2 * h + (p >> 1)], 0x64646464u, (p & 1) ? 0x00070006u : 0x00050004u);
+                }
                 Q[m] = dot2(qp, x[p], Q[m]);
                 S[m] = dot2(c_one, x[p], S[m]);
             }
@@ -241,7 +253,7 @@ __device__ __forceinline__ void chunk_accumulate(uint32_t xbase, uint32_t tok_st
 #ifndef PBL_MIN_WAVES
 #define PBL_MIN_WAVES 1
 #endif
-template <int MB, int WPB>
+template <int MB, int WPB, bool SF>
 __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void pbl_gemv_kernel(GemvArgs args) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -360,6 +372,15 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
         accsum[m] = transpose_reduce16(acc[m], lane);
     }
 
+    // row-owner lanes: lane l owns row rho(l) (4 lanes per row)
+    const int rho = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+    const int sub = lane & 3;
+    const pbl_rowparams pr = reinterpret_cast<const pbl_rowparams*>(rec + 144)[rho];
+    // SF layers in a mixed grouped launch are told apart at run time (wave-uniform)
+    const bool sf = SF && (L.flags & PBL_FLAG_SAL_F16);
+    const uint8_t* crow = tailcnt + ((size_t(ntail) + 15) & ~size_t(15));
+    const bool has_crow = L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16);
+
     // ---- phase 2: salient chunks (next round's loads issued before this round's math) ---
     float2* part = part_all + size_t(wave) * L.max_nch * MB;
     {
@@ -381,20 +402,31 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
             float Q[MB], S[MB];
 #pragma unroll
             for (int m = 0; m < MB; ++m) { Q[m] = 0.f; S[m] = 0.f; }
-            if (PBL_ABLATE == 1) {
-                abl ^= c0 ^ d4[0] ^ d4[1] ^ d4[2] ^ d4[3] ^ q4[0] ^ q4[1] ^ q4[2] ^ q4[3];
-            } else if (base + PBL_WAVE <= nfull) {
-                chunk_accumulate<MB, false>(xbase, tok_stride, c0, d4, q4, 16, zaddr, c_one, Q, S);
-            } else {
-                int cnt = 16;
+            int cnt = 16;
+            if (base + PBL_WAVE > nfull) {
                 if (cc >= nfull) cnt = tailcnt[cc - nfull];
                 if (!valid) cnt = 0;
-                chunk_accumulate<MB, true>(xbase, tok_stride, c0, d4, q4, cnt, zaddr, c_one, Q, S);
+            }
+            if (PBL_ABLATE == 1) {
+                abl ^= c0 ^ d4[0] ^ d4[1] ^ d4[2] ^ d4[3] ^ q4[0] ^ q4[1] ^ q4[2] ^ q4[3];
+            } else if (SF && sf) {
+                // this chunk's row -> its (scale, zero) from the row-owner lane (no memory round trip)
+                const int crw = crow[cc];
+                const int owner = ((crw & 8) << 2) | ((crw & 4) << 2) | ((crw & 2) << 2) | ((crw & 1) << 2);
+                const float ss = __shfl(pr.sscale, owner, PBL_WAVE), sz = __shfl(pr.szero, owner, PBL_WAVE);
+                if (base + PBL_WAVE <= nfull)
+                    chunk_accumulate<MB, false, true>(xbase, tok_stride, c0, d4, q4, 16, zaddr, c_one, ss, sz, Q, S);
+                else
+                    chunk_accumulate<MB, true, true>(xbase, tok_stride, c0, d4, q4, cnt, zaddr, c_one, ss, sz, Q, S);
+            } else if (base + PBL_WAVE <= nfull) {
+                chunk_accumulate<MB, false, false>(xbase, tok_stride, c0, d4, q4, 16, zaddr, c_one, 0.f, 0.f, Q, S);
+            } else {
+                chunk_accumulate<MB, true, false>(xbase, tok_stride, c0, d4, q4, cnt, zaddr, c_one, 0.f, 0.f, Q, S);
             }
             if (valid) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m)   // undo the 1024 code bias here, once per chunk
-                    part[size_t(m) * L.max_nch + c] = make_float2(fmaf(-1024.f, S[m], Q[m]), S[m]);
+                for (int m = 0; m < MB; ++m)   // code mode: undo the 1024 code bias here, once per chunk
+                    part[size_t(m) * L.max_nch + c] = make_float2((SF && sf) ? Q[m] : fmaf(-1024.f, S[m], Q[m]), S[m]);
             }
         }
     }
@@ -402,18 +434,14 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     __builtin_amdgcn_wave_barrier();
 
     // ---- phase 3: reduce, combine, store -------------------------------------------
-    const int rho = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-    const int sub = lane & 3;
     const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16)[rho];
-    const pbl_rowparams pr = reinterpret_cast<const pbl_rowparams*>(rec + 144)[rho];
     float A, B;
     class_consts(rho & 7, A, B);
     const float alpha = 0.5f * (pr.hi - pr.lo), mu = 0.5f * (pr.hi + pr.lo);
     const uint32_t row = rb * 16 + rho;
     // exceptions are read as ONE aligned 64-bit word each: a scalar load of the fp32
     // field off a 2-byte-aligned base silently drops the low address bits on gfx950
-    const uint2* exc = reinterpret_cast<const uint2*>(
-        rec + off_sal + ((size_t(nch) * 2 + 15) & ~size_t(15)) + size_t(nch) * 32 + ((size_t(ntail) + 15) & ~size_t(15)));
+    const uint2* exc = reinterpret_cast<const uint2*>(crow + (has_crow ? ((size_t(nch) + 15) & ~size_t(15)) : 0));
 
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
@@ -436,7 +464,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
         }
         // explicit fma chain: every template instantiation rounds identically (M=4 == 4 x M=1)
         const float D = fmaf(A, accsum[m], -(B * X[m]));
-        const float sal = fmaf(pr.sscale, fmaf(-pr.szero, S, Q), -(pr.hi * S));
+        const float sal = (SF && sf) ? fmaf(-pr.hi, S, Q) : fmaf(pr.sscale, fmaf(-pr.szero, S, Q), -(pr.hi * S));
         float yv = fmaf(alpha, D, fmaf(mu, X[m], sal)) + e;
         if (L.bias && row < L.N) yv += L.bias[row];
         if (PBL_ABLATE == 1 && abl == 0x9E3779B9u) yv += 1.f;
@@ -454,9 +482,9 @@ size_t lds_bytes(uint32_t P, uint32_t max_nch, int mb, int wpb) {
     return s + 16;
 }
 
-template <int MB, int WPB>
+template <int MB, int WPB, bool SF>
 int launch(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    auto k = pbl_gemv_kernel<MB, WPB>;
+    auto k = pbl_gemv_kernel<MB, WPB, SF>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return PBL_ERR_UNSUPPORTED;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -596,6 +624,8 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
             const u32x4 d4 = deltap[c], q4 = codep[c];
             const int cnt = c >= nfull ? int(tailcnt[c - nfull]) : 16;
             const int row = crow[c];
+            const pbl_rowparams cp = reinterpret_cast<const pbl_rowparams*>(rec + 144)[row];
+            const bool sf16 = L.flags & PBL_FLAG_SAL_F16;
             uint32_t col2 = 2u * col0p[c];
             float Q[MB], S[MB], H[MB];
 #pragma unroll
@@ -605,7 +635,8 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
                 col2 += (d4[k >> 2] >> (8 * (k & 3))) & 0xFFu;
                 if (k < cnt) {
                     const uint32_t col = col2 >> 1;
-                    const float qf = float((q4[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                    float qf = cp.sscale * (float((q4[k >> 2] >> (8 * (k & 3))) & 0xFFu) - cp.szero);  // the weight itself
+                    if (sf16) qf = float(_Float16(qf));
                     const float hv = hitab[(col >> gshift) * 16 + row];
 #pragma unroll
                     for (int m = 0; m < MB; ++m) {
@@ -629,7 +660,6 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
     const int rho = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
     const int sub = lane & 3;
     const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16)[rho];
-    const pbl_rowparams pr = reinterpret_cast<const pbl_rowparams*>(rec + 144)[rho];
     const uint32_t row = rb * 16 + rho;
     const uint2* exc = reinterpret_cast<const uint2*>(crow + ((size_t(nch) + 15) & ~size_t(15)));
 #pragma unroll
@@ -654,7 +684,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
                 e += (__builtin_bit_cast(float, ex.y) - hitab[(col >> gshift) * 16 + rho]) * float(xs[m * xstride + col]);
             }
         }
-        float yv = T[m] + (fmaf(pr.sscale, fmaf(-pr.szero, S, Q), -H)) + e;
+        float yv = T[m] + (Q - H) + e;
         if (L.bias && row < L.N) yv += L.bias[row];
         if (sub == 0 && row < L.N) {
             if (args.y_f32) static_cast<float*>(yg)[size_t(m) * L.N + row] = yv;
@@ -707,15 +737,19 @@ int linear_groups(const pbl_layer* layer, const void* x, void* y, int M, int y_f
     return PBL_OK;
 }
 
-template <int WPB>
-int launch_mb(int mb, const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+template <int WPB, bool SF>
+int launch_mb2(int mb, const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     switch (mb) {
-        case 1: return launch<1, WPB>(a, grid, lds, st);
-        case 2: return launch<2, WPB>(a, grid, lds, st);
-        case 3: return launch<3, WPB>(a, grid, lds, st);
-        case 4: return launch<4, WPB>(a, grid, lds, st);
+        case 1: return launch<1, WPB, SF>(a, grid, lds, st);
+        case 2: return launch<2, WPB, SF>(a, grid, lds, st);
+        case 3: return launch<3, WPB, SF>(a, grid, lds, st);
+        case 4: return launch<4, WPB, SF>(a, grid, lds, st);
         default: return PBL_ERR_INVALID_ARG;
     }
+}
+template <int WPB>
+int launch_mb(int mb, bool sf, const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    return sf ? launch_mb2<WPB, true>(mb, a, grid, lds, st) : launch_mb2<WPB, false>(mb, a, grid, lds, st);
 }
 
 }  // namespace
@@ -748,7 +782,8 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
         a.M = mb; a.y_f32 = y_f32; a.grouped = 0;
         const dim3 grid((layer->NRB + wpb - 1) / wpb, 1, 1);
         const size_t lds = lds_bytes(layer->P, layer->max_nch, mb, wpb);
-        const int rc = wpb == 4 ? launch_mb<4>(mb, a, grid, lds, st) : launch_mb<1>(mb, a, grid, lds, st);
+        const bool sf = layer->flags & PBL_FLAG_SAL_F16;
+        const int rc = wpb == 4 ? launch_mb<4>(mb, sf, a, grid, lds, st) : launch_mb<1>(mb, sf, a, grid, lds, st);
         if (rc != PBL_OK) return rc;
     }
     return PBL_OK;
@@ -760,13 +795,14 @@ int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, 
     (void)max_nexc;
     if (!layers_dev || !x_dev || !y_dev || Lc < 1 || M < 1 || M > PBL_MAX_TOKENS_PER_LAUNCH)
         return PBL_ERR_INVALID_ARG;
-    if (any_groups || Lc > 65535) return PBL_ERR_UNSUPPORTED;
+    if ((any_groups & 1) || Lc > 65535) return PBL_ERR_UNSUPPORTED;
     GemvArgs a{};
     a.layers = layers_dev; a.xs = x_dev; a.ys = y_dev; a.M = M; a.y_f32 = y_f32; a.grouped = 1;
     const int wpb = 4;
     const uint32_t P = (max_K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS;
     const dim3 grid((max_NRB + wpb - 1) / wpb, Lc, 1);
-    return launch_mb<4>(M, a, grid, lds_bytes(P, max_nch, M, wpb), static_cast<hipStream_t>(stream));
+    // any_groups bit 1: the group may contain PBL_FLAG_SAL_F16 layers (told apart per layer at run time)
+    return launch_mb<4>(M, (any_groups & 2) != 0, a, grid, lds_bytes(P, max_nch, M, wpb), static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -76,12 +76,13 @@ class PackedWeight:
         return PackedWeight(blob, h.N, h.K, h.P, h.G, h.NRB, h.flags, h.max_nch, h.max_nexc, h.nnz, h.nexc)
 
 
-def pack_dense(W, hi, lo, sscale=None, szero=None, sal_mask=None) -> PackedWeight:
+def pack_dense(W, hi, lo, sscale=None, szero=None, sal_mask=None, sal_f16: bool = False) -> PackedWeight:
     """Pack a dense simulated weight.  W [N,K]; hi, lo [N,G] (the two values the
     binarized weights of each row/group take); sscale, szero [N] (salient value =
     sscale*(q - szero), HighQuantizer's form, gptq_pb/high_quant.py:6-8) or None.
     Exact for any input: values on neither level nor the code grid are stored as
-    fp32 exceptions."""
+    fp32 exceptions.  sal_f16: W came from an fp16 checkpoint, i.e. salient values are
+    fl16(sscale*(q-szero)) (PBL_FLAG_SAL_F16)."""
     W = _f32(W)
     N, K = W.shape
     hi = _f32(hi).reshape(N, -1)
@@ -98,10 +99,11 @@ def pack_dense(W, hi, lo, sscale=None, szero=None, sal_mask=None) -> PackedWeigh
     L = _lib.lib()
     ptr = lambda a: a.ctypes.data if a is not None else None  # noqa: E731
     size = C.c_size_t(0)
-    _lib.check(L.pbl_pack_dense_f32(ptr(W), N, K, G, ptr(hi), ptr(lo), ptr(ss), ptr(sz), ptr(sm),
+    flags = _lib.PBL_FLAG_SAL_F16 if sal_f16 else 0
+    _lib.check(L.pbl_pack_dense_f32(ptr(W), N, K, G, ptr(hi), ptr(lo), ptr(ss), ptr(sz), ptr(sm), flags,
                                     None, 0, C.byref(size)), "pack(size)")
     blob = torch.empty(size.value, dtype=torch.uint8)
-    _lib.check(L.pbl_pack_dense_f32(ptr(W), N, K, G, ptr(hi), ptr(lo), ptr(ss), ptr(sz), ptr(sm),
+    _lib.check(L.pbl_pack_dense_f32(ptr(W), N, K, G, ptr(hi), ptr(lo), ptr(ss), ptr(sz), ptr(sm), flags,
                                     blob.data_ptr(), size.value, C.byref(size)), "pack")
     return PackedWeight.from_blob(blob)
 
@@ -132,11 +134,43 @@ def infer_levels(W: np.ndarray, groupsize: int = -1, low_mask: np.ndarray | None
     return hi, lo
 
 
-def infer_code_grid(W: np.ndarray, hi: np.ndarray, lo: np.ndarray, groupsize: int = -1):
-    """Per-row affine grid (sscale, szero) of the values that are on neither level:
-    sscale = smallest positive gap between distinct such values, szero chosen so
-    the smallest code is 0.  Values that are off the inferred grid simply become
-    exceptions in the packer, so a wrong guess costs bytes, never correctness."""
+def _best_scale(v: np.ndarray, n: np.ndarray, cands: np.ndarray, sal_f16: bool):
+    """Among fp32 candidate scales, the one reproducing most values v == fl(c * n) exactly."""
+    best = (-1, np.float32(cands[0]))
+    nf = n.astype(np.float32)
+    for c in cands:
+        rec = (np.float32(c) * nf).astype(np.float32)
+        if sal_f16:
+            rec = rec.astype(np.float16).astype(np.float32)
+        hits = int(np.count_nonzero(rec == v))
+        if hits > best[0]:
+            best = (hits, np.float32(c))
+    return best[1]
+
+
+def _spectral_scale(v64: np.ndarray) -> float | None:
+    """Grid pitch of values known to be (noisy) integer multiples of an unknown step: the
+    LARGEST s whose integrality score  mean cos(2 pi v / s)  is near the maximum (sub-multiples
+    s/2, s/3 score as well, hence "largest").  Used when the quick estimates fail, e.g. after
+    GPTQ error feedback has moved the row extremes off codes 0 / 255."""
+    span = float(v64[-1] - v64[0])
+    if span <= 0:
+        return None
+    sub = v64 if v64.size <= 96 else v64[np.linspace(0, v64.size - 1, 96).astype(int)]
+    s_grid = np.exp(np.arange(np.log(span / 255.0 * 0.98), np.log(span / 4.0), 4e-4))
+    score = np.cos(2.0 * np.pi * sub[None, :] / s_grid[:, None]).mean(1)
+    good = np.nonzero(score >= 0.9 * score.max())[0]
+    return float(s_grid[good[-1]]) if good.size else None
+
+
+def infer_code_grid(W: np.ndarray, hi: np.ndarray, lo: np.ndarray, groupsize: int = -1, sal_f16: bool = False):
+    """Per-row affine grid (sscale, szero) of the values that are on neither level, i.e.
+    HighQuantizer's scale*(q-zero) (gptq_pb/high_quant.py:6-8) re-discovered from a dense
+    checkpoint.  Estimate: the row's extreme off-level values are codes 0 and 255 (the row's
+    min / max weight are always salient), refined by least squares and an exact-match search
+    over neighbouring fp32 scales (through the fp16 round trip when sal_f16).  Values that
+    stay off the inferred grid become exceptions in the packer, so a poor guess costs bytes,
+    never correctness."""
     W = _f32(W)
     N, K = W.shape
     gs = K if groupsize == -1 else groupsize
@@ -151,32 +185,41 @@ def infer_code_grid(W: np.ndarray, hi: np.ndarray, lo: np.ndarray, groupsize: in
             continue
         if v.size == 1:
             ss[r] = abs(v[0]) if v[0] != 0 else 1.0
-            sz[r] = 0.0 if v[0] >= 0 else 2.0  # value = ss*(q - sz): q=1 or q=1 with sz=2 -> -ss
-            if v[0] == 0:
-                sz[r] = 0.0
+            sz[r] = 2.0 if v[0] < 0 else 0.0     # value = ss*(1 - sz)
             continue
-        gaps = np.diff(v.astype(np.float64))
-        s = float(gaps[gaps > 0].min())
-        span = np.rint((v[-1] - v[0]) / s)
-        if 1 <= span <= 255:
-            s = float((v[-1] - v[0]) / span)
-        # the true scale is an fp32 number: pick the neighbour of the estimate that
-        # reproduces the most values bit-exactly as fl32(s*(q - z))
-        best = (-1, np.float32(s), np.float32(0))
-        cand = np.float32(s)
-        cands = [cand]
-        for _ in range(3):
-            cands.append(np.nextafter(cands[-1], np.float32(np.inf)))
-        cand = np.float32(s)
-        for _ in range(3):
-            cand = np.nextafter(cand, np.float32(-np.inf))
-            cands.append(cand)
-        for c in cands:
-            z = np.float32(-np.rint(v[0] / c))
-            q = np.rint(v / c) + z
-            rec = (c * (q.astype(np.float32) - z)).astype(np.float32)
-            hits = int(np.count_nonzero((rec == v) & (q >= 0) & (q <= 255)))
-            if hits > best[0]:
-                best = (hits, c, z)
-        ss[r], sz[r] = best[1], best[2]
+        v64 = v.astype(np.float64)
+        gaps = np.diff(v64)
+        gmin = float(gaps[gaps > 0].min())
+        # coarse scales: full range / 255 (both extreme codes present: magnitude saliency) and the
+        # smallest gap or a fraction of it (adjacent codes need not both occur)
+        coarse = [(v64[-1] - v64[0]) / 255.0, gmin, gmin / 2.0, gmin / 3.0, None]
+        best = None
+        for s0 in coarse:
+            if s0 is None:                          # last resort, only if nothing fitted well
+                if best is not None and best[0] >= 0.98 * v.size:
+                    break
+                s0 = _spectral_scale(v64)
+                if s0 is None:
+                    break
+            s1, ok = s0, True
+            for lim in (4, 16, 64, 1 << 30):       # progressive least squares, small |n| first:
+                n = np.rint(v64 / s1)               # the coarse estimate only has to be right to
+                sel = (np.abs(n) <= lim) & (n != 0)  # within 0.5/lim for the codes it is fitted on
+                if sel.any():
+                    s1 = float((v64[sel] * n[sel]).sum() / (n[sel] * n[sel]).sum())
+            n = np.rint(v64 / s1)
+            if n.max() - n.min() > 255 or not np.any(n):
+                continue
+            width = 6e-5 if sal_f16 else 4e-7
+            cands = np.unique((s1 * (1.0 + np.linspace(-width, width, 241))).astype(np.float32))
+            c = _best_scale(v, n, cands, sal_f16)
+            rec = (c * n.astype(np.float32)).astype(np.float32)
+            if sal_f16:
+                rec = rec.astype(np.float16).astype(np.float32)
+            hits = int(np.count_nonzero(rec == v))
+            if best is None or hits > best[0]:
+                # any integer zero point with all codes in [0,255] reproduces the same values
+                best = (hits, c, np.float32(-n.min()))
+        if best is not None:
+            ss[r], sz[r] = best[1], best[2]
     return ss, sz

@@ -100,9 +100,10 @@ class PBLinear(nn.Module, BinaryInterface):
             sz = np.asarray(high_zero.detach().cpu().numpy() if isinstance(high_zero, torch.Tensor) else high_zero,
                             np.float32).reshape(-1)
         else:
-            ss, sz = infer_code_grid(Wn, hi, lo, groupsize)
+            ss, sz = infer_code_grid(Wn, hi, lo, groupsize, sal_f16=W_fq.dtype == torch.float16)
         sal = (~lm).astype(np.uint8) if lm is not None else None
-        return cls(pack_dense(Wn, hi, lo, ss, sz, sal), bias, W_fq.dtype)
+        # an fp16 checkpoint holds fl16(scale*(q-zero)) at the salient positions (gptq.py:182)
+        return cls(pack_dense(Wn, hi, lo, ss, sz, sal, sal_f16=W_fq.dtype == torch.float16), bias, W_fq.dtype)
 
     @classmethod
     def from_quantizers(cls, W: torch.Tensor, low_mask: torch.Tensor, mean, scale, hscale, hzero,
@@ -133,7 +134,7 @@ class PBLinear(nn.Module, BinaryInterface):
         if dtype == torch.float16:  # the reference stores the result in the checkpoint dtype
             out, hi, lo = out.half().float(), hi.half().float(), lo.half().float()
         packed = pack_dense(out.numpy(), hi.numpy(), lo.numpy(), hs.reshape(-1).numpy(), hz.reshape(-1).numpy(),
-                            (~lm).numpy().astype(np.uint8))
+                            (~lm).numpy().astype(np.uint8), sal_f16=dtype == torch.float16)
         return cls(packed, bias, dtype)
 
     # -- nn.Linear surface ----------------------------------------------------------

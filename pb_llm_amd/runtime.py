@@ -51,7 +51,8 @@ class GroupedGemv:
         self.max_K = Kmax
         self.max_nch = max(p.max_nch for p in self.packed)
         self.max_nexc = max(p.max_nexc for p in self.packed)
-        self.any_groups = int(any(p.G > 1 for p in self.packed))
+        # bit 0: column groups present (unsupported in a grouped launch), bit 1: fp16-checkpoint layers present
+        self.any_groups = int(any(p.G > 1 for p in self.packed)) | (2 * int(any(p.flags & _lib.PBL_FLAG_SAL_F16 for p in self.packed)))
 
     def algorithmic_bytes(self) -> int:
         return sum(p.algorithmic_bytes(self.M, b is not None) for p, b in zip(self.packed, self.biases))

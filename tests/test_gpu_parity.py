@@ -117,11 +117,25 @@ def test_g5_ptq_from_dense_checkpoint_gpu(metric, gs, rtn, lf):
     layer = Q.PBLinear.from_dense(torch.from_numpy(g["W_fq"]), None, torch.from_numpy(mask), gs,
                                   g["hscale"], g["hzero"]).to(DEV)
     np.testing.assert_array_equal(layer.weight.numpy(), g["W_fq"])   # exact repack of the checkpoint
+    assert layer.packed.nexc <= 8, "fp16-rounded salients must stay 1-byte codes (PBL_FLAG_SAL_F16)"
     for x, key in ((x1, "y1"), (x32, "y32")):
         y = layer(T(x))
         assert_parity(y, O.dense_linear(x, g["W_fq"]))
         assert_parity(y, g[key])
-    assert_parity(layer(T(x32).float()), g["y32_f32"], 2e-5)
+    assert_parity(layer(T(x32).float()), g["y32_f32"], 2e-5)   # salients re-rounded to fp16 in-kernel: exact weights
+
+
+@pytest.mark.parametrize("metric,gs", [("magnitude", -1), ("hessian", -1), ("magnitude", 128)])
+def test_g5_flattened_fp16_checkpoint_gpu(metric, gs):
+    """qat/eval_after_qat.py / --load_quantized see ONLY the dense fp16 matrix: structure is
+    re-inferred (levels, code grid through the fp16 rounding); forward vs the reference output."""
+    _, _, x1, x32 = g5_inputs()
+    g = golden(g5_name(metric, gs, False, 0.9))
+    layer = Q.PBLinear.from_dense(torch.from_numpy(g["W_fq"]), None, None, gs).to(DEV)
+    np.testing.assert_array_equal(layer.weight.numpy(), g["W_fq"])
+    assert layer.packed.nexc <= 0.02 * layer.packed.nnz   # off-grid leftovers only cost bytes
+    assert_parity(layer(T(x32)), g["y32"])
+    assert_parity(layer(T(x1)), O.dense_linear(x1, g["W_fq"]))
 
 
 def test_g5_from_quantizers_matches_from_dense():

@@ -121,10 +121,31 @@ def test_infer_structure_from_dense_checkpoint():
     assert p.nexc <= 0.02 * p.nnz
 
 
+def test_fp16_checkpoint_packs_as_codes_not_exceptions():
+    """gptq_pb writes W_fq back as fp16 (gptq.py:182): salient values are fl16(scale*(q-zero)).
+    With PBL_FLAG_SAL_F16 they stay 1-byte codes and unpack bit-exactly."""
+    W, mask, r = _ptq_case(64, 1024, seed=13)
+    W16 = r["W_fq"].astype(np.float16)
+    hi, lo = infer_levels(W16.astype(np.float32), -1, mask)
+    p = pack_dense(W16.astype(np.float32), hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8), sal_f16=True)
+    assert p.flags & _lib.PBL_FLAG_SAL_F16
+    assert p.nexc <= 2 and p.nnz >= int((~mask).sum()) - 2
+    np.testing.assert_array_equal(FR.decode(p.blob.numpy()), W16.astype(np.float32))
+    np.testing.assert_array_equal(p.unpack().numpy(), W16.astype(np.float32))
+    # without the flag the same matrix needs an 8-byte exception per salient weight
+    p0 = pack_dense(W16.astype(np.float32), hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8))
+    assert p0.nexc > 0.5 * int((~mask).sum()) and p.nbytes < 0.5 * p0.nbytes
+    # flattened checkpoint, nothing but the fp16 matrix: structure re-inferred through the rounding
+    from pb_llm_amd.quant import PBLinear
+    layer = PBLinear.from_dense(torch.from_numpy(W16))
+    np.testing.assert_array_equal(layer.weight.numpy(), W16)
+    assert layer.packed.nexc <= 0.05 * layer.packed.nnz
+
+
 def test_bad_arguments_and_blobs():
     L = _lib.lib()
     sz = C.c_size_t(0)
-    assert L.pbl_pack_dense_f32(None, 1, 1, 1, None, None, None, None, None, None, 0, C.byref(sz)) == -1
+    assert L.pbl_pack_dense_f32(None, 1, 1, 1, None, None, None, None, None, 0, None, 0, C.byref(sz)) == -1
     W = np.zeros((16, 512), np.float32)
     hi = np.ones((16, 3), np.float32)
     with pytest.raises(_lib.PblError):       # K % G != 0 / groupsize not a multiple of 128
