@@ -184,6 +184,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_s = tt.tolist()
 
+    traffic = None
+    try:  # HBM bytes per launch from the committed PMC profile of this exact workload (never measured here)
+        tj = json.load(open(os.path.join(REPO, "profiles", "traffic_r01.json")))
+        key = f"N{a.N}_K{a.K}_L{a.layers}_M{a.M}_lf{a.low_frac}_{a.mode}"
+        if tj.get("workload_key") == key and not tp:
+            traffic = tj["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     if rank == 0:
         b_alg = grp.algorithmic_bytes()
         launches = a.steps * (1 if a.mode == "grouped" else a.layers)
@@ -205,7 +213,7 @@ def main():
                        "parallelism": (f"tp{world} (every layer K-split, one RCCL all-reduce of [L,M,N] fp32 per step)" if tp
                                        else f"dp{world} (independent layer streams, no collective)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pbl_gemv_kernel<1,4>" if a.mode == "grouped" else "pbl_gemv_kernel<1,1>",
                          "algorithmic_bytes_per_launch": b_launch,
                          "packed_bytes_per_launch": grp.packed_bytes() / (1 if a.mode == "grouped" else a.layers),

@@ -14,6 +14,7 @@
 namespace {
 
 inline size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
+inline size_t align128(size_t x) { return (x + 127) & ~size_t(127); }
 
 // Kernel-form dequant used for the representability check and by the unpacker:
 // the value HighQuantizer produces, scale * (q - zero) (gptq_pb/high_quant.py:6-8).

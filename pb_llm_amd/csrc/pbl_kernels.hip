@@ -269,8 +269,15 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     } else {
         L = args.layer; xg = args.x; yg = args.y;
     }
-    const uint32_t rb0 = blockIdx.x * WPB;
-    if (rb0 >= L.NRB) return;  // whole workgroup exits together (grouped launches over-provision)
+    // XCD-aware record mapping (speed only, never correctness): the dispatcher places
+    // workgroup b on XCD b % 8, so give each XCD a CONTIGUOUS range of a layer's records and
+    // the 128-byte lines shared by neighbouring records stay within one L2.  Measured neutral
+    // (FETCH_SIZE 1416.8 -> 1414.0 MB per 224-layer launch): there is no inter-record reuse.
+    const uint32_t nwg = (L.NRB + WPB - 1) / WPB;
+    if (blockIdx.x >= nwg) return;  // whole workgroup exits together (grouped launches over-provision)
+    const uint32_t xq = nwg >> 3, xr_ = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const uint32_t wg = (xcd < xr_ ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq) + xi;
+    const uint32_t rb0 = wg * WPB;
 
     const int K = int(L.K), P = int(L.P);
     const int Kp = P * PBL_PANEL_COLS;
