@@ -253,8 +253,14 @@ __device__ __forceinline__ void chunk_accumulate(uint32_t xbase, uint32_t tok_st
 #ifndef PBL_MIN_WAVES
 #define PBL_MIN_WAVES 1
 #endif
-template <int MB, int WPB, bool SF>
+// SPLIT == 1: each of the WPB waves of a workgroup owns its own record (throughput mode, the
+// L-layer stream).  SPLIT > 1 (== WPB): the waves of a workgroup COOPERATE on one record --
+// wave w takes panels w, w+S, ... and salient rounds w, w+S, ... and the partial sums are
+// merged through LDS -- so one small layer (256 records at N = 4096) still puts thousands of
+// waves on the chip (latency mode, sequential decode).
+template <int MB, int WPB, bool SF, int SPLIT>
 __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void pbl_gemv_kernel(GemvArgs args) {
+    static_assert(SPLIT == 1 || SPLIT == WPB, "split mode uses every wave of the workgroup on one record");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,11 +279,13 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     // workgroup b on XCD b % 8, so give each XCD a CONTIGUOUS range of a layer's records and
     // the 128-byte lines shared by neighbouring records stay within one L2.  Measured neutral
     // (FETCH_SIZE 1416.8 -> 1414.0 MB per 224-layer launch): there is no inter-record reuse.
-    const uint32_t nwg = (L.NRB + WPB - 1) / WPB;
+    const uint32_t nwg = SPLIT > 1 ? L.NRB : (L.NRB + WPB - 1) / WPB;
     if (blockIdx.x >= nwg) return;  // whole workgroup exits together (grouped launches over-provision)
     const uint32_t xq = nwg >> 3, xr_ = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
     const uint32_t wg = (xcd < xr_ ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq) + xi;
-    const uint32_t rb0 = wg * WPB;
+    const uint32_t rb0 = SPLIT > 1 ? wg : wg * WPB;
+    const int wslot = SPLIT > 1 ? wave : 0;      // this wave's first panel / salient round
+    constexpr int WSTEP = SPLIT;                 // ... and its stride
 
     const int K = int(L.K), P = int(L.P);
     const int Kp = P * PBL_PANEL_COLS;
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
 
     // ---- record lookup + first loads, issued BEFORE x is staged so that HBM latency of
     //      the weight stream overlaps the L2->LDS copy of x and the barrier ----------------
-    const uint32_t rb = rb0 + wave;
+    const uint32_t rb = SPLIT > 1 ? rb0 : rb0 + wave;
     const bool active = rb < L.NRB;
     const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
     const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[active ? rb : rb0];
@@ -312,10 +320,11 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     uint32_t abl = 0;
     (void)abl;
     if (active && PBL_ABLATE != 2) {
-        t0 = __builtin_nontemporal_load(tiles);
-        if (P > 1) t1 = __builtin_nontemporal_load(tiles + 64);
-        if (nch > 0) {
-            const int cc = lane < nch ? lane : nch - 1;
+        if (wslot < P) t0 = __builtin_nontemporal_load(tiles + wslot * 64);
+        if (wslot + WSTEP < P) t1 = __builtin_nontemporal_load(tiles + (wslot + WSTEP) * 64);
+        if (nch > wslot * PBL_WAVE) {
+            const int c_first = wslot * PBL_WAVE + lane;
+            const int cc = c_first < nch ? c_first : nch - 1;
             s_c0 = col0p[cc];
             s_d4 = __builtin_nontemporal_load(deltap + cc);
             s_q4 = __builtin_nontemporal_load(codep + cc);
@@ -354,9 +363,9 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     // fp16x2 (1.0, 1.0) kept in a VGPR the compiler cannot constant-fold into a literal
     uint32_t c_one = 0x3C003C00u;
     asm volatile("" : "+v"(c_one));
-    for (int p = 0; p < P; ++p) {
+    for (int p = wslot; p < P; p += WSTEP) {
         u32x4 t2 = t1;
-        if (p + 2 < P && PBL_ABLATE != 2) t2 = __builtin_nontemporal_load(tiles + (p + 2) * 64);
+        if (p + 2 * WSTEP < P && PBL_ABLATE != 2) t2 = __builtin_nontemporal_load(tiles + (p + 2 * WSTEP) * 64);
         const uint32_t* xw = reinterpret_cast<const uint32_t*>(xs + p * PBL_PANEL_COLS) + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -383,25 +392,26 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     const int rho = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
     const int sub = lane & 3;
     const pbl_rowparams pr = reinterpret_cast<const pbl_rowparams*>(rec + 144)[rho];
+    const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16)[rho];   // issued early: phase 3 must not wait on HBM
     // SF layers in a mixed grouped launch are told apart at run time (wave-uniform)
     const bool sf = SF && (L.flags & PBL_FLAG_SAL_F16);
     const uint8_t* crow = tailcnt + ((size_t(ntail) + 15) & ~size_t(15));
     const bool has_crow = L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16);
 
     // ---- phase 2: salient chunks (next round's loads issued before this round's math) ---
-    float2* part = part_all + size_t(wave) * L.max_nch * MB;
+    float2* part = part_all + (SPLIT > 1 ? size_t(0) : size_t(wave) * L.max_nch * MB);
     {
         const uint32_t xbase = uint32_t(reinterpret_cast<uintptr_t>(xs));      // LDS byte offset of x
         const uint32_t tok_stride = uint32_t(xstride) * 2u;
         const uint32_t zaddr = xbase + 2u * uint32_t(Kp);                      // a zero slot
-        for (int base = 0; base < nch; base += PBL_WAVE) {
+        for (int base = wslot * PBL_WAVE; base < nch; base += WSTEP * PBL_WAVE) {
             const int c = base + lane;
             const bool valid = c < nch;
             const int cc = valid ? c : nch - 1;
             const uint32_t c0 = s_c0;
             const u32x4 d4 = s_d4, q4 = s_q4;
-            if (base + PBL_WAVE < nch && PBL_ABLATE != 2) {
-                const int cn = c + PBL_WAVE < nch ? c + PBL_WAVE : nch - 1;
+            if (base + WSTEP * PBL_WAVE < nch && PBL_ABLATE != 2) {
+                const int cn = c + WSTEP * PBL_WAVE < nch ? c + WSTEP * PBL_WAVE : nch - 1;
                 s_c0 = col0p[cn];
                 s_d4 = __builtin_nontemporal_load(deltap + cn);
                 s_q4 = __builtin_nontemporal_load(codep + cn);
@@ -437,11 +447,30 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    if constexpr (SPLIT > 1) {
+        // merge the S waves' binary partials (lane l of every wave holds row rho(l)); the chunk
+        // partials already sit in the shared `part` array
+        float2* red = part_all + size_t(L.max_nch) * MB;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) red[(m * SPLIT + wave) * PBL_WAVE + lane] = make_float2(accsum[m], X[m]);
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            float a_ = 0.f, x_ = 0.f;
+#pragma unroll
+            for (int w = 0; w < SPLIT; ++w) {
+                const float2 v = red[(m * SPLIT + w) * PBL_WAVE + lane];
+                a_ += v.x; x_ += v.y;
+            }
+            accsum[m] = a_; X[m] = x_;
+        }
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     // ---- phase 3: reduce, combine, store -------------------------------------------
-    const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16)[rho];
     float A, B;
     class_consts(rho & 7, A, B);
     const float alpha = 0.5f * (pr.hi - pr.lo), mu = 0.5f * (pr.hi + pr.lo);
@@ -482,16 +511,17 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     }
 }
 
-size_t lds_bytes(uint32_t P, uint32_t max_nch, int mb, int wpb) {
+size_t lds_bytes(uint32_t P, uint32_t max_nch, int mb, int wpb, int split = 1) {
     const size_t xstride = size_t(P) * PBL_PANEL_COLS + 8;
     size_t s = (size_t(mb) * xstride * 2 + 15) & ~size_t(15);
-    s += size_t(wpb) * max_nch * mb * sizeof(float2);
+    if (split > 1) s += (size_t(max_nch) + size_t(split) * PBL_WAVE) * mb * sizeof(float2);
+    else s += size_t(wpb) * max_nch * mb * sizeof(float2);
     return s + 16;
 }
 
-template <int MB, int WPB, bool SF>
+template <int MB, int WPB, bool SF, int SPLIT = 1>
 int launch(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    auto k = pbl_gemv_kernel<MB, WPB, SF>;
+    auto k = pbl_gemv_kernel<MB, WPB, SF, SPLIT>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return PBL_ERR_UNSUPPORTED;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -758,6 +788,32 @@ template <int WPB>
 int launch_mb(int mb, bool sf, const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     return sf ? launch_mb2<WPB, true>(mb, a, grid, lds, st) : launch_mb2<WPB, false>(mb, a, grid, lds, st);
 }
+// latency mode: S waves per record
+template <int S>
+int launch_split(int mb, bool sf, const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    if (sf) {
+        switch (mb) {
+            case 1: return launch<1, S, true, S>(a, grid, lds, st);
+            case 2: return launch<2, S, true, S>(a, grid, lds, st);
+            case 3: return launch<3, S, true, S>(a, grid, lds, st);
+            case 4: return launch<4, S, true, S>(a, grid, lds, st);
+        }
+    } else {
+        switch (mb) {
+            case 1: return launch<1, S, false, S>(a, grid, lds, st);
+            case 2: return launch<2, S, false, S>(a, grid, lds, st);
+            case 3: return launch<3, S, false, S>(a, grid, lds, st);
+            case 4: return launch<4, S, false, S>(a, grid, lds, st);
+        }
+    }
+    return PBL_ERR_INVALID_ARG;
+}
+// waves per record so that a launch of `records` records fields >= ~2048 waves
+int pick_split(uint32_t records, uint32_t P) {
+    int s = 1;
+    while (s < 8 && records * uint32_t(s) < 2048u && uint32_t(2 * s) <= (P > 1 ? P : 1u) * 2u) s *= 2;
+    return s;
+}
 
 }  // namespace
 
@@ -773,13 +829,16 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
     if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (layer->G != 1) return linear_groups(layer, x, y, M, y_f32, st);
-    // wide workgroups only when there are enough records to still fill 256 CUs
-    const int wpb = layer->NRB >= 1024 ? 4 : 1;
     const size_t esz = y_f32 ? 4 : 2;
+    const bool sf = layer->flags & PBL_FLAG_SAL_F16;
+    // throughput mode (a wave per record, 4 per workgroup) when there are enough records to fill the
+    // chip; otherwise latency mode: S waves share a record
+    const int split = layer->NRB >= 2048 ? 1 : pick_split(layer->NRB, layer->P);
+    const int wpb = split > 1 ? split : (layer->NRB >= 1024 ? 4 : 1);
     // tokens per weight pass: as many as fit a 96 KiB LDS budget (x tile + chunk partials),
     // so that K = 13824 layers still run several workgroups per CU
     int mb_max = PBL_MAX_TOKENS_PER_LAUNCH;
-    while (mb_max > 1 && lds_bytes(layer->P, layer->max_nch, mb_max, wpb) > 96 * 1024) --mb_max;
+    while (mb_max > 1 && lds_bytes(layer->P, layer->max_nch, mb_max, wpb, split) > 96 * 1024) --mb_max;
     for (int m0 = 0; m0 < M; m0 += mb_max) {
         const int mb = M - m0 < mb_max ? M - m0 : mb_max;
         GemvArgs a{};
@@ -787,10 +846,15 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
         a.x = static_cast<const _Float16*>(x) + size_t(m0) * layer->K;
         a.y = static_cast<char*>(y) + size_t(m0) * layer->N * esz;
         a.M = mb; a.y_f32 = y_f32; a.grouped = 0;
-        const dim3 grid((layer->NRB + wpb - 1) / wpb, 1, 1);
-        const size_t lds = lds_bytes(layer->P, layer->max_nch, mb, wpb);
-        const bool sf = layer->flags & PBL_FLAG_SAL_F16;
-        const int rc = wpb == 4 ? launch_mb<4>(mb, sf, a, grid, lds, st) : launch_mb<1>(mb, sf, a, grid, lds, st);
+        const dim3 grid(split > 1 ? layer->NRB : (layer->NRB + wpb - 1) / wpb, 1, 1);
+        const size_t lds = lds_bytes(layer->P, layer->max_nch, mb, wpb, split);
+        int rc;
+        switch (split) {
+            case 8: rc = launch_split<8>(mb, sf, a, grid, lds, st); break;
+            case 4: rc = launch_split<4>(mb, sf, a, grid, lds, st); break;
+            case 2: rc = launch_split<2>(mb, sf, a, grid, lds, st); break;
+            default: rc = wpb == 4 ? launch_mb<4>(mb, sf, a, grid, lds, st) : launch_mb<1>(mb, sf, a, grid, lds, st);
+        }
         if (rc != PBL_OK) return rc;
     }
     return PBL_OK;

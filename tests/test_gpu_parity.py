@@ -313,7 +313,9 @@ def test_grouped_launch_matches_individual():
     torch.cuda.synchronize()
     for p, x, y, ref in zip(grp.packed, xs, ys, refs):
         assert_parity(y, ref)
-        assert torch.equal(y, Q.PBLinear(p, None)(T(x)))   # same kernel, same bits
+        # single-layer launches of small layers run in split (latency) mode: same math, another
+        # summation split, so equal to rounding rather than bit-for-bit
+        assert_parity(Q.PBLinear(p, None)(T(x)), y.float().cpu().numpy().astype(np.float64), 2e-3)
 
 
 def test_misuse_raises():
