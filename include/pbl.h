@@ -174,6 +174,14 @@ size_t pbl_gemv_lds_bytes(const pbl_layer* layer, int m);
  * stream: hipStream_t (as void*). */
 int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream);
 
+/* Reconstruct the dense simulated weight ON THE DEVICE: W_out [N,K] row-major, fp16
+ * (out_f32 == 0) or fp32.  This is the GEMM-regime path (M >= ~16, prefill): unpack into a
+ * transient workspace, then a plain library GEMM (rocBLAS / hipBLASLt through torch) --
+ * exactly the arithmetic the reference runs on its dense fake-quant weight
+ * (gptq_pb/gptq.py:180-184 + nn.Linear).  For fp16 output every value must be
+ * fp16-representable to be exact (true for layers packed from an fp16 checkpoint). */
+int pbl_unpack_dev(const pbl_layer* layer, void* W_out, int out_f32, void* stream);
+
 /* L independent layers in ONE launch (decode-time fused QKV / gate+up, and the
  * stream benchmark of SURVEY.md 8(d)).  layers_dev: DEVICE array of L pbl_layer;
  * x_dev / y_dev: DEVICE arrays of L pointers (fp16 [M,K_l] / fp16 [M,N_l]);

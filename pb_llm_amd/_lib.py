@@ -40,7 +40,7 @@ class PblError(RuntimeError):
 _lib = None
 
 EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_blob_describe",
-           "pbl_unpack_dense_f32", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemv_f16_grouped"]
+           "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemv_f16_grouped"]
 
 
 def lib() -> C.CDLL:
@@ -64,6 +64,8 @@ def lib() -> C.CDLL:
     L.pbl_blob_describe.argtypes = [vp, sz, C.POINTER(PblLayer)]
     L.pbl_unpack_dense_f32.restype = C.c_int
     L.pbl_unpack_dense_f32.argtypes = [vp, sz, vp]
+    L.pbl_unpack_dev.restype = C.c_int
+    L.pbl_unpack_dev.argtypes = [C.POINTER(PblLayer), vp, C.c_int, vp]
     L.pbl_gemv_lds_bytes.restype = sz
     L.pbl_gemv_lds_bytes.argtypes = [C.POINTER(PblLayer), C.c_int]
     L.pbl_linear_f16.restype = C.c_int

@@ -40,6 +40,14 @@ __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), c, false);
 }
 
+// fl16(fl32(a*b)): the checkpoint's value of a salient weight is DOUBLE rounded (fp32 product,
+// then `.to(fp16)`, gptq_pb/gptq.py:182).  hipcc would fuse mul + cvt into one single-rounding
+// v_fma_mixlo_f16 (1 fp16 ulp off on ~1e-5 of the values); the empty asm keeps the fp32 product.
+__device__ __forceinline__ _Float16 round_f16_twice(float prod) {
+    asm volatile("" : "+v"(prod));
+    return _Float16(prod);
+}
+
 __device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, PBL_WAVE); }
 
 // Bit classes 8..15 of an fp16 half-word: pair mask M and OR-constant C such that
@@ -233,8 +241,8 @@ __device__ __forceinline__ void chunk_accumulate(uint32_t xbase, uint32_t tok_st
                 if constexpr (SF) {
                     const uint32_t qw = q4[2 * h + (p >> 1)] >> ((p & 1) * 16);
                     h2 w;
-                    w.x = _Float16(ss * (float(qw & 0xFFu) - sz));
-                    w.y = _Float16(ss * (float((qw >> 8) & 0xFFu) - sz));
+                    w.x = round_f16_twice(ss * (float(qw & 0xFFu) - sz));
+                    w.y = round_f16_twice(ss * (float((qw >> 8) & 0xFFu) - sz));
                     qp = __builtin_bit_cast(uint32_t, w);
                 } else {
                     qp = __builtin_amdgcn_perm(q4[2 * h + (p >> 1)], 0x64646464u, (p & 1) ? 0x00070006u : 0x00050004u);
@@ -673,7 +681,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
                 if (k < cnt) {
                     const uint32_t col = col2 >> 1;
                     float qf = cp.sscale * (float((q4[k >> 2] >> (8 * (k & 3))) & 0xFFu) - cp.szero);  // the weight itself
-                    if (sf16) qf = float(_Float16(qf));
+                    if (sf16) qf = float(round_f16_twice(qf));
                     const float hv = hitab[(col >> gshift) * 16 + row];
 #pragma unroll
                     for (int m = 0; m < MB; ++m) {
@@ -727,6 +735,122 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
             if (args.y_f32) static_cast<float*>(yg)[size_t(m) * L.N + row] = yv;
             else static_cast<_Float16*>(yg)[size_t(m) * L.N + row] = _Float16(yv);
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Device-side unpack: PBL1 -> dense row-major [N,K] (fp16 or fp32); the GEMM-regime path
+// (the dense matrix lives only in a transient workspace).  One workgroup of 4 waves per
+// record: wave w expands panels w, w+4, ... through an LDS transpose so that every global
+// store is 16 bytes per lane (narrow stores cost up to 6x per byte on this part), then the
+// waves scatter the salient code entries lane-per-chunk with 16-byte loads, then exceptions.
+template <typename OutT>
+__global__ __launch_bounds__(4 * PBL_WAVE) void pbl_unpack_kernel(pbl_layer L, OutT* __restrict__ Wout) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t rb = blockIdx.x;
+    const int K = int(L.K), P = int(L.P), G = int(L.G);
+    const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
+    const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[rb];
+    const uint8_t* rec = blob + size_t(__builtin_amdgcn_readfirstlane(info.x)) * 16;
+    const int nfull = __builtin_amdgcn_readfirstlane(info.y), ntail = __builtin_amdgcn_readfirstlane(info.z);
+    const int nexc = __builtin_amdgcn_readfirstlane(info.w), nch = nfull + ntail;
+    const bool groups = L.flags & PBL_FLAG_HAS_GROUPS, sf16 = L.flags & PBL_FLAG_SAL_F16;
+    const uint32_t tiles_off = groups ? ((400u + 128u * uint32_t(G) + 15u) & ~15u) : 400u;
+    const uint32_t off_sal = tiles_off + uint32_t(P) * 1024u;
+    const pbl_rowparams* params = reinterpret_cast<const pbl_rowparams*>(rec + 144);
+    const pbl_rowinfo* rinfo = reinterpret_cast<const pbl_rowinfo*>(rec + 16);
+    const float2* ghl = reinterpret_cast<const float2*>(rec + 400);
+    const int gwords = groups ? (K / G) / 128 : (1 << 30);   // dwords of a lane per column group
+    const int nrows = (L.N - rb * 16) < 16u ? int(L.N - rb * 16) : 16;
+
+    // Sign plane.  The 4 lanes of a quad hold, per dword, 16 rows x 8 CONSECUTIVE columns
+    // (2 each).  Each lane fetches the quad's 4 dwords by DPP broadcast and expands rows
+    // q, q+4, q+8, q+12 (q = lane & 3) to 8 consecutive values -> 16-byte stores (narrow stores
+    // cost up to 6x per byte on this part); a wave-store covers 4 rows x 256 contiguous bytes.
+    const int q = lane & 3, quad = lane >> 2;
+    float hi_r[4], lo_r[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { hi_r[m] = params[q + 4 * m].hi; lo_r[m] = params[q + 4 * m].lo; }
+    const u32x4* tiles = reinterpret_cast<const u32x4*>(rec + tiles_off) + lane;
+    for (int p = wave; p < P; p += 4) {
+        const u32x4 t = __builtin_nontemporal_load(tiles + p * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t w4[4];
+            w4[0] = __builtin_amdgcn_update_dpp(0, int(t[i]), 0x00, 0xF, 0xF, false);   // quad_perm [0,0,0,0]
+            w4[1] = __builtin_amdgcn_update_dpp(0, int(t[i]), 0x55, 0xF, 0xF, false);   // [1,1,1,1]
+            w4[2] = __builtin_amdgcn_update_dpp(0, int(t[i]), 0xAA, 0xF, 0xF, false);   // [2,2,2,2]
+            w4[3] = __builtin_amdgcn_update_dpp(0, int(t[i]), 0xFF, 0xF, 0xF, false);   // [3,3,3,3]
+            const int col = p * PBL_PANEL_COLS + i * 128 + 8 * quad;
+            if (col >= K) continue;
+            const int g = (p * 4 + i) / gwords;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int rho = q + 4 * m;
+                if (rho >= nrows) continue;
+                const int pos = rho < 8 ? rho + 8 : rho - 8;
+                float hi = hi_r[m], lo = lo_r[m];
+                if (groups) { const float2 hl = ghl[rho * G + (g < G ? g : G - 1)]; hi = hl.x; lo = hl.y; }
+                OutT v[8];
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    v[2 * sl] = OutT(((w4[sl] >> pos) & 1u) ? hi : lo);
+                    v[2 * sl + 1] = OutT(((w4[sl] >> (16 + pos)) & 1u) ? hi : lo);
+                }
+                OutT* dst = Wout + size_t(rb * 16 + rho) * K + col;
+                if (col + 8 <= K && (K % (16 / sizeof(OutT))) == 0) {
+                    if constexpr (sizeof(OutT) == 2) {
+                        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(v);
+                    } else {
+                        reinterpret_cast<u32x4*>(dst)[0] = reinterpret_cast<const u32x4*>(v)[0];
+                        reinterpret_cast<u32x4*>(dst)[1] = reinterpret_cast<const u32x4*>(v)[1];
+                    }
+                } else {
+                    for (int e = 0; e < 8 && col + e < K; ++e) dst[e] = v[e];
+                }
+            }
+        }
+    }
+    // the sparse entries below overwrite positions written above by any of the 4 waves
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const uint8_t* sal = rec + off_sal;
+    const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
+    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + ((size_t(nch) * 2 + 15) & ~size_t(15)));
+    const u32x4* codep = deltap + nch;
+    const uint8_t* tailcnt = reinterpret_cast<const uint8_t*>(codep + nch);
+    const bool has_crow = L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16);
+    const uint8_t* after_tail = tailcnt + ((size_t(ntail) + 15) & ~size_t(15));
+    const uint2* exc = reinterpret_cast<const uint2*>(after_tail + (has_crow ? ((size_t(nch) + 15) & ~size_t(15)) : 0));
+    for (int c = threadIdx.x; c < nch; c += 4 * PBL_WAVE) {
+        // row of chunk c: full chunks are laid out row by row (then the tail chunks likewise) and the
+        // per-row start indices are non-decreasing, so the owner is the last row whose start is <= c
+        int rho = 0;
+        if (c < nfull) { for (int r = 1; r < 16; ++r) rho += int(rinfo[r].start) <= c; }
+        else { const int t_ = c - nfull; for (int r = 1; r < 16; ++r) rho += int(rinfo[r].tailidx) <= t_; }
+        const int cnt = c >= nfull ? int(tailcnt[c - nfull]) : 16;
+        const u32x4 d4 = deltap[c], q4 = codep[c];
+        const float ss = params[rho].sscale, sz = params[rho].szero;
+        OutT* wrow = Wout + size_t(rb * 16 + rho) * K;
+        uint32_t col = col0p[c];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            col += ((d4[e >> 2] >> (8 * (e & 3))) & 0xFFu) >> 1;
+            float w = ss * (float((q4[e >> 2] >> (8 * (e & 3))) & 0xFFu) - sz);
+            if (sf16) w = float(round_f16_twice(w));
+            if (e < cnt && col < uint32_t(K) && rho < nrows) wrow[col] = OutT(w);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int k = threadIdx.x; k < nexc; k += 4 * PBL_WAVE) {
+        const uint2 ex = exc[k];
+        const uint32_t r = rb * 16 + (ex.x >> 16), c = ex.x & 0xFFFFu;
+        if (r < L.N && c < uint32_t(K)) Wout[size_t(r) * K + c] = OutT(__builtin_bit_cast(float, ex.y));
     }
 }
 
@@ -858,6 +982,17 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
         if (rc != PBL_OK) return rc;
     }
     return PBL_OK;
+}
+
+int pbl_unpack_dev(const pbl_layer* layer, void* W_out, int out_f32, void* stream) {
+    if (!layer || !layer->blob || !W_out) return PBL_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    pbl_layer L = *layer;
+    void* argv[] = {&L, &W_out};
+    const void* k = out_f32 ? reinterpret_cast<const void*>(pbl_unpack_kernel<float>)
+                            : reinterpret_cast<const void*>(pbl_unpack_kernel<_Float16>);
+    return hipLaunchKernel(k, dim3(layer->NRB), dim3(4 * PBL_WAVE), argv, 0, st) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
 }
 
 int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, void* const* y_dev, int Lc,

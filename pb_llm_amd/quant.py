@@ -32,8 +32,34 @@ class BinaryInterface:
         return {"weight": self.weight.data.half().cpu(), "bias": self.bias}
 
 
+# M at which the forward switches from the bit-unpacking GEMV (weights streamed once per 4 tokens)
+# to "unpack to a transient dense workspace + library GEMM" (prefill / large batches).
+GEMM_THRESHOLD = 12
+_workspaces: dict = {}
+
+
+def _dense_workspace(device, numel: int, dtype) -> torch.Tensor:
+    """One reusable scratch buffer per (device, dtype): the dense weight exists only while a
+    large-M forward runs, so a model never holds more than one unpacked layer."""
+    key = (str(device), dtype)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = torch.empty(numel, dtype=dtype, device=device)
+        _workspaces[key] = buf
+    return buf[:numel]
+
+
+def unpack_on_device(packed: PackedWeight, dtype=torch.float16) -> torch.Tensor:
+    """Dense [N, K] view of the packed layer in the transient workspace (pbl_unpack_dev)."""
+    W = _dense_workspace(packed.blob.device, packed.N * packed.K, dtype).view(packed.N, packed.K)
+    layer = packed.layer_struct(None)
+    stream = torch.cuda.current_stream(packed.blob.device).cuda_stream
+    _lib.check(_lib.lib().pbl_unpack_dev(C.byref(layer), W.data_ptr(), int(dtype == torch.float32), stream), "unpack_dev")
+    return W
+
+
 def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: torch.Tensor,
-                      out_f32: bool = False) -> torch.Tensor:
+                      out_f32: bool = False, dense_dtype=None) -> torch.Tensor:
     """y = F.linear(x, w_sim, bias) through libpbl (pbl_linear_f16).  x [..., K] on
     the GPU, fp16 (native) or fp32/bf16 (split into two fp16 terms, fp32 output).
     out_f32: return the fp32 accumulator unrounded (tensor-parallel partial sums)."""
@@ -51,6 +77,15 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     L = _lib.lib()
     if M == 0:
         return x.new_zeros(*lead, packed.N)
+    if M >= GEMM_THRESHOLD:
+        # GEMM regime: dense weight in the workspace + library GEMM, i.e. exactly what the
+        # reference executes (F.linear over the dense fake-quant weight).  fp16 weights when
+        # the layer is fp16-exact (packed from an fp16 checkpoint), else fp32.
+        wdt = torch.float16 if (x.dtype == torch.float16 and dense_dtype in (None, torch.float16)) else torch.float32
+        W = unpack_on_device(packed, wdt)
+        y = torch.nn.functional.linear(x2.to(wdt), W, None if bias_f32 is None else bias_f32.to(wdt))
+        y = y.float() if out_f32 else y.to(x.dtype)
+        return y.reshape(*lead, packed.N)
     if x.dtype == torch.float16:
         xc = x2.contiguous()
         y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
@@ -155,7 +190,8 @@ class PBLinear(nn.Module, BinaryInterface):
         return self.pbl_bias
 
     def forward(self, x):
-        return pb_linear_forward(self.packed, self.pbl_bias, x)
+        dd = torch.float16 if self.weight_dtype == torch.float16 else torch.float32
+        return pb_linear_forward(self.packed, self.pbl_bias, x, dense_dtype=dd)
 
     def to_regular_linear(self) -> nn.Linear:
         lin = nn.Linear(self.in_features, self.out_features, bias=self.pbl_bias is not None)
@@ -199,7 +235,8 @@ class _DenseBacked(nn.Module, BinaryInterface):
         return self.bias.detach().float().to(device) if self.bias is not None else None
 
     def forward(self, x):
-        return pb_linear_forward(self._packed_on(x.device), self._bias_f32(x.device), x)
+        dd = torch.float16 if self.weight.dtype == torch.float16 else torch.float32
+        return pb_linear_forward(self._packed_on(x.device), self._bias_f32(x.device), x, dense_dtype=dd)
 
 
 class BinaryLinear(_DenseBacked):

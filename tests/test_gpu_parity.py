@@ -294,6 +294,41 @@ def test_llama13b_ffn_shapes_m32():
         assert_parity(y, g["y"], 2e-3)   # reference fp16-weight output (weights rounded to fp16 there)
 
 
+# ---------------------------------------------------------------- GEMM regime (device unpack + library GEMM)
+@pytest.mark.parametrize("gs,f16", [(-1, False), (-1, True), (128, False), (128, True)])
+def test_device_unpack_matches_host_unpack(gs, f16):
+    N, K = 100, 1536
+    W = synth.llm_weight(N, K, seed=31, heavy_tail=True)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, gs)
+    r = O.ptq_rtn(W, mask, 8, gs)
+    Wd = r["W_fq"].astype(np.float16).astype(np.float32) if f16 else r["W_fq"].copy()
+    Wd[7, 700] = 0.3333 if not f16 else np.float32(np.float16(0.3333))          # an exception
+    G = 1 if gs == -1 else K // gs
+    from pb_llm_amd.packing import infer_levels
+    hi, lo = infer_levels(Wd, gs, mask)
+    p = pack_dense(Wd, hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8), sal_f16=f16).to(DEV)
+    assert p.nexc >= 1 and p.G == G
+    W32 = Q.unpack_on_device(p, torch.float32).cpu().numpy()
+    np.testing.assert_array_equal(W32, Wd)
+    if f16:
+        W16 = Q.unpack_on_device(p, torch.float16).cpu().numpy()
+        np.testing.assert_array_equal(W16, Wd.astype(np.float16))
+
+
+@pytest.mark.parametrize("M", [12, 64, 257])
+def test_gemm_regime_forward(M, llama7b_qproj):
+    W, mask, r = llama7b_qproj
+    W16 = torch.from_numpy(r["W_fq"]).half()
+    layer = Q.PBLinear.from_dense(W16, None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+    x = synth.activations((M, 4096), 9, 21)
+    y = layer(T(x))
+    assert y.shape == (M, 4096) and y.dtype == torch.float16
+    assert_parity(y, O.dense_linear(x, W16.numpy()))
+    # the GEMV path (M < threshold) and the GEMM path agree on the same tokens
+    y_small = torch.cat([layer(T(x[i:i + 4])) for i in range(0, 12, 4)])
+    assert_parity(y[:12], y_small.float().cpu().numpy().astype(np.float64), 2e-3)
+
+
 # ---------------------------------------------------------------- grouped launch
 def test_grouped_launch_matches_individual():
     shapes = [(4096, 4096), (4096, 4096), (1024, 4096), (768, 768), (11008, 4096)]
