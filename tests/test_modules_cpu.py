@@ -1,0 +1,113 @@
+"""CPU tests of the host-side module logic that needs no kernel: mask generation against
+the goldens, the Hessian-mask loader, (de)serialisation, replace_linear_with_pb."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import pb_oracle as O
+from pb_llm_amd import io as pbio
+from pb_llm_amd import quant as Q
+from pb_llm_amd import synth
+from conftest import golden
+
+
+def _w():
+    W = synth.llm_weight(768, 768, seed=4, heavy_tail=True)
+    W[7, 9] = 0.0
+    return W
+
+
+def test_gen_outlier_mask_matches_reference_on_cpu():
+    g = golden("g4_pb_qat_linear")
+    m = Q.BinaryXnorExceptOutliersLinear(torch.from_numpy(_w()), None, 0.1)
+    m.gen_outlier_mask()
+    np.testing.assert_array_equal(np.packbits(m.outlier_mask.numpy()), g["mask_f32"])
+    np.testing.assert_array_equal(m.weight.data.numpy(), g["w_hat_f32"])
+    np.testing.assert_allclose(m.binary_scale.numpy(), g["binary_scale_f32"], rtol=3e-6)
+    assert m.binary_scale.shape == (1, 1)
+    assert abs(m.outlier_nbits - float(g["outlier_nbits_f32"])) < 1e-12
+    # dense view used by to_regular_linear equals the oracle's w_sim
+    w_sim = m.binarize_except_outliers().numpy()
+    mask = np.unpackbits(g["mask_f32"])[:768 * 768].astype(bool).reshape(768, 768)
+    np.testing.assert_array_equal(w_sim, O.binarize_except_outliers(g["w_hat_f32"], mask, m.binary_scale.numpy()))
+    # packing reproduces it exactly (codes of the 8-bit grid, +-alpha levels, zeros as code 0)
+    p = m._pack()
+    np.testing.assert_array_equal(p.unpack().numpy(), w_sim)
+    assert p.nexc <= 0.01 * p.nnz
+    lin = m.to_regular_linear()
+    assert isinstance(lin, nn.Linear) and torch.equal(lin.weight.data, torch.from_numpy(w_sim))
+
+
+def test_weight_quant_8bit_host_matches_golden():
+    g = golden("g3_weight_quant_8bit")
+    for tag, dt in (("f32", torch.float32), ("f16", torch.float16)):
+        w = torch.from_numpy(g["W"]).to(dt)
+        ok = np.ones(8, bool); ok[3] = False
+        np.testing.assert_array_equal(Q.weight_quant_8bit(w, simulated=False).numpy()[ok], g["codes_" + tag][ok])
+        np.testing.assert_array_equal(Q.weight_quant_8bit(w, simulated=True).float().numpy()[ok], g["sim_" + tag][ok])
+
+
+def test_hessian_variant_loads_gptq_mask(tmp_path, monkeypatch):
+    """quant/outlier_quantizer.py:126-143: mask file present -> outlier_mask = ~mask and
+    binary_scale stays None until a train() forward; missing -> magnitude fallback."""
+    monkeypatch.chdir(tmp_path)
+    W = torch.from_numpy(_w())
+    low = torch.from_numpy(O.ptq_low_mask(_w(), 0.9, "magnitude"))
+    m = Q.BinaryXnorExceptOutliersLinearHessian(W.clone(), None, 0.1)
+    m.global_name = "model/layers/0/q_proj"
+    m.gen_outlier_mask()                       # no file -> magnitude fallback
+    assert m.binary_scale is not None
+    pbio.save_low_mask(low, 0.9, m.global_name)
+    assert os.path.exists("gptq_pb/outputs/mask/mask_0.9_model_layers_0_q_proj.pkl")
+    m2 = Q.BinaryXnorExceptOutliersLinearHessian(W.clone(), None, 0.1)
+    m2.global_name = m.global_name
+    m2.gen_outlier_mask()
+    assert torch.equal(m2.outlier_mask, ~low) and m2.binary_scale is None
+    m2.train()
+    m2._refresh_scale()                        # what the first train() forward does
+    assert m2.binary_scale is not None and m2.binary_scale.shape == (1, 1)
+
+
+class Tiny(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.q_proj = nn.Linear(512, 64, bias=False)
+        self.mlp = nn.Sequential(nn.Linear(512, 96), nn.ReLU(), nn.Linear(96, 32))
+        self.lm_head = nn.Linear(32, 10)
+
+
+def _pb_factory(lin: nn.Linear):
+    W = lin.weight.data.float().numpy()
+    if W.shape[1] < 128:
+        return Q.BinaryLinear(lin.weight.data, lin.bias.data if lin.bias is not None else None)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude")
+    r = O.ptq_rtn(W, mask, 8, -1)
+    return Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]), lin.bias, torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
+
+
+def test_replace_save_load_roundtrip(tmp_path):
+    torch.manual_seed(0)
+    model = Tiny()
+    Q.replace_linear_with_pb(model, _pb_factory)           # skips lm_head like gptq_pb/modelutils.find_layers
+    assert isinstance(model.q_proj, Q.PBLinear) and isinstance(model.mlp[0], Q.PBLinear)
+    assert isinstance(model.mlp[2], Q.BinaryLinear) and isinstance(model.lm_head, nn.Linear)
+    assert model.mlp[0].global_name == "mlp.0"
+    model.mlp[2]._packed_on(torch.device("cpu"))
+    meta = pbio.save_pb(model, str(tmp_path / "ckpt"))
+    assert set(meta) == {"q_proj", "mlp.0", "mlp.2"} and meta["mlp.2"]["class"] == "BinaryLinear"
+    fresh = pbio.load_pb(Tiny(), str(tmp_path / "ckpt"))
+    for name in meta:
+        a = dict(model.named_modules())[name]
+        b = dict(fresh.named_modules())[name]
+        pa = a.packed if isinstance(a, Q.PBLinear) else a._packed
+        assert isinstance(b, Q.PBLinear) and torch.equal(pa.blob, b.packed.blob)
+        assert torch.equal(pa.unpack(), b.packed.unpack())
+        if a.bias is not None:
+            assert torch.equal(a.bias.detach().float(), b.bias)
+    sd = fresh.state_dict()
+    assert "q_proj.pbl_blob" in sd and sd["q_proj.pbl_blob"].dtype == torch.uint8
+    with pytest.raises(KeyError):
+        pbio.load_pb(nn.Sequential(nn.Linear(4, 4)), str(tmp_path / "ckpt"))
