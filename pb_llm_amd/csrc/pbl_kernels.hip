@@ -1004,11 +1004,15 @@ int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, 
     if ((any_groups & 1) || Lc > 65535) return PBL_ERR_UNSUPPORTED;
     GemvArgs a{};
     a.layers = layers_dev; a.xs = x_dev; a.ys = y_dev; a.M = M; a.y_f32 = y_f32; a.grouped = 1;
-    const int wpb = 4;
+#ifndef PBL_GROUPED_WPB
+#define PBL_GROUPED_WPB 4
+#endif
+    const int wpb = PBL_GROUPED_WPB;
     const uint32_t P = (max_K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS;
     const dim3 grid((max_NRB + wpb - 1) / wpb, Lc, 1);
     // any_groups bit 1: the group may contain PBL_FLAG_SAL_F16 layers (told apart per layer at run time)
-    return launch_mb<4>(M, (any_groups & 2) != 0, a, grid, lds_bytes(P, max_nch, M, wpb), static_cast<hipStream_t>(stream));
+    return launch_mb<PBL_GROUPED_WPB>(M, (any_groups & 2) != 0, a, grid, lds_bytes(P, max_nch, M, wpb),
+                                      static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -360,3 +360,48 @@ def test_misuse_raises():
         m(torch.zeros(1, 100, device=DEV))
     with pytest.raises(_lib.PblError):
         m(torch.zeros(1, 512))
+
+
+# ---------------------------------------------------------------- model level (HF LLaMA, random init)
+def test_llama_model_forward_with_pb_linears():
+    """Drop-in at model level: a random-init HF LlamaForCausalLM (2 layers, hidden 512), every
+    decoder Linear quantized by the oracle's restatement of gptq_pb RTN (low_frac 0.9 + 8-bit
+    salients), then swapped for PBLinear.  Logits and perplexity vs the SAME model with dense
+    fake-quant fp16 weights (what gptq_pb/run.py evaluates).  T=48 tokens exercises the GEMM
+    regime, a 5-token prompt the GEMV regime (HF calls each projection with [B, T, K])."""
+    import copy
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from pb_llm_amd import harness as H
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8,
+                      num_key_value_heads=8, vocab_size=1000, max_position_embeddings=256)
+    model = LlamaForCausalLM(cfg).half().eval()
+
+    def producer(name, W):
+        Wn = W.float().numpy()
+        mask = O.ptq_low_mask(Wn, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(Wn, mask, 8, -1)
+        return dict(W_fq=torch.from_numpy(r["W_fq"]), low_mask=torch.from_numpy(mask), hscale=r["hscale"], hzero=r["hzero"])
+
+    side = H.quantize_dense_(model, producer)
+    assert len(side) == 14 and "lm_head" not in side
+    dense = copy.deepcopy(model).to(DEV)
+    pb = H.to_pb_(model, side).to(DEV)
+    n_pb = sum(isinstance(m, Q.PBLinear) for m in pb.modules())
+    assert n_pb == 14 and isinstance(pb.lm_head, torch.nn.Linear)
+    ids = torch.from_numpy((synth.uniform01(96, 5, 1) * 1000).astype(np.int64)).view(1, -1).to(DEV)
+    with torch.no_grad():
+        for T_ in (5, 48):
+            ref = dense(ids[:, :T_]).logits.float().cpu().numpy()
+            out = pb(ids[:, :T_]).logits.float().cpu().numpy()
+            rel, _ = O.parity_errors(out, ref)
+            assert rel < 5e-3, (T_, rel)     # two decoder layers of fp16 arithmetic stacked
+        p_ref = H.perplexity(dense, ids, 48)
+        p_pb = H.perplexity(pb, ids, 48)
+    assert abs(p_pb - p_ref) / p_ref < 5e-3, (p_pb, p_ref)
+    # flattened checkpoint: no side information at all
+    flat = H.to_pb_(copy.deepcopy(dense).cpu(), None).to(DEV)
+    with torch.no_grad():
+        out = flat(ids[:, :5]).logits.float().cpu().numpy()
+        ref5 = dense(ids[:, :5]).logits.float().cpu().numpy()
+    assert O.parity_errors(out, ref5)[0] < 5e-3

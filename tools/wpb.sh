@@ -1,0 +1,10 @@
+#!/bin/bash
+SRC="pb_llm_amd/csrc/pbl_kernels.hip pb_llm_amd/csrc/pbl_host.cpp"
+cp pb_llm_amd/libpbl.so /tmp/libpbl_orig.so
+for W in 2 4 8; do
+  /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -shared --offload-arch=gfx950 -DPBL_GROUPED_WPB=$W $SRC -o pb_llm_amd/libpbl.so 2>/dev/null
+  touch pb_llm_amd/libpbl.so
+  echo "== grouped WPB=$W"
+  python bench.py --steps 2000 --warmup 400 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('  layer-tok/s %.0f  GB/s %.0f  us/layer %.3f' % (j['value'], j['roofline']['achieved'], j['roofline']['us_per_layer']))"
+done
+cp /tmp/libpbl_orig.so pb_llm_amd/libpbl.so
