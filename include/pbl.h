@@ -182,6 +182,12 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
  * fp16-representable to be exact (true for layers packed from an fp16 checkpoint). */
 int pbl_unpack_dev(const pbl_layer* layer, void* W_out, int out_f32, void* stream);
 
+/* Small-batch GEMM straight from the packed format: y[M,N] = x[M,K] @ W^T + bias for
+ * 1 <= M <= 64, fp16 in/out, ONE pass over the packed weights for all tokens (band-wise expansion
+ * to exact fp16 in LDS + v_mfma_f32_16x16x32_f16).  Only for fp16-exact layers
+ * (PBL_FLAG_SAL_F16); others return PBL_ERR_UNSUPPORTED and use pbl_linear_f16 / pbl_unpack_dev. */
+int pbl_gemm_small_f16(const pbl_layer* layer, const void* x, void* y, int M, void* stream);
+
 /* L independent layers in ONE launch (decode-time fused QKV / gate+up, and the
  * stream benchmark of SURVEY.md 8(d)).  layers_dev: DEVICE array of L pbl_layer;
  * x_dev / y_dev: DEVICE arrays of L pointers (fp16 [M,K_l] / fp16 [M,N_l]);

@@ -40,7 +40,7 @@ class PblError(RuntimeError):
 _lib = None
 
 EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_blob_describe",
-           "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemv_f16_grouped"]
+           "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemm_small_f16", "pbl_gemv_f16_grouped"]
 
 
 def lib() -> C.CDLL:
@@ -70,6 +70,8 @@ def lib() -> C.CDLL:
     L.pbl_gemv_lds_bytes.argtypes = [C.POINTER(PblLayer), C.c_int]
     L.pbl_linear_f16.restype = C.c_int
     L.pbl_linear_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
+    L.pbl_gemm_small_f16.restype = C.c_int
+    L.pbl_gemm_small_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, vp]
     L.pbl_gemv_f16_grouped.restype = C.c_int
     L.pbl_gemv_f16_grouped.argtypes = [vp, vp, vp, C.c_int, C.c_int, u32, u32, u32, u32, C.c_int, C.c_int, vp]
     _lib = L

@@ -35,6 +35,10 @@ class BinaryInterface:
 # M at which the forward switches from the bit-unpacking GEMV (weights streamed once per 4 tokens)
 # to "unpack to a transient dense workspace + library GEMM" (prefill / large batches).
 GEMM_THRESHOLD = 12
+# ... and, for fp16-exact layers, the band GEMM (pbl_gemm_small_f16: one pass over the packed
+# weights for all tokens, MFMA) covers GEMM_THRESHOLD <= M <= SMALL_GEMM_MAX.
+SMALL_GEMM_MAX = 32
+SMALL_GEMM_MIN_RECORDS = 512   # below this the band kernel cannot fill the chip; the dense path wins
 _workspaces: dict = {}
 
 
@@ -77,6 +81,13 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     L = _lib.lib()
     if M == 0:
         return x.new_zeros(*lead, packed.N)
+    if (GEMM_THRESHOLD <= M <= SMALL_GEMM_MAX and x.dtype == torch.float16 and not out_f32
+            and (packed.flags & _lib.PBL_FLAG_SAL_F16) and packed.max_nch <= 3000
+            and packed.NRB >= SMALL_GEMM_MIN_RECORDS):
+        xc = x2.contiguous()
+        y = torch.empty(M, packed.N, dtype=torch.float16, device=x.device)
+        _lib.check(L.pbl_gemm_small_f16(C.byref(layer), xc.data_ptr(), y.data_ptr(), M, stream), "gemm_small")
+        return y.reshape(*lead, packed.N)
     if M >= GEMM_THRESHOLD:
         # GEMM regime: dense weight in the workspace + library GEMM, i.e. exactly what the
         # reference executes (F.linear over the dense fake-quant weight).  fp16 weights when

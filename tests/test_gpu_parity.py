@@ -329,6 +329,32 @@ def test_gemm_regime_forward(M, llama7b_qproj):
     assert_parity(y[:12], y_small.float().cpu().numpy().astype(np.float64), 2e-3)
 
 
+@pytest.mark.parametrize("N,K,gs,M,bias", [(4096, 4096, -1, 32, False), (100, 1536, -1, 12, True), (33, 640, 128, 17, True),
+                                            (768, 3072, -1, 64, False), (5120, 13824, -1, 33, False)])
+def test_band_gemm_small_batch(N, K, gs, M, bias):
+    """pbl_gemm_small_f16 (12 <= M <= 64, fp16-exact layers): one weight pass + MFMA"""
+    W = synth.llm_weight(N, K, seed=N + K + M, heavy_tail=True)
+    lf = 0.8 if N * K > 5e7 else 0.9
+    mask = O.ptq_low_mask(W, lf, "magnitude", None, gs)
+    r = O.ptq_rtn(W, mask, 8, gs)
+    W16 = torch.from_numpy(r["W_fq"]).half()
+    W16[min(5, N - 1), K // 2 + 1] = 0.4321           # an exception
+    b = synth.normal((N,), 2, 3, 0.1) if bias else None
+    layer = Q.PBLinear.from_dense(W16, T(b).cpu() if bias else None, torch.from_numpy(mask), gs, r["hscale"], r["hzero"]).to(DEV)
+    assert layer.packed.flags & _lib.PBL_FLAG_SAL_F16 and layer.packed.nexc >= 1
+    x = synth.activations((M, K), N, 21)
+    Q.SMALL_GEMM_MAX, Q.SMALL_GEMM_MIN_RECORDS = 64, 1       # force the band kernel for every shape here
+    try:
+        y = layer(T(x))
+    finally:
+        Q.SMALL_GEMM_MAX, Q.SMALL_GEMM_MIN_RECORDS = 32, 512
+    assert y.shape == (M, N) and y.dtype == torch.float16
+    assert_parity(y, O.dense_linear(x, W16.numpy(), b))
+    # against the reference's own GPU arithmetic on the dense checkpoint (F.linear fp16)
+    ref_gpu = torch.nn.functional.linear(T(x), W16.to(DEV), T(b).half() if bias else None)
+    assert_parity(y, ref_gpu.float().cpu().numpy().astype(np.float64), 2e-3)
+
+
 # ---------------------------------------------------------------- grouped launch
 def test_grouped_launch_matches_individual():
     shapes = [(4096, 4096), (4096, 4096), (1024, 4096), (768, 768), (11008, 4096)]
