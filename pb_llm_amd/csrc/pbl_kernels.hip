@@ -1007,12 +1007,23 @@ int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, 
 #ifndef PBL_GROUPED_WPB
 #define PBL_GROUPED_WPB 4
 #endif
-    const int wpb = PBL_GROUPED_WPB;
     const uint32_t P = (max_K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS;
+    const bool sf = (any_groups & 2) != 0;   // bit 1: the group may contain PBL_FLAG_SAL_F16 layers
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // few records in total (fused q/k/v, gate+up at decode time): latency mode, S waves per record
+    const int split = uint64_t(max_NRB) * uint64_t(Lc) >= 2048u ? 1 : pick_split(max_NRB * uint32_t(Lc), P);
+    if (split > 1) {
+        const dim3 grid(max_NRB, Lc, 1);
+        const size_t lds = lds_bytes(P, max_nch, M, split, split);
+        switch (split) {
+            case 8: return launch_split<8>(M, sf, a, grid, lds, st);
+            case 4: return launch_split<4>(M, sf, a, grid, lds, st);
+            default: return launch_split<2>(M, sf, a, grid, lds, st);
+        }
+    }
+    const int wpb = PBL_GROUPED_WPB;
     const dim3 grid((max_NRB + wpb - 1) / wpb, Lc, 1);
-    // any_groups bit 1: the group may contain PBL_FLAG_SAL_F16 layers (told apart per layer at run time)
-    return launch_mb<PBL_GROUPED_WPB>(M, (any_groups & 2) != 0, a, grid, lds_bytes(P, max_nch, M, wpb),
-                                      static_cast<hipStream_t>(stream));
+    return launch_mb<PBL_GROUPED_WPB>(M, sf, a, grid, lds_bytes(P, max_nch, M, wpb), st);
 }
 
 }  // extern "C"
