@@ -932,10 +932,14 @@ int launch_split(int mb, bool sf, const GemvArgs& a, dim3 grid, size_t lds, hipS
     }
     return PBL_ERR_INVALID_ARG;
 }
-// waves per record so that a launch of `records` records fields >= ~2048 waves
+#ifndef PBL_SPLIT_TARGET_WAVES
+#define PBL_SPLIT_TARGET_WAVES 8192u
+#endif
+// waves per record so that a launch of `records` records fields about a full chip of waves
+// (256 CUs x 32); more waves per record shorten every wave's serial load -> compute chain
 int pick_split(uint32_t records, uint32_t P) {
     int s = 1;
-    while (s < 8 && records * uint32_t(s) < 2048u && uint32_t(2 * s) <= (P > 1 ? P : 1u) * 2u) s *= 2;
+    while (s < 8 && records * uint32_t(s) < PBL_SPLIT_TARGET_WAVES && uint32_t(2 * s) <= (P > 1 ? P : 1u) * 2u) s *= 2;
     return s;
 }
 
@@ -957,7 +961,7 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
     const bool sf = layer->flags & PBL_FLAG_SAL_F16;
     // throughput mode (a wave per record, 4 per workgroup) when there are enough records to fill the
     // chip; otherwise latency mode: S waves share a record
-    const int split = layer->NRB >= 2048 ? 1 : pick_split(layer->NRB, layer->P);
+    const int split = layer->NRB >= PBL_SPLIT_TARGET_WAVES ? 1 : pick_split(layer->NRB, layer->P);
     const int wpb = split > 1 ? split : (layer->NRB >= 1024 ? 4 : 1);
     // tokens per weight pass: as many as fit a 96 KiB LDS budget (x tile + chunk partials),
     // so that K = 13824 layers still run several workgroups per CU
@@ -1011,7 +1015,7 @@ int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, 
     const bool sf = (any_groups & 2) != 0;   // bit 1: the group may contain PBL_FLAG_SAL_F16 layers
     hipStream_t st = static_cast<hipStream_t>(stream);
     // few records in total (fused q/k/v, gate+up at decode time): latency mode, S waves per record
-    const int split = uint64_t(max_NRB) * uint64_t(Lc) >= 2048u ? 1 : pick_split(max_NRB * uint32_t(Lc), P);
+    const int split = uint64_t(max_NRB) * uint64_t(Lc) >= PBL_SPLIT_TARGET_WAVES ? 1 : pick_split(max_NRB * uint32_t(Lc), P);
     if (split > 1) {
         const dim3 grid(max_NRB, Lc, 1);
         const size_t lds = lds_bytes(P, max_nch, M, split, split);
