@@ -51,25 +51,36 @@ def build_base_layers(n_distinct, N, K, low_frac, seed0):
 
 
 def cpu_baseline(dense_layers, K, M, budget_s=12.0):
-    """The reference's CPU path on this box's host cores: F.linear over the dense
-    fake-quant fp32 weight (what gptq_pb/run.py / eval_after_qat.py execute per layer,
-    BASELINE.md section 3 item 1), bounded sample."""
-    import torch.nn.functional as F
+    """The reference's CPU path on this box's host cores, via the oracle's statement of it
+    (oracle/pb_oracle.py: torch_dense_linear = F.linear over the dense fake-quant fp32 weight, what
+    gptq_pb/run.py / eval_after_qat.py execute per layer), on a bounded
+    sample.  Also the QAT layer as written (weight re-simulated on every call, item 2)."""
+    from oracle import pb_oracle as O
     from pb_llm_amd import synth
     Ws = [torch.from_numpy(w) for w in dense_layers]
     xs = [torch.from_numpy(synth.activations((M, K), 900 + i, 21)).float() for i in range(len(Ws))]
     for w, x in zip(Ws, xs):
-        F.linear(x, w)
+        O.torch_dense_linear(x, w)
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
         for w, x in zip(Ws, xs):
-            F.linear(x, w)
+            O.torch_dense_linear(x, w)
         n += len(Ws)
     dt = time.perf_counter() - t0
+    # as-written QAT forward: a few calls are enough (tens of ms each)
+    w = Ws[0]
+    mask = w.abs() > w.abs().flatten().kthvalue(int(0.9 * w.numel()))[0]
+    scale = w[~mask].abs().mean().view(1, 1)
+    O.torch_qat_forward_as_written(xs[0], w, mask, scale)
+    t1 = time.perf_counter()
+    nq = 5
+    for _ in range(nq):
+        O.torch_qat_forward_as_written(xs[0], w, mask, scale)
+    qat_ms = 1e3 * (time.perf_counter() - t1) / nq
     return dict(value=n * M / dt, unit="layer-tokens/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} fp32 F.linear calls over {len(Ws)} distinct dense {Ws[0].shape[0]}x{K} "
-                       f"fake-quant weights (cache-cold rotation), {dt:.1f} s",
-                ms_per_layer=1e3 * dt / n)
+                sample=f"{n} fp32 F.linear calls (oracle.torch_dense_linear) over {len(Ws)} distinct dense "
+                       f"{Ws[0].shape[0]}x{K} fake-quant weights (cache-cold rotation), {dt:.1f} s",
+                ms_per_layer=1e3 * dt / n, qat_forward_as_written_ms_per_layer=qat_ms)
 
 
 def main():

@@ -340,6 +340,26 @@ def xnor_binary_linear_forward(x, W, bias=None):
 
 
 # --------------------------------------------------------------------------- #
+# The reference's CPU path as it actually executes (torch), for bench.py's cpu_baseline leg
+# --------------------------------------------------------------------------- #
+def torch_dense_linear(x, W_fq, bias=None):
+    """What gptq_pb/run.py / qat/eval_after_qat.py execute per layer on the host: stock
+    nn.Linear.forward == F.linear over the dense fake-quant weight (gptq_pb/gptq.py:180-184)."""
+    import torch.nn.functional as F
+    return F.linear(x, W_fq, bias)
+
+
+def torch_qat_forward_as_written(x, W_hat, outlier_mask, binary_scale, bias=None, outlier_scale=1.0):
+    """BinaryXnorExceptOutliersLinear.forward as written (quant/outlier_quantizer.py:83-106):
+    re-simulate the dense weight on EVERY call (mul, sign, mul, where), then F.linear."""
+    import torch
+    import torch.nn.functional as F
+    scaled = W_hat * outlier_scale
+    binary = torch.sign(W_hat) * binary_scale
+    return F.linear(x, torch.where(outlier_mask, scaled, binary), bias)
+
+
+# --------------------------------------------------------------------------- #
 # Parity metric used throughout tests/ (SURVEY 8(c) "Tolerances")
 # --------------------------------------------------------------------------- #
 def parity_errors(y: np.ndarray, y_ref: np.ndarray):
