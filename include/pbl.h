@@ -31,20 +31,21 @@
  * ---------------------------------------------------------------------------
  * Packed format "PBL1" (one blob per layer, identical on host and device):
  *
- *   [pbl_blob_header 80 B][rb_info: pbl_rec_info[NRB+1], 16 B each]
- *   [record 0][record 1]...[record NRB-1]        NRB = ceil(N/16)
+ *   [pbl_blob_header 80 B][rb_info: pbl_rec_info[NRB+1], 16 B each][pad to 128 B]
+ *   [record 0][record 1]...[record NRB-1]        NRB = ceil(N/16); every record starts on a 128-B line
  *
  * rb_info[b] = {record offset in units of 16 B, nfull, ntail, nexc}: ONE 16-byte scalar load
  * tells a wavefront where its record is and how long its salient lists are, so every
  * load of the record can be issued at once (rb_info[NRB].off16 = end of blob).
  * A record holds one ROW-BLOCK of 16 output rows and is the unit of work of one
- * wavefront.  P = ceil(K/512) column panels.  Record layout (all 16-B aligned):
+ * wavefront.  P = ceil(K/512) column panels.  Record layout (PBL_* macros below; tiles, col0,
+ * delta and code start on 128-B lines):
  *   +0    pbl_rec_header (16 B): nfull, ntail, nexc, off_sal (bytes from record start)
  *   +16   rowinfo[16]  (8 B each): u16 start, u16 nfull, u16 tailidx, u8 ntail, u8 0
  *   +144  params[16]   (16 B each): f32 hi, lo, sscale, szero     (group 0 / G==1)
  *   +400  [G>1 only]   ghl[16][G] (8 B each): f32 hi, lo per column group
- *   +T    tiles[P]     1 KiB each: the sign plane of 16 rows x 512 columns
- *   +off_sal: col0[nch_pad] (u16, nch = nfull+ntail, padded to x8), delta[nch][16] (u8),
+ *   +T    tiles[P]     1 KiB each: the sign plane of 16 rows x 512 columns (T = PBL_TILES_OFF(G) = 512 for G == 1)
+ *   +off_sal: col0[nch] (u16, nch = nfull+ntail), delta[nch][16] (u8),
  *             code[nch][16] (u8), tailcnt[ntail_pad16] (u8), [flags & (HAS_GROUPS|SAL_F16)] crow[nch_pad16]
  *             (u8, row-in-block of each chunk), exc[nexc] (pbl_exception, 8 B)
  *
@@ -83,6 +84,23 @@ extern "C" {
 #define PBL_CHUNK 16
 #define PBL_MAX_GAP 127 /* largest column step inside a chunk (stored doubled in a u8) */
 #define PBL_MAX_TOKENS_PER_LAUNCH 4 /* M handled per weight pass by the GEMV kernel */
+
+/* Record layout arithmetic (shared by the packer, the decoder and the kernels).  Records and the
+ * big arrays inside them start on 128-byte lines: the weight stream is read with non-temporal
+ * 1 KiB wave-loads, and a load that straddles a line fetches the shared line twice (measured:
+ * +8 % FETCH_SIZE with 16-byte alignment). */
+#define PBL_ALIGN16(x) (((x) + 15u) & ~15u)
+#define PBL_ALIGN128(x) (((x) + 127u) & ~127u)
+#define PBL_REC_ROWINFO_OFF 16u
+#define PBL_REC_PARAMS_OFF 144u
+#define PBL_REC_GHL_OFF 400u
+#define PBL_TILES_OFF(G) PBL_ALIGN128(400u + ((G) > 1u ? 128u * (G) : 0u))
+#define PBL_SAL_DELTA_OFF(nch) PBL_ALIGN128((nch) * 2u)                                   /* from off_sal */
+#define PBL_SAL_CODE_OFF(nch) (PBL_SAL_DELTA_OFF(nch) + PBL_ALIGN128((nch) * 16u))
+#define PBL_SAL_TAILCNT_OFF(nch) (PBL_SAL_CODE_OFF(nch) + PBL_ALIGN128((nch) * 16u))
+#define PBL_SAL_CROW_OFF(nch, ntail) (PBL_SAL_TAILCNT_OFF(nch) + PBL_ALIGN16(ntail))
+#define PBL_SAL_EXC_OFF(nch, ntail, has_crow) (PBL_SAL_CROW_OFF(nch, ntail) + ((has_crow) ? PBL_ALIGN16(nch) : 0u))
+#define PBL_SAL_BYTES(nch, ntail, nexc, has_crow) PBL_ALIGN128(PBL_SAL_EXC_OFF(nch, ntail, has_crow) + (nexc) * 8u)
 
 typedef enum {
     PBL_OK = 0,

@@ -18,6 +18,10 @@ def _a16(x):
     return (x + 15) & ~15
 
 
+def _a128(x):
+    return (x + 127) & ~127
+
+
 def read_header(blob: np.ndarray) -> dict:
     f = HDR.unpack(blob[:80].tobytes())
     keys = ["magic", "version", "N", "K", "P", "G", "NRB", "flags", "max_nch", "max_nexc",
@@ -53,6 +57,7 @@ def decode(blob: np.ndarray) -> np.ndarray:
         params = rec[144:400].view(np.float32).reshape(16, 4)
         ghl = rec[400:400 + 16 * G * 8].view(np.float32).reshape(16, G, 2) if G > 1 else None
         tiles_off = off_sal - P * 1024
+        assert tiles_off == _a128(400 + (128 * G if G > 1 else 0)) and rb_off[b] % 128 == 0
         tiles = rec[tiles_off:off_sal].view(np.uint32).reshape(P, 64, 4)
         for rho in range(16):
             pos = rho + 8 if rho < 8 else rho - 8
@@ -73,11 +78,11 @@ def decode(blob: np.ndarray) -> np.ndarray:
         nch = nfull + ntail
         s = off_sal
         col0 = rec[s: s + 2 * nch].view(np.uint16).astype(np.int64)
-        s += _a16(2 * nch)
+        s += _a128(2 * nch)
         delta = rec[s: s + 16 * nch].reshape(nch, 16).astype(np.int64)
-        s += 16 * nch
+        s += _a128(16 * nch)
         code = rec[s: s + 16 * nch].reshape(nch, 16).astype(np.float32)
-        s += 16 * nch
+        s += _a128(16 * nch)
         tailcnt = rec[s: s + ntail].astype(np.int64)
         s += _a16(ntail)
         if h["flags"] & 0x3:   # HAS_GROUPS | SAL_F16: per-chunk row ids

@@ -50,21 +50,22 @@ __global__ __launch_bounds__(4 * GW) void pbl_gemm_band_kernel(pbl_layer L, cons
     const int nfull = __builtin_amdgcn_readfirstlane(info.y), ntail = __builtin_amdgcn_readfirstlane(info.z);
     const int nexc = __builtin_amdgcn_readfirstlane(info.w), nch = nfull + ntail;
     const bool groups = L.flags & PBL_FLAG_HAS_GROUPS;
-    const uint32_t tiles_off = groups ? ((400u + 128u * uint32_t(G) + 15u) & ~15u) : 400u;
+    const uint32_t tiles_off = PBL_TILES_OFF(uint32_t(G));
     const uint32_t off_sal = tiles_off + uint32_t(P) * 1024u;
-    const pbl_rowparams* params = reinterpret_cast<const pbl_rowparams*>(rec + 144);
-    const pbl_rowinfo* rinfo = reinterpret_cast<const pbl_rowinfo*>(rec + 16);
-    const float2* ghl = reinterpret_cast<const float2*>(rec + 400);
+    const pbl_rowparams* params = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
+    const pbl_rowinfo* rinfo = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF);
+    const float2* ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
     const int gwords = groups ? (K / G) / 128 : (1 << 30);
     const u32x4* tiles = reinterpret_cast<const u32x4*>(rec + tiles_off) + lane;
     const uint8_t* sal = rec + off_sal;
+    const uint32_t nchu = uint32_t(nch);
     const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
-    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + ((size_t(nch) * 2 + 15) & ~size_t(15)));
-    const u32x4* codep = deltap + nch;
-    const uint8_t* tailcnt = reinterpret_cast<const uint8_t*>(codep + nch);
+    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + PBL_SAL_DELTA_OFF(nchu));
+    const u32x4* codep = reinterpret_cast<const u32x4*>(sal + PBL_SAL_CODE_OFF(nchu));
+    const uint8_t* tailcnt = sal + PBL_SAL_TAILCNT_OFF(nchu);
     const bool has_crow = L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16);
-    const uint8_t* crow = tailcnt + ((size_t(ntail) + 15) & ~size_t(15));
-    const uint2* exc = reinterpret_cast<const uint2*>(crow + (has_crow ? ((size_t(nch) + 15) & ~size_t(15)) : 0));
+    const uint8_t* crow = sal + PBL_SAL_CROW_OFF(nchu, uint32_t(ntail));
+    const uint2* exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), has_crow));
 
     v4f acc[NTB];
 #pragma unroll

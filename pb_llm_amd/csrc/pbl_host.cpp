@@ -42,20 +42,10 @@ inline int bit_index(int rho, int e) {
     return e * 16 + pos;
 }
 
-size_t record_fixed_bytes(uint32_t P, uint32_t G) {
-    size_t s = sizeof(pbl_rec_header) + 16 * sizeof(pbl_rowinfo) + 16 * sizeof(pbl_rowparams);
-    if (G > 1) s += size_t(16) * G * 8;
-    s = align16(s);
-    return s + size_t(P) * 1024;
-}
+size_t record_fixed_bytes(uint32_t P, uint32_t G) { return size_t(PBL_TILES_OFF(G)) + size_t(P) * 1024; }
 
 size_t record_sal_bytes(size_t nch, size_t ntail, size_t nexc, bool has_crow) {
-    size_t s = align16(nch * 2);       // col0
-    s += nch * 16 * 2;                 // delta + code
-    s += align16(ntail);               // tailcnt
-    if (has_crow) s += align16(nch);   // crow: row-in-block of every chunk
-    s += nexc * sizeof(pbl_exception);
-    return align16(s);
+    return PBL_SAL_BYTES(uint32_t(nch), uint32_t(ntail), uint32_t(nexc), has_crow);
 }
 
 }  // namespace
@@ -91,7 +81,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
     const uint32_t NRB = (N + 15) / 16;
 
     const size_t rboff_pos = sizeof(pbl_blob_header);
-    const size_t rec0 = align16(rboff_pos + size_t(NRB + 1) * sizeof(pbl_rec_info));
+    const size_t rec0 = align128(rboff_pos + size_t(NRB + 1) * sizeof(pbl_rec_info));
     const size_t fixed = record_fixed_bytes(P, G);
     const size_t tiles_off = fixed - size_t(P) * 1024;
 
@@ -203,27 +193,28 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
             std::memcpy(rec, &h, sizeof(h));
             std::memcpy(rec + 16, rb.ri, sizeof(rb.ri));
             std::memcpy(rec + 16 + 128, params, sizeof(params));
-            if (G > 1) std::memcpy(rec + 400, ghl.data(), ghl.size() * 4);
+            if (G > 1) std::memcpy(rec + PBL_REC_GHL_OFF, ghl.data(), ghl.size() * 4);
             std::memcpy(rec + tiles_off, tile.data(), tile.size() * 4);
             uint8_t* s = rec + fixed;
+            const uint32_t nch32 = uint32_t(nch), ntail32 = uint32_t(ntail);
+            const bool has_crow = G > 1 || sal16;
             uint16_t* col0 = reinterpret_cast<uint16_t*>(s);
             for (size_t k = 0; k < nfull; ++k) col0[k] = rb.col0_full[k];
             for (size_t k = 0; k < ntail; ++k) col0[nfull + k] = rb.col0_tail[k];
-            s += align16(nch * 2);
-            if (nfull) std::memcpy(s, rb.delta_full.data(), nfull * 16);
-            if (ntail) std::memcpy(s + nfull * 16, rb.delta_tail.data(), ntail * 16);
-            s += nch * 16;
-            if (nfull) std::memcpy(s, rb.code_full.data(), nfull * 16);
-            if (ntail) std::memcpy(s + nfull * 16, rb.code_tail.data(), ntail * 16);
-            s += nch * 16;
-            if (ntail) std::memcpy(s, rb.tailcnt.data(), ntail);
-            s += align16(ntail);
-            if (G > 1 || sal16) {
-                if (nfull) std::memcpy(s, rb.crow_full.data(), nfull);
-                if (ntail) std::memcpy(s + nfull, rb.crow_tail.data(), ntail);
-                s += align16(nch);
+            uint8_t* dl = s + PBL_SAL_DELTA_OFF(nch32);
+            if (nfull) std::memcpy(dl, rb.delta_full.data(), nfull * 16);
+            if (ntail) std::memcpy(dl + nfull * 16, rb.delta_tail.data(), ntail * 16);
+            uint8_t* cd = s + PBL_SAL_CODE_OFF(nch32);
+            if (nfull) std::memcpy(cd, rb.code_full.data(), nfull * 16);
+            if (ntail) std::memcpy(cd + nfull * 16, rb.code_tail.data(), ntail * 16);
+            if (ntail) std::memcpy(s + PBL_SAL_TAILCNT_OFF(nch32), rb.tailcnt.data(), ntail);
+            if (has_crow) {
+                uint8_t* cr = s + PBL_SAL_CROW_OFF(nch32, ntail32);
+                if (nfull) std::memcpy(cr, rb.crow_full.data(), nfull);
+                if (ntail) std::memcpy(cr + nfull, rb.crow_tail.data(), ntail);
             }
-            if (!rb.exc.empty()) std::memcpy(s, rb.exc.data(), rb.exc.size() * sizeof(pbl_exception));
+            if (!rb.exc.empty())
+                std::memcpy(s + PBL_SAL_EXC_OFF(nch32, ntail32, has_crow), rb.exc.data(), rb.exc.size() * sizeof(pbl_exception));
         }
         cur += rec_bytes;
     }
@@ -273,15 +264,16 @@ int pbl_unpack_dense_f32(const void* host_blob, size_t bytes, float* Wout) {
         std::memcpy(&rh, rec, sizeof(rh));
         const pbl_rowinfo* ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16);
         const pbl_rowparams* pr = reinterpret_cast<const pbl_rowparams*>(rec + 144);
-        const float* ghl = reinterpret_cast<const float*>(rec + 400);
+        const float* ghl = reinterpret_cast<const float*>(rec + PBL_REC_GHL_OFF);
         const uint32_t* tile = reinterpret_cast<const uint32_t*>(rec + tiles_off);
-        const size_t nch = size_t(rh.nfull) + rh.ntail;
+        const uint32_t nch = rh.nfull + rh.ntail;
         const uint8_t* s = rec + rh.off_sal;
+        const bool has_crow = L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16);
         const uint16_t* col0 = reinterpret_cast<const uint16_t*>(s);
-        const uint8_t* delta = s + align16(nch * 2);
-        const uint8_t* code = delta + nch * 16;
-        const uint8_t* tailcnt = code + nch * 16;
-        const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(tailcnt + align16(rh.ntail) + ((L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16)) ? align16(nch) : 0));
+        const uint8_t* delta = s + PBL_SAL_DELTA_OFF(nch);
+        const uint8_t* code = s + PBL_SAL_CODE_OFF(nch);
+        const uint8_t* tailcnt = s + PBL_SAL_TAILCNT_OFF(nch);
+        const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(s + PBL_SAL_EXC_OFF(nch, rh.ntail, has_crow));
         for (int rho = 0; rho < 16; ++rho) {
             const uint32_t r = b * 16 + rho;
             if (r >= N) continue;

@@ -312,15 +312,16 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     const int ntail = __builtin_amdgcn_readfirstlane(info.z);
     const int nexc = __builtin_amdgcn_readfirstlane(info.w);
     const int nch = nfull + ntail;
-    const uint32_t tiles_off = (L.flags & PBL_FLAG_HAS_GROUPS) ? ((400u + 128u * L.G + 15u) & ~15u) : 400u;
+    const uint32_t tiles_off = PBL_TILES_OFF(L.G);
     const uint32_t off_sal = tiles_off + uint32_t(P) * 1024u;
+    const uint32_t nchu = uint32_t(nch);
 
     const u32x4* tiles = reinterpret_cast<const u32x4*>(rec + tiles_off) + lane;
     const uint8_t* sal = rec + off_sal;
     const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
-    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + ((size_t(nch) * 2 + 15) & ~size_t(15)));
-    const u32x4* codep = deltap + nch;
-    const uint8_t* tailcnt = reinterpret_cast<const uint8_t*>(codep + nch);
+    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + PBL_SAL_DELTA_OFF(nchu));
+    const u32x4* codep = reinterpret_cast<const u32x4*>(sal + PBL_SAL_CODE_OFF(nchu));
+    const uint8_t* tailcnt = sal + PBL_SAL_TAILCNT_OFF(nchu);
 
     u32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
     uint32_t s_c0 = 0;
@@ -399,11 +400,11 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     // row-owner lanes: lane l owns row rho(l) (4 lanes per row)
     const int rho = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
     const int sub = lane & 3;
-    const pbl_rowparams pr = reinterpret_cast<const pbl_rowparams*>(rec + 144)[rho];
-    const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16)[rho];   // issued early: phase 3 must not wait on HBM
+    const pbl_rowparams pr = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF)[rho];
+    const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF)[rho];   // issued early: phase 3 must not wait on HBM
     // SF layers in a mixed grouped launch are told apart at run time (wave-uniform)
     const bool sf = SF && (L.flags & PBL_FLAG_SAL_F16);
-    const uint8_t* crow = tailcnt + ((size_t(ntail) + 15) & ~size_t(15));
+    const uint8_t* crow = sal + PBL_SAL_CROW_OFF(nchu, uint32_t(ntail));
     const bool has_crow = L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16);
 
     // ---- phase 2: salient chunks (next round's loads issued before this round's math) ---
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     const uint32_t row = rb * 16 + rho;
     // exceptions are read as ONE aligned 64-bit word each: a scalar load of the fp32
     // field off a 2-byte-aligned base silently drops the low address bits on gfx950
-    const uint2* exc = reinterpret_cast<const uint2*>(crow + (has_crow ? ((size_t(nch) + 15) & ~size_t(15)) : 0));
+    const uint2* exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), has_crow));
 
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
     const int ntail = __builtin_amdgcn_readfirstlane(info.z);
     const int nexc = __builtin_amdgcn_readfirstlane(info.w);
     const int nch = nfull + ntail;
-    const uint32_t tiles_off = (400u + 128u * uint32_t(G) + 15u) & ~15u;
+    const uint32_t tiles_off = PBL_TILES_OFF(uint32_t(G));
     const uint32_t off_sal = tiles_off + uint32_t(P) * 1024u;
 
     {   // stage x, build this wave's coefficient tables
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
             for (int i = K + tid; i < xstride; i += nthr) xs[m * xstride + i] = _Float16(0);
         }
         if (active) {
-            const float2* ghl = reinterpret_cast<const float2*>(rec + 400);
+            const float2* ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
             for (int idx = lane; idx < 16 * G; idx += PBL_WAVE) {
                 const int rho = idx & 15, g = idx >> 4;
                 const float2 hl = ghl[rho * G + g];
@@ -658,18 +659,19 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
 
     // salient chunks: per entry  q*x, x and hi[row][group(col)]*x
     const uint8_t* sal = rec + off_sal;
+    const uint32_t nchu = uint32_t(nch);
     const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
-    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + ((size_t(nch) * 2 + 15) & ~size_t(15)));
-    const u32x4* codep = deltap + nch;
-    const uint8_t* tailcnt = reinterpret_cast<const uint8_t*>(codep + nch);
-    const uint8_t* crow = tailcnt + ((size_t(ntail) + 15) & ~size_t(15));
+    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + PBL_SAL_DELTA_OFF(nchu));
+    const u32x4* codep = reinterpret_cast<const u32x4*>(sal + PBL_SAL_CODE_OFF(nchu));
+    const uint8_t* tailcnt = sal + PBL_SAL_TAILCNT_OFF(nchu);
+    const uint8_t* crow = sal + PBL_SAL_CROW_OFF(nchu, uint32_t(ntail));
     for (int base = 0; base < nch; base += PBL_WAVE) {
         const int c = base + lane;
         if (c < nch) {
             const u32x4 d4 = deltap[c], q4 = codep[c];
             const int cnt = c >= nfull ? int(tailcnt[c - nfull]) : 16;
             const int row = crow[c];
-            const pbl_rowparams cp = reinterpret_cast<const pbl_rowparams*>(rec + 144)[row];
+            const pbl_rowparams cp = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF)[row];
             const bool sf16 = L.flags & PBL_FLAG_SAL_F16;
             uint32_t col2 = 2u * col0p[c];
             float Q[MB], S[MB], H[MB];
@@ -704,9 +706,9 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
 
     const int rho = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
     const int sub = lane & 3;
-    const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + 16)[rho];
+    const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF)[rho];
     const uint32_t row = rb * 16 + rho;
-    const uint2* exc = reinterpret_cast<const uint2*>(crow + ((size_t(nch) + 15) & ~size_t(15)));
+    const uint2* exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), true));
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
         float Q = 0.f, S = 0.f, H = 0.f;
@@ -756,11 +758,11 @@ __global__ __launch_bounds__(4 * PBL_WAVE) void pbl_unpack_kernel(pbl_layer L, O
     const int nfull = __builtin_amdgcn_readfirstlane(info.y), ntail = __builtin_amdgcn_readfirstlane(info.z);
     const int nexc = __builtin_amdgcn_readfirstlane(info.w), nch = nfull + ntail;
     const bool groups = L.flags & PBL_FLAG_HAS_GROUPS, sf16 = L.flags & PBL_FLAG_SAL_F16;
-    const uint32_t tiles_off = groups ? ((400u + 128u * uint32_t(G) + 15u) & ~15u) : 400u;
+    const uint32_t tiles_off = PBL_TILES_OFF(uint32_t(G));
     const uint32_t off_sal = tiles_off + uint32_t(P) * 1024u;
-    const pbl_rowparams* params = reinterpret_cast<const pbl_rowparams*>(rec + 144);
-    const pbl_rowinfo* rinfo = reinterpret_cast<const pbl_rowinfo*>(rec + 16);
-    const float2* ghl = reinterpret_cast<const float2*>(rec + 400);
+    const pbl_rowparams* params = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
+    const pbl_rowinfo* rinfo = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF);
+    const float2* ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
     const int gwords = groups ? (K / G) / 128 : (1 << 30);   // dwords of a lane per column group
     const int nrows = (L.N - rb * 16) < 16u ? int(L.N - rb * 16) : 16;
 
@@ -818,13 +820,13 @@ __global__ __launch_bounds__(4 * PBL_WAVE) void pbl_unpack_kernel(pbl_layer L, O
     __syncthreads();
 
     const uint8_t* sal = rec + off_sal;
+    const uint32_t nchu = uint32_t(nch);
     const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
-    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + ((size_t(nch) * 2 + 15) & ~size_t(15)));
-    const u32x4* codep = deltap + nch;
-    const uint8_t* tailcnt = reinterpret_cast<const uint8_t*>(codep + nch);
+    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + PBL_SAL_DELTA_OFF(nchu));
+    const u32x4* codep = reinterpret_cast<const u32x4*>(sal + PBL_SAL_CODE_OFF(nchu));
+    const uint8_t* tailcnt = sal + PBL_SAL_TAILCNT_OFF(nchu);
     const bool has_crow = L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16);
-    const uint8_t* after_tail = tailcnt + ((size_t(ntail) + 15) & ~size_t(15));
-    const uint2* exc = reinterpret_cast<const uint2*>(after_tail + (has_crow ? ((size_t(nch) + 15) & ~size_t(15)) : 0));
+    const uint2* exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), has_crow));
     for (int c = threadIdx.x; c < nch; c += 4 * PBL_WAVE) {
         // row of chunk c: full chunks are laid out row by row (then the tail chunks likewise) and the
         // per-row start indices are non-decreasing, so the owner is the last row whose start is <= c
