@@ -48,8 +48,6 @@ __device__ __forceinline__ _Float16 round_f16_twice(float prod) {
     return _Float16(prod);
 }
 
-__device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, PBL_WAVE); }
-
 // Bit classes 8..15 of an fp16 half-word: pair mask M and OR-constant C such that
 // (w & M) | C is an fp16x2 holding {lo_c, lo_c + d_c} per element.  The signed
 // sum over a lane's columns is  D = A_c * acc - B_c * Xl  (Xl = plain sum of x).

@@ -379,6 +379,30 @@ def test_grouped_launch_matches_individual():
         assert_parity(Q.PBLinear(p, None)(T(x)), y.float().cpu().numpy().astype(np.float64), 2e-3)
 
 
+def test_hipgraph_capture_and_side_stream(llama7b_qproj):
+    """the C ABI is asynchronous on the stream it is given and graph-capturable (no allocation or
+    synchronisation inside): capture one forward on a side stream, replay it with new inputs"""
+    W, mask, r = llama7b_qproj
+    p = pack_dense(r["W_fq"], r["scale"][0] + r["mean"][0], -r["scale"][0] + r["mean"][0], r["hscale"],
+                   r["hzero"], (~mask).astype(np.uint8)).to(DEV)
+    layer = Q.PBLinear(p, None)
+    xs = [synth.activations((1, 4096), 40 + i, 21) for i in range(3)]
+    x_static = T(xs[0]).clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        y_side = layer(x_static)              # eager on a non-default stream
+    side.synchronize()
+    assert_parity(y_side, O.dense_linear(xs[0], r["W_fq"]))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        y_static = layer(x_static)
+    for x in xs:
+        x_static.copy_(T(x))
+        g.replay()
+        torch.cuda.synchronize()
+        assert_parity(y_static, O.dense_linear(x, r["W_fq"]))
+
+
 def test_misuse_raises():
     W = synth.llm_weight(16, 512, seed=1)
     m = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV)

@@ -150,6 +150,8 @@ def test_bad_arguments_and_blobs():
     hi = np.ones((16, 3), np.float32)
     with pytest.raises(_lib.PblError):       # K % G != 0 / groupsize not a multiple of 128
         pack_dense(W, hi, -hi)
+    with pytest.raises(_lib.PblError):       # column indices are 16 bit with pre-doubled byte steps: K <= 32767
+        pack_dense(np.zeros((1, 32768), np.float32), np.ones((1, 1), np.float32), -np.ones((1, 1), np.float32))
     junk = torch.zeros(256, dtype=torch.uint8)
     with pytest.raises(_lib.PblError):
         PackedWeight.from_blob(junk)
