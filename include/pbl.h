@@ -61,7 +61,9 @@
  *   to 16: a chunk closes after 16 entries or when the next column step exceeds 127.
  *   Chunk c: col0[c] = column of entry 0; delta[c][k] = 2 * (column step from entry
  *   k-1 to k), i.e. the BYTE step in an fp16 x vector (delta[c][0] = 0); code[c][k] = q.  Chunks with exactly 16 entries are
- *   "full"; the others are "tail" chunks and carry their count in tailcnt[].
+ *   "full"; the others are "tail" chunks and carry their count in tailcnt[].  With PBL_FLAG_TAIL_REPEAT the
+ *   unused entries of a tail chunk have step 0 and REPEAT the last entry's code, so a reader that writes
+ *   positions (rather than accumulates) may process all 16 entries of any chunk without looking at tailcnt.
  *   Chunk order within a record: full chunks of row 0, row 1, ... row 15 (indices
  *   0..nfull-1), then the tail chunks of row 0, row 1, ... (indices nfull..nch-1).
  *   rowinfo[r]: full chunks [start, start+nfull), tail chunks
@@ -119,6 +121,7 @@ typedef enum {
                                     checkpoint (gptq_pb/gptq.py:182 `.to(fp16)`).  Unpack and the GEMV both
                                     apply the fp16 rounding (v_cvt_pk_f16_f32), so the layer is reproduced
                                     bit-exactly. */
+#define PBL_FLAG_TAIL_REPEAT 0x4u /* tail-chunk padding repeats the last entry (step 0, same code); set by this packer */
 
 typedef struct {
     uint32_t magic, version;
@@ -187,8 +190,9 @@ size_t pbl_gemv_lds_bytes(const pbl_layer* layer, int m);
 
 /* y[M,N] = x[M,K] @ W_sim^T + bias.  x, y: device fp16, row-major, contiguous
  * (replaces F.linear(x, w_sim, bias): quant/outlier_quantizer.py:105,
- * quant/quantizer.py:86,193).  M >= 1; weights are streamed once per
- * PBL_MAX_TOKENS_PER_LAUNCH tokens.  y_f32 != 0: y is fp32 instead of fp16.
+ * quant/quantizer.py:86,193).  M >= 1: up to PBL_MAX_TOKENS_PER_LAUNCH tokens run on the bit-unpacking GEMV,
+ * more on the matrix-core kernel (pbl_gemm_mfma_f16, weights streamed once per 32 tokens) when the layer
+ * qualifies, else in GEMV passes of 4.  y_f32 != 0: y is fp32 instead of fp16.
  * stream: hipStream_t (as void*). */
 int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream);
 
@@ -200,11 +204,12 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
  * fp16-representable to be exact (true for layers packed from an fp16 checkpoint). */
 int pbl_unpack_dev(const pbl_layer* layer, void* W_out, int out_f32, void* stream);
 
-/* Small-batch GEMM straight from the packed format: y[M,N] = x[M,K] @ W^T + bias for
- * 1 <= M <= 64, fp16 in/out, ONE pass over the packed weights for all tokens (band-wise expansion
- * to exact fp16 in LDS + v_mfma_f32_16x16x32_f16).  Only for fp16-exact layers
- * (PBL_FLAG_SAL_F16); others return PBL_ERR_UNSUPPORTED and use pbl_linear_f16 / pbl_unpack_dev. */
-int pbl_gemm_small_f16(const pbl_layer* layer, const void* x, void* y, int M, void* stream);
+/* Matrix-core kernel for 1 <= M <= 32 tokens, any layer with G == 1, K % 8 == 0, PBL_FLAG_TAIL_REPEAT and x
+ * 16-B aligned (else PBL_ERR_UNSUPPORTED): ONE pass over the packed weights for all tokens; per 256-column
+ * half panel the class-coded sign plane, the salient operand and a salient mask are expanded in LDS and
+ * contracted with v_mfma_f32_16x16x32_f16; fp32 decode identical to the GEMV.  y fp16 (y_f32 == 0) or fp32.
+ * pbl_linear_f16 routes M > 4 here by itself. */
+int pbl_gemm_mfma_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream);
 
 /* L independent layers in ONE launch (decode-time fused QKV / gate+up, and the
  * stream benchmark of SURVEY.md 8(d)).  layers_dev: DEVICE array of L pbl_layer;

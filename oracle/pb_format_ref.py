@@ -109,6 +109,8 @@ def decode(blob: np.ndarray) -> np.ndarray:
             for t in range(int(ri["tailidx"]), int(ri["tailidx"]) + int(ri["ntail"])):
                 ch, n = nfull + t, tailcnt[t]
                 W[b * 16 + rho, cols[ch, :n]] = deq(ss, code[ch, :n], sz)
+                if h["flags"] & 0x4:   # PBL_FLAG_TAIL_REPEAT: padding repeats the last entry with step 0
+                    assert 1 <= n < 16 and (delta[ch, n:] == 0).all() and (code[ch, n:] == code[ch, n - 1]).all()
         for e in exc:
             W[b * 16 + int(e["row"]), int(e["col"])] = e["value"]
     return W[:N, :K].copy()

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libpbl.so")
 PBL_MAX_TOKENS_PER_LAUNCH = 4
 PBL_FLAG_HAS_GROUPS = 0x1
 PBL_FLAG_SAL_F16 = 0x2
+PBL_FLAG_TAIL_REPEAT = 0x4
 
 
 class PblLayer(C.Structure):
@@ -40,7 +41,7 @@ class PblError(RuntimeError):
 _lib = None
 
 EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_blob_describe",
-           "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemm_small_f16", "pbl_gemv_f16_grouped"]
+           "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemm_mfma_f16", "pbl_gemv_f16_grouped"]
 
 
 def lib() -> C.CDLL:
@@ -70,8 +71,8 @@ def lib() -> C.CDLL:
     L.pbl_gemv_lds_bytes.argtypes = [C.POINTER(PblLayer), C.c_int]
     L.pbl_linear_f16.restype = C.c_int
     L.pbl_linear_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
-    L.pbl_gemm_small_f16.restype = C.c_int
-    L.pbl_gemm_small_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, vp]
+    L.pbl_gemm_mfma_f16.restype = C.c_int
+    L.pbl_gemm_mfma_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
     L.pbl_gemv_f16_grouped.restype = C.c_int
     L.pbl_gemv_f16_grouped.argtypes = [vp, vp, vp, C.c_int, C.c_int, u32, u32, u32, u32, C.c_int, C.c_int, vp]
     _lib = L

@@ -157,6 +157,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
                     d[k] = k ? uint8_t(2 * (ents[i + k].col - ents[i + k - 1].col)) : 0;  // byte step in the fp16 x tile
                     q[k] = ents[i + k].code;
                 }
+                for (size_t k = cnt; k < 16; ++k) q[k] = q[cnt - 1];   // PBL_FLAG_TAIL_REPEAT: padding repeats the last entry
                 if (cnt == 16) {
                     rb.col0_full.push_back(ents[i].col);
                     rb.delta_full.insert(rb.delta_full.end(), d, d + 16);
@@ -225,7 +226,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
         pbl_blob_header h;
         std::memset(&h, 0, sizeof(h));
         h.magic = PBL_MAGIC; h.version = PBL_VERSION; h.N = N; h.K = K; h.P = P; h.G = G; h.NRB = NRB;
-        h.flags = (G > 1 ? PBL_FLAG_HAS_GROUPS : 0) | (sal16 ? PBL_FLAG_SAL_F16 : 0);
+        h.flags = (G > 1 ? PBL_FLAG_HAS_GROUPS : 0) | (sal16 ? PBL_FLAG_SAL_F16 : 0) | PBL_FLAG_TAIL_REPEAT;
         h.max_nch = max_nch; h.max_nexc = max_nexc; h.nnz = nnz; h.nexc = nexc_total;
         h.blob_bytes = cur; h.rb_off_pos = uint32_t(rboff_pos);
         std::memcpy(blob, &h, sizeof(h));

@@ -959,6 +959,18 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
     if (layer->G != 1) return linear_groups(layer, x, y, M, y_f32, st);
     const size_t esz = y_f32 ? 4 : 2;
     const bool sf = layer->flags & PBL_FLAG_SAL_F16;
+    // more than one GEMV pass: the matrix-core kernel streams the weights once per 32 tokens instead of once
+    // per 4 (tiny layers at M <= 8 stay on the GEMV: both are launch-latency bound and the GEMV starts faster)
+    if (M > PBL_MAX_TOKENS_PER_LAUNCH && (M > 8 || layer->NRB >= 128) && !(layer->K & 7) &&
+        (layer->flags & PBL_FLAG_TAIL_REPEAT) && !(reinterpret_cast<uintptr_t>(x) & 15)) {
+        int m0 = 0, rc = PBL_OK;
+        for (; m0 < M && rc == PBL_OK; m0 += 32) {
+            const int mb = M - m0 < 32 ? M - m0 : 32;
+            rc = pbl_gemm_mfma_f16(layer, static_cast<const _Float16*>(x) + size_t(m0) * layer->K,
+                                   static_cast<char*>(y) + size_t(m0) * layer->N * esz, mb, y_f32, stream);
+        }
+        if (rc != PBL_ERR_UNSUPPORTED) return rc;   // unsupported (LDS budget): every slab failed the same way, fall through
+    }
     // throughput mode (a wave per record, 4 per workgroup) when there are enough records to fill the
     // chip; otherwise latency mode: S waves share a record
     const int split = layer->NRB >= PBL_SPLIT_TARGET_WAVES ? 1 : pick_split(layer->NRB, layer->P);

@@ -32,13 +32,13 @@ class BinaryInterface:
         return {"weight": self.weight.data.half().cpu(), "bias": self.bias}
 
 
-# M at which the forward switches from the bit-unpacking GEMV (weights streamed once per 4 tokens)
-# to "unpack to a transient dense workspace + library GEMM" (prefill / large batches).
+# Kernel choice by token count (rows of x after flattening):
+#   rows <= 4            bit-unpacking GEMV (pbl_linear_f16), weights streamed once
+#   rows <= MFMA_MAX     matrix-core kernel (pbl_linear_f16 routes to pbl_gemm_mfma_f16), weights streamed once
+#   above                unpack to a transient dense workspace + library GEMM (prefill / large batches)
+# Layers the matrix-core kernel cannot take (column groups, K % 8) switch to the dense path at GEMM_THRESHOLD.
+MFMA_MAX = 32
 GEMM_THRESHOLD = 12
-# ... and, for fp16-exact layers, the band GEMM (pbl_gemm_small_f16: one pass over the packed
-# weights for all tokens, MFMA) covers GEMM_THRESHOLD <= M <= SMALL_GEMM_MAX.
-SMALL_GEMM_MAX = 32
-SMALL_GEMM_MIN_RECORDS = 512   # below this the band kernel cannot fill the chip; the dense path wins
 _workspaces: dict = {}
 
 
@@ -62,6 +62,16 @@ def unpack_on_device(packed: PackedWeight, dtype=torch.float16) -> torch.Tensor:
     return W
 
 
+def mfma_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False) -> torch.Tensor:
+    """pbl_gemm_mfma_f16: x2 [M<=32, K] fp16 contiguous on the GPU -> [M, N] (fp16 or fp32)."""
+    M = x2.shape[0]
+    y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
+    layer = packed.layer_struct(bias_f32)
+    stream = torch.cuda.current_stream(x2.device).cuda_stream
+    _lib.check(_lib.lib().pbl_gemm_mfma_f16(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), stream), "gemm_mfma")
+    return y
+
+
 def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: torch.Tensor,
                       out_f32: bool = False, dense_dtype=None) -> torch.Tensor:
     """y = F.linear(x, w_sim, bias) through libpbl (pbl_linear_f16).  x [..., K] on
@@ -81,14 +91,9 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     L = _lib.lib()
     if M == 0:
         return x.new_zeros(*lead, packed.N)
-    if (GEMM_THRESHOLD <= M <= SMALL_GEMM_MAX and x.dtype == torch.float16 and not out_f32
-            and (packed.flags & _lib.PBL_FLAG_SAL_F16) and packed.max_nch <= 3000
-            and packed.NRB >= SMALL_GEMM_MIN_RECORDS):
-        xc = x2.contiguous()
-        y = torch.empty(M, packed.N, dtype=torch.float16, device=x.device)
-        _lib.check(L.pbl_gemm_small_f16(C.byref(layer), xc.data_ptr(), y.data_ptr(), M, stream), "gemm_small")
-        return y.reshape(*lead, packed.N)
-    if M >= GEMM_THRESHOLD:
+    mfma_ok = packed.G == 1 and packed.K % 8 == 0 and bool(packed.flags & _lib.PBL_FLAG_TAIL_REPEAT)
+    rows = M if x.dtype == torch.float16 else 2 * M     # fp32 / bf16 x runs as two fp16 terms
+    if (rows > MFMA_MAX) if mfma_ok else (M >= GEMM_THRESHOLD):
         # GEMM regime: dense weight in the workspace + library GEMM, i.e. exactly what the
         # reference executes (F.linear over the dense fake-quant weight).  fp16 weights when
         # the layer is fp16-exact (packed from an fp16 checkpoint), else fp32.

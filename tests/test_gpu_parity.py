@@ -324,15 +324,16 @@ def test_gemm_regime_forward(M, llama7b_qproj):
     y = layer(T(x))
     assert y.shape == (M, 4096) and y.dtype == torch.float16
     assert_parity(y, O.dense_linear(x, W16.numpy()))
-    # the GEMV path (M < threshold) and the GEMM path agree on the same tokens
+    # the GEMV path (M <= 4) and the batched path agree on the same tokens
     y_small = torch.cat([layer(T(x[i:i + 4])) for i in range(0, 12, 4)])
     assert_parity(y[:12], y_small.float().cpu().numpy().astype(np.float64), 2e-3)
 
 
 @pytest.mark.parametrize("N,K,gs,M,bias", [(4096, 4096, -1, 32, False), (100, 1536, -1, 12, True), (33, 640, 128, 17, True),
                                             (768, 3072, -1, 64, False), (5120, 13824, -1, 33, False)])
-def test_band_gemm_small_batch(N, K, gs, M, bias):
-    """pbl_gemm_small_f16 (12 <= M <= 64, fp16-exact layers): one weight pass + MFMA"""
+def test_small_batch_dispatch(N, K, gs, M, bias):
+    """5 <= M <= 64 on fp16 checkpoints through the module: matrix-core kernel up to 32 tokens (column-group
+    layers: GEMV passes, then dense), dense workspace + library GEMM above"""
     W = synth.llm_weight(N, K, seed=N + K + M, heavy_tail=True)
     lf = 0.8 if N * K > 5e7 else 0.9
     mask = O.ptq_low_mask(W, lf, "magnitude", None, gs)
@@ -343,16 +344,47 @@ def test_band_gemm_small_batch(N, K, gs, M, bias):
     layer = Q.PBLinear.from_dense(W16, T(b).cpu() if bias else None, torch.from_numpy(mask), gs, r["hscale"], r["hzero"]).to(DEV)
     assert layer.packed.flags & _lib.PBL_FLAG_SAL_F16 and layer.packed.nexc >= 1
     x = synth.activations((M, K), N, 21)
-    Q.SMALL_GEMM_MAX, Q.SMALL_GEMM_MIN_RECORDS = 64, 1       # force the band kernel for every shape here
-    try:
-        y = layer(T(x))
-    finally:
-        Q.SMALL_GEMM_MAX, Q.SMALL_GEMM_MIN_RECORDS = 32, 512
+    y = layer(T(x))
     assert y.shape == (M, N) and y.dtype == torch.float16
     assert_parity(y, O.dense_linear(x, W16.numpy(), b))
     # against the reference's own GPU arithmetic on the dense checkpoint (F.linear fp16)
     ref_gpu = torch.nn.functional.linear(T(x), W16.to(DEV), T(b).half() if bias else None)
     assert_parity(y, ref_gpu.float().cpu().numpy().astype(np.float64), 2e-3)
+
+
+@pytest.mark.parametrize("N,K,M,kind,bias", [(4096, 4096, 32, "fp32", False), (4096, 4096, 7, "fp16", False),
+                                              (100, 1536, 12, "fp16", True), (33, 520, 17, "fp32", True),
+                                              (768, 3072, 1, "qat", True), (5120, 13824, 32, "fp16", False)])
+def test_mfma_kernel(N, K, M, kind, bias):
+    """pbl_gemm_mfma_f16: matrix-core kernel for 1..32 tokens, any G == 1 layer"""
+    W = synth.llm_weight(N, K, seed=N + K + M, heavy_tail=True)
+    b = synth.normal((N,), 2, 3, 0.1) if bias else None
+    bt = T(b) if bias else None
+    if kind == "qat":
+        m = Q.BinaryXnorExceptOutliersLinear(torch.from_numpy(W), None, 0.1)
+        m.eval(); m.gen_outlier_mask()
+        p = m._pack().to(DEV)
+        Wd = m.binarize_except_outliers().numpy()
+    else:
+        lf = 0.8 if N * K > 5e7 else 0.9
+        mask = O.ptq_low_mask(W, lf, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        Wd = r["W_fq"].copy()
+        if kind == "fp16":
+            Wd = Wd.astype(np.float16).astype(np.float32)
+        Wd[min(5, N - 1), K // 2 + 1] = 0.4321 if kind == "fp32" else np.float32(np.float16(0.4321))
+        from pb_llm_amd.packing import infer_levels
+        hi, lo = infer_levels(Wd, -1, mask)
+        p = pack_dense(Wd, hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8), sal_f16=kind == "fp16").to(DEV)
+        assert p.nexc >= 1
+    x = synth.activations((M, K), N, 21)
+    ref = O.dense_linear(x, Wd, b)
+    y = Q.mfma_forward(p, bt, T(x))
+    assert y.shape == (M, N) and y.dtype == torch.float16
+    assert_parity(y, ref)
+    y32 = Q.mfma_forward(p, bt, T(x), out_f32=True)
+    assert_parity(y32, ref, 2e-4)
+    assert torch.equal(y32, Q.mfma_forward(p, bt, T(x), out_f32=True))      # deterministic
 
 
 # ---------------------------------------------------------------- grouped launch

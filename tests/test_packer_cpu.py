@@ -89,6 +89,19 @@ def test_pack_sign_zero_and_empty_salient():
     assert p2.nnz == 0 and p2.max_nch == 0
 
 
+def test_packer_sets_tail_repeat_flag():
+    """PBL_FLAG_TAIL_REPEAT (include/pbl.h): the MFMA kernel writes all 16 entries of every chunk, so tail
+    padding must repeat the last entry; oracle/pb_format_ref.decode asserts the rule on every tail chunk."""
+    W = synth.llm_weight(40, 1100, seed=9)
+    mask = O.ptq_low_mask(W, 0.83, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    p = pack_dense(r["W_fq"], r["scale"][0] + r["mean"][0], -r["scale"][0] + r["mean"][0], r["hscale"], r["hzero"],
+                   (~mask).astype(np.uint8))
+    assert p.flags & _lib.PBL_FLAG_TAIL_REPEAT
+    assert FR.stats(p.blob.numpy())["ntail"] > 0 if "ntail" in FR.stats(p.blob.numpy()) else True
+    np.testing.assert_array_equal(FR.decode(p.blob.numpy()), r["W_fq"])
+
+
 def test_pack_large_column_gaps_and_dense_rows():
     N, K = 16, 2048
     W = np.full((N, K), -0.5, np.float32)
