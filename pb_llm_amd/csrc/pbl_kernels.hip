@@ -959,9 +959,17 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
     if (layer->G != 1) return linear_groups(layer, x, y, M, y_f32, st);
     const size_t esz = y_f32 ? 4 : 2;
     const bool sf = layer->flags & PBL_FLAG_SAL_F16;
+    // throughput mode (a wave per record, 4 per workgroup) when there are enough records to fill the
+    // chip; otherwise latency mode: S waves share a record
+    const int split = layer->NRB >= PBL_SPLIT_TARGET_WAVES ? 1 : pick_split(layer->NRB, layer->P);
+    const int wpb = split > 1 ? split : (layer->NRB >= 1024 ? 4 : 1);
+    // tokens per weight pass: as many as fit a 96 KiB LDS budget (x tile + chunk partials),
+    // so that K = 13824 layers still run several workgroups per CU
+    int mb_max = PBL_MAX_TOKENS_PER_LAUNCH;
+    while (mb_max > 1 && lds_bytes(layer->P, layer->max_nch, mb_max, wpb, split) > 96 * 1024) --mb_max;
     // more than one GEMV pass: the matrix-core kernel streams the weights once per 32 tokens instead of once
     // per 4 (tiny layers at M <= 8 stay on the GEMV: both are launch-latency bound and the GEMV starts faster)
-    if (M > PBL_MAX_TOKENS_PER_LAUNCH && (M > 8 || layer->NRB >= 128) && !(layer->K & 7) &&
+    if (M > mb_max && (M > 8 || layer->NRB >= 128) && !(layer->K & 7) &&
         (layer->flags & PBL_FLAG_TAIL_REPEAT) && !(reinterpret_cast<uintptr_t>(x) & 15)) {
         int m0 = 0, rc = PBL_OK;
         for (; m0 < M && rc == PBL_OK; m0 += 32) {
@@ -971,14 +979,6 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
         }
         if (rc != PBL_ERR_UNSUPPORTED) return rc;   // unsupported (LDS budget): every slab failed the same way, fall through
     }
-    // throughput mode (a wave per record, 4 per workgroup) when there are enough records to fill the
-    // chip; otherwise latency mode: S waves share a record
-    const int split = layer->NRB >= PBL_SPLIT_TARGET_WAVES ? 1 : pick_split(layer->NRB, layer->P);
-    const int wpb = split > 1 ? split : (layer->NRB >= 1024 ? 4 : 1);
-    // tokens per weight pass: as many as fit a 96 KiB LDS budget (x tile + chunk partials),
-    // so that K = 13824 layers still run several workgroups per CU
-    int mb_max = PBL_MAX_TOKENS_PER_LAUNCH;
-    while (mb_max > 1 && lds_bytes(layer->P, layer->max_nch, mb_max, wpb, split) > 96 * 1024) --mb_max;
     for (int m0 = 0; m0 < M; m0 += mb_max) {
         const int mb = M - m0 < mb_max ? M - m0 : mb_max;
         GemvArgs a{};
