@@ -222,6 +222,30 @@ int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, 
                          int L, int M, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch,
                          uint32_t max_nexc, int group_flags, int y_f32, void* stream);
 
+/* ---------------- QAT step, weight side ------------------------------------------ */
+/* The elementwise work of one training step of BinaryXnorExceptOutliersLinear
+ * (quant/outlier_quantizer.py:83-99; straight-through estimator quant/quantizer.py:18-25), fused into
+ * streaming kernels; the step's GEMMs stay library GEMMs.  W, mask (1 byte per element, nonzero = salient,
+ * the layout of a torch.bool tensor), out, g: device pointers, 16-byte aligned, n = N*K elements.
+ * dtype codes PBL_DTYPE_*.  scale: DEVICE float (written by pbl_qat_scale, read by the others -- no host sync). */
+#define PBL_DTYPE_F32 0
+#define PBL_DTYPE_F16 1
+#define PBL_DTYPE_BF16 2
+#define PBL_QAT_PARTIALS 1024
+/* bytes of device scratch pbl_qat_scale needs */
+size_t pbl_qat_workspace_bytes(void);
+/* *scale_out = mean |W_i| over mask_i == 0 (binary_scale, outlier_quantizer.py:90-93); nan if none.
+ * Deterministic (fixed grid and tree). */
+int pbl_qat_scale(const void* W, int w_dtype, const uint8_t* mask, size_t n, void* workspace, float* scale_out, void* stream);
+/* out_i = mask_i ? W_i * outlier_scale : sign(W_i) * scale   (outlier_quantizer.py:94-98), sign(0) = 0.
+ * Products are rounded to W's dtype like the reference, then converted to out_dtype (f32 -> f16/bf16 is the
+ * autocast cast in front of F.linear).  Supported: f32->f32/f16/bf16, f16->f16, bf16->bf16. */
+int pbl_qat_wsim(const void* W, int w_dtype, const uint8_t* mask, const float* scale, float outlier_scale,
+                 void* out, int out_dtype, size_t n, void* stream);
+/* in place: g_i (= dL/dw_sim_i) *= mask_i ? (train_outlier ? outlier_scale : 0) : scale   -> dL/dW_i. */
+int pbl_qat_wgrad(void* g, int g_dtype, const uint8_t* mask, const float* scale, float outlier_scale, int train_outlier,
+                  size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -340,6 +340,58 @@ def xnor_binary_linear_forward(x, W, bias=None):
 
 
 # --------------------------------------------------------------------------- #
+# One QAT training step (forward + straight-through backward), float64 "truth"
+# --------------------------------------------------------------------------- #
+def _bf16(a: np.ndarray) -> np.ndarray:
+    """round-to-nearest-even to bfloat16, returned as float32 (the autocast cast in front of F.linear)"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16).astype(np.uint32)
+    return r.view(np.float32).reshape(a.shape)
+
+
+def pb_qat_step(x, dy, W_hat, mask, bias=None, outlier_scale=1.0, train_outlier=False, gemm_bf16=False):
+    """BinaryXnorExceptOutliersLinear in train() mode, forward and backward
+    (quant/outlier_quantizer.py:83-106; STEBinary quant/quantizer.py:18-25).
+      s      = mean |W[~mask]|, detached, a SCALAR (boolean indexing flattens)        :90-93
+      w_sim  = where(mask, W*outlier_scale [detached unless train_outlier], sign(W)*s) :94-98
+      y      = x w_sim^T + b                                                           :104-105
+      dL/dx  = dy w_sim;  dL/dw_sim = dy^T x;  dL/db = sum dy
+      dL/dW  = dL/dw_sim * (mask ? (train_outlier ? outlier_scale : 0) : s)   (STE: d sign(W)/dW := 1)
+    gemm_bf16: what bf16 autocast (qat/run_qat.py:120) does -- x, w_sim, bias and dy are rounded to
+    bf16 in front of the GEMMs, products accumulated wide.  Returns float64 arrays + s."""
+    s = refresh_binary_scale(W_hat, mask)
+    w_sim = binarize_except_outliers(W_hat, mask, s, outlier_scale).astype(np.float32)
+    K, N = W_hat.shape[1], W_hat.shape[0]
+    x2, dy2 = x.reshape(-1, K).astype(np.float32), dy.reshape(-1, N).astype(np.float32)
+    b = None if bias is None else bias.astype(np.float32)
+    if gemm_bf16:
+        x2, dy2, w_sim = _bf16(x2), _bf16(dy2), _bf16(w_sim)
+        b = None if b is None else _bf16(b)
+    y = dense_linear(x2, w_sim, b).reshape(*x.shape[:-1], N)
+    dx = (dy2.astype(np.float64) @ w_sim.astype(np.float64)).reshape(x.shape)
+    g = dy2.astype(np.float64).T @ x2.astype(np.float64)
+    coef = np.where(mask, float(outlier_scale) if train_outlier else 0.0, float(s.reshape(())))
+    return dict(y=y, dx=dx, dW=g * coef, db=dy2.astype(np.float64).sum(0), binary_scale=s)
+
+
+def ste_linear_step(x, dy, W, bias=None, xnor=False):
+    """BinaryLinear / XnorBinaryLinear training step (quant/quantizer.py:84-86, 181-193).
+    BinaryLinear: w = STE(W) -> dL/dW = dL/dw.  Xnor: c = W - rowmean(W); a = mean|c| detached;
+    w = STE(c)*a -> dL/dc = dL/dw * a;  dL/dW = dL/dc - rowmean(dL/dc)."""
+    K, N = W.shape[1], W.shape[0]
+    w = xnor_binary_linear_weight(W) if xnor else binary_linear_weight(W)
+    x2, dy2 = x.reshape(-1, K).astype(np.float64), dy.reshape(-1, N).astype(np.float64)
+    y = dense_linear(x, w, bias)
+    dx = (dy2 @ w.astype(np.float64)).reshape(x.shape)
+    g = dy2.T @ x2
+    if xnor:
+        c = W.astype(np.float64) - W.astype(np.float64).mean(-1, keepdims=True)
+        g = g * np.abs(c).mean(-1, keepdims=True)
+        g = g - g.mean(-1, keepdims=True)
+    return dict(y=y, dx=dx, dW=g, db=dy2.sum(0))
+
+
+# --------------------------------------------------------------------------- #
 # The reference's CPU path as it actually executes (torch), for bench.py's cpu_baseline leg
 # --------------------------------------------------------------------------- #
 def torch_dense_linear(x, W_fq, bias=None):

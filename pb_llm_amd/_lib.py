@@ -16,6 +16,7 @@ PBL_MAX_TOKENS_PER_LAUNCH = 4
 PBL_FLAG_HAS_GROUPS = 0x1
 PBL_FLAG_SAL_F16 = 0x2
 PBL_FLAG_TAIL_REPEAT = 0x4
+PBL_DTYPE_F32, PBL_DTYPE_F16, PBL_DTYPE_BF16 = 0, 1, 2
 
 
 class PblLayer(C.Structure):
@@ -41,7 +42,8 @@ class PblError(RuntimeError):
 _lib = None
 
 EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_blob_describe",
-           "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemm_mfma_f16", "pbl_gemv_f16_grouped"]
+           "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemm_mfma_f16", "pbl_gemv_f16_grouped",
+           "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad"]
 
 
 def lib() -> C.CDLL:
@@ -75,6 +77,14 @@ def lib() -> C.CDLL:
     L.pbl_gemm_mfma_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
     L.pbl_gemv_f16_grouped.restype = C.c_int
     L.pbl_gemv_f16_grouped.argtypes = [vp, vp, vp, C.c_int, C.c_int, u32, u32, u32, u32, C.c_int, C.c_int, vp]
+    L.pbl_qat_workspace_bytes.restype = sz
+    L.pbl_qat_workspace_bytes.argtypes = []
+    L.pbl_qat_scale.restype = C.c_int
+    L.pbl_qat_scale.argtypes = [vp, C.c_int, vp, sz, vp, vp, vp]
+    L.pbl_qat_wsim.restype = C.c_int
+    L.pbl_qat_wsim.argtypes = [vp, C.c_int, vp, vp, C.c_float, vp, C.c_int, sz, vp]
+    L.pbl_qat_wgrad.restype = C.c_int
+    L.pbl_qat_wgrad.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_int, sz, vp]
     _lib = L
     return L
 

@@ -9,8 +9,9 @@ Mirrors /root/reference/quant/{quantizer,outlier_quantizer}.py:
                                    train_outlier=False)   quant/outlier_quantizer.py:33-123
     BinaryXnorExceptOutliersLinearHessian   quant/outlier_quantizer.py:126-143
 and adds PBLinear.from_dense / from_quantizers for GPTQ-PB fake-quant weights
-(gptq_pb/gptq.py:155,180-184).  Forward is inference-only (no autograd); there is
-no CPU fallback: a CPU tensor raises.
+(gptq_pb/gptq.py:155,180-184).  eval(): the packed HIP path (no autograd).  train(): the QAT step with the
+reference's straight-through gradients (pb_llm_amd/qat.py; fused HIP kernels for the weight-side
+elementwise work, library GEMMs).  There is no CPU fallback: a CPU tensor raises.
 """
 from __future__ import annotations
 
@@ -22,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .qat import STEBinary, qat_linear
 from .packing import PackedWeight, infer_code_grid, infer_levels, pack_dense
 
 
@@ -250,7 +252,18 @@ class _DenseBacked(nn.Module, BinaryInterface):
     def _bias_f32(self, device):
         return self.bias.detach().float().to(device) if self.bias is not None else None
 
+    def _train_weight(self):
+        """dense simulated weight WITH the reference's autograd graph (straight-through estimator)"""
+        raise NotImplementedError
+
     def forward(self, x):
+        if self.training:
+            # QAT step: the weights change every step, so nothing is packed; the dense simulated weight is
+            # built on the GPU with the straight-through estimator and a library GEMM runs on it
+            if not x.is_cuda:
+                raise _lib.PblError("PB linear forward needs a GPU tensor: there is no CPU path")
+            self.invalidate()
+            return torch.nn.functional.linear(x, self._train_weight(), self.bias)
         dd = torch.float16 if self.weight.dtype == torch.float16 else torch.float32
         return pb_linear_forward(self._packed_on(x.device), self._bias_f32(x.device), x, dense_dtype=dd)
 
@@ -266,6 +279,9 @@ class BinaryLinear(_DenseBacked):
 
     def quant_weight(self):
         return self.weight.detach().sign()
+
+    def _train_weight(self):
+        return STEBinary.apply(self.weight)                       # quant/quantizer.py:84-85
 
     def _pack(self):
         w = self.quant_weight().cpu()
@@ -289,6 +305,10 @@ class XnorBinaryLinear(_DenseBacked):
             w = w * (~outlier_mask)
         scaling_factor = w.abs().mean(-1).view(-1, 1)
         return w.sign() * scaling_factor
+
+    def _train_weight(self):                                      # quant/quantizer.py:181-189
+        w = self.weight - self.weight.mean(-1).view(-1, 1)
+        return STEBinary.apply(w) * w.abs().mean(-1).view(-1, 1).detach()
 
     def _pack(self):
         w = self.weight.detach().cpu()
@@ -394,7 +414,13 @@ class BinaryXnorExceptOutliersLinear(_DenseBacked):
         if self.outlier_mask is None:
             self.gen_outlier_mask()
         if self.training:
-            self._refresh_scale()
+            # QAT step (quant/outlier_quantizer.py:83-106): fused HIP kernels for binary_scale / w_sim / the
+            # straight-through weight gradient, library GEMMs; binary_scale is refreshed from the current
+            # weights without a host sync and persists into later eval() like the reference's
+            y, s = qat_linear(x, self.weight, self.bias, self.outlier_mask, self.outlier_scale, self.train_outlier)
+            self.binary_scale = s.to(self.weight.dtype).view(1, 1)
+            self.invalidate()
+            return y
         return super().forward(x)
 
     def to_regular_linear(self):

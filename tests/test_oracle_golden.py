@@ -206,3 +206,36 @@ def test_g6_llama7b_qproj_rtn_hashes():
     assert O.parity_errors(g["y_f32"], y)[0] < 1e-5
     if sha(W16) != str(g["W_fq_sha"]):               # allow a handful of 1-ulp flips
         np.testing.assert_allclose(r["scale"], g["scale"], rtol=3e-6)
+
+
+# ---------------------------------------------------------------- G8: one QAT training step
+def _g8():
+    g = golden("g8_qat_step")
+    return g, lambda tag: np.unpackbits(g[f"mask_{tag}"])[:96 * 320].reshape(96, 320).astype(bool)
+
+
+def _relmax(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("tag,kw", [("base", {}), ("train_outlier", dict(train_outlier=True, outlier_scale=0.5))])
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_g8_qat_step_oracle_matches_reference(tag, kw, mode):
+    """oracle.pb_qat_step == the reference module's forward + autograd backward (imported, CPU).
+    bf16: the reference's outputs are themselves rounded to bf16 (2^-9), hence 1e-2."""
+    g, mask = _g8()
+    r = O.pb_qat_step(g["x"], g["dy"], g[f"w_hat_{tag}"], mask(tag), g["b"], gemm_bf16=mode == "bf16", **kw)
+    tol = 2e-6 if mode == "f32" else 1e-2
+    for k in ("y", "dx", "dW", "db"):
+        assert _relmax(r[k], g[f"{k}_{tag}_{mode}"]) < tol, k
+    assert np.float32(r["binary_scale"].reshape(())) == np.float32(g[f"binary_scale_{tag}_{mode}"].reshape(()))
+    if not kw:   # salient weights get no gradient unless train_outlier
+        assert not g[f"dW_{tag}_{mode}"][mask(tag)].any()
+
+
+@pytest.mark.parametrize("tag", ["binary", "xnor"])
+def test_g8_ste_linear_step_oracle_matches_reference(tag):
+    g, _ = _g8()
+    r = O.ste_linear_step(g["x"], g["dy"], g["W"], g["b"], xnor=tag == "xnor")
+    for k in ("y", "dx", "dW", "db"):
+        assert _relmax(r[k], g[f"{k}_{tag}"]) < 2e-6, k

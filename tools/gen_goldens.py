@@ -220,7 +220,50 @@ def g7(out):
     big_rtn(out, "g7_llama13b_ffn_5120x13824_lf0.8", 5120, 13824, 0.8, 32, seed=8)
 
 
-ALL = dict(G1=g1_g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7)
+def g8(out):
+    """One QAT training step (forward + backward) through the reference modules on CPU:
+    BinaryXnorExceptOutliersLinear (train_outlier False / True, outlier_scale 1 / 0.5, fp32 and bf16-autocast),
+    BinaryLinear and XnorBinaryLinear (straight-through estimator)."""
+    N, K, M = 96, 320, 5
+    W = synth.llm_weight(N, K, seed=8, heavy_tail=True)
+    W[3, 11] = 0.0
+    b = synth.normal((N,), 8, 3, 0.1)
+    x = synth.normal((2, M, K), 8, 5, 1.0)
+    dy = synth.normal((2, M, N), 8, 6, 1.0)
+    res = dict(W=W, b=b, x=x, dy=dy)
+    for tag, kw in (("base", {}), ("train_outlier", dict(train_outlier=True, outlier_scale=0.5))):
+        m = quant.BinaryXnorExceptOutliersLinear(T(W), T(b), 0.1, **kw)
+        m.train()
+        with quiet():
+            m.gen_outlier_mask()
+        res[f"mask_{tag}"] = np.packbits(m.outlier_mask.numpy())
+        res[f"w_hat_{tag}"] = m.weight.data.numpy().copy()
+        for mode in ("f32", "bf16"):
+            m.zero_grad()
+            xt = T(x).clone().requires_grad_(True)
+            ctx = torch.autocast("cpu", dtype=torch.bfloat16) if mode == "bf16" else contextlib.nullcontext()
+            with ctx:
+                y = m(xt)
+            y.backward(T(dy).to(y.dtype))
+            res[f"y_{tag}_{mode}"] = y.detach().float().numpy()
+            res[f"dW_{tag}_{mode}"] = m.weight.grad.float().numpy().copy()
+            res[f"db_{tag}_{mode}"] = m.bias.grad.float().numpy().copy()
+            res[f"dx_{tag}_{mode}"] = xt.grad.float().numpy().copy()
+            res[f"binary_scale_{tag}_{mode}"] = m.binary_scale.float().numpy()
+    for tag, cls in (("binary", quant.BinaryLinear), ("xnor", quant.XnorBinaryLinear)):
+        m = cls(T(W), T(b))
+        m.train()
+        xt = T(x).clone().requires_grad_(True)
+        y = m(xt)
+        y.backward(T(dy))
+        res[f"y_{tag}"] = y.detach().numpy()
+        res[f"dW_{tag}"] = m.weight.grad.numpy().copy()
+        res[f"db_{tag}"] = m.bias.grad.numpy().copy()
+        res[f"dx_{tag}"] = xt.grad.numpy().copy()
+    save(out, "g8_qat_step", **res)
+
+
+ALL = dict(G1=g1_g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
