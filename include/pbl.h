@@ -246,6 +246,21 @@ int pbl_qat_wsim(const void* W, int w_dtype, const uint8_t* mask, const float* s
 int pbl_qat_wgrad(void* g, int g_dtype, const uint8_t* mask, const float* scale, float outlier_scale, int train_outlier,
                   size_t n, void* stream);
 
+/* ---------------- producer side: salient selection and the 8-bit row quantizer -------------------- */
+/* BinaryXnorExceptOutliersLinear.gen_outlier_mask (quant/outlier_quantizer.py:54-81) on the device, bit-identical
+ * to the reference's CPU arithmetic.  W: device, n = N*K elements, dtype PBL_DTYPE_*; everything stays on `stream`. */
+size_t pbl_prep_workspace_bytes(void);
+/* out2[0] = k_lo-th smallest, out2[1] = k_hi-th smallest element of W (1-based ranks, torch.kthvalue :57-66),
+ * as DEVICE floats.  Exact: 3-pass radix select over order-preserving keys.  k outside [1, n] -> INVALID_ARG
+ * (torch raises).  workspace: pbl_prep_workspace_bytes() device bytes, 16-B aligned. */
+int pbl_kth_pair(const void* W, int w_dtype, size_t n, uint64_t k_lo, uint64_t k_hi, void* workspace, float* out2, void* stream);
+/* mask_out[i] = (W[i] < thr2[0]) | (W[i] > thr2[1])   (strict, :69); one byte per element (torch.bool layout). */
+int pbl_outlier_mask(const void* W, int w_dtype, size_t n, const float* thr2, uint8_t* mask_out, void* stream);
+/* weight_quant_8bit(W, simulated=True) IN PLACE, per row of W[N,K] (quant/outlier_quantizer.py:10-29: integer-rounded
+ * zero point, wrapping uint8 cast, arithmetic in the reference's dtypes and order).  code_scale[r] = range_r / 255 and
+ * code_zp[r] = zero point: W_hat[r,j] = code * code_scale[r] + code_zp[r] with an integer code 0..255.  K <= 16384. */
+int pbl_quant8_rows(void* W, int w_dtype, uint32_t N, uint32_t K, float* code_scale, float* code_zp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,7 +43,8 @@ _lib = None
 
 EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_blob_describe",
            "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemm_mfma_f16", "pbl_gemv_f16_grouped",
-           "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad"]
+           "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad",
+           "pbl_prep_workspace_bytes", "pbl_kth_pair", "pbl_outlier_mask", "pbl_quant8_rows"]
 
 
 def lib() -> C.CDLL:
@@ -85,6 +86,14 @@ def lib() -> C.CDLL:
     L.pbl_qat_wsim.argtypes = [vp, C.c_int, vp, vp, C.c_float, vp, C.c_int, sz, vp]
     L.pbl_qat_wgrad.restype = C.c_int
     L.pbl_qat_wgrad.argtypes = [vp, C.c_int, vp, vp, C.c_float, C.c_int, sz, vp]
+    L.pbl_prep_workspace_bytes.restype = sz
+    L.pbl_prep_workspace_bytes.argtypes = []
+    L.pbl_kth_pair.restype = C.c_int
+    L.pbl_kth_pair.argtypes = [vp, C.c_int, sz, C.c_uint64, C.c_uint64, vp, vp, vp]
+    L.pbl_outlier_mask.restype = C.c_int
+    L.pbl_outlier_mask.argtypes = [vp, C.c_int, sz, vp, vp, vp]
+    L.pbl_quant8_rows.restype = C.c_int
+    L.pbl_quant8_rows.argtypes = [vp, C.c_int, u32, u32, vp, vp, vp]
     _lib = L
     return L
 

@@ -365,12 +365,21 @@ class BinaryXnorExceptOutliersLinear(_DenseBacked):
     def gen_outlier_mask(self):
         with torch.no_grad():
             w = self.weight
-            w_flat = w.view(-1)
-            lower = torch.kthvalue(w_flat, int(w_flat.numel() * self.outlier_fraction / 2))[0]
-            upper = torch.kthvalue(w_flat, int(w_flat.numel() * (1 - self.outlier_fraction / 2)))[0]
-            self.outlier_mask = ((w < lower) | (w > upper)).detach()
-            self.binary_scale = w[~self.outlier_mask].abs().mean(-1).view(-1, 1).detach()
-            self._quantize_weights_8bit()
+            if w.is_cuda:
+                # on the device: exact radix select for the two thresholds, mask, binary_scale and the row
+                # quantizer as HIP kernels (pb_llm_amd/prep.py), bit-identical to the host path below
+                from .prep import gen_outlier_mask_magnitude_
+                data = w.data.contiguous()
+                self.outlier_mask, self.binary_scale, self._code_scale, self._code_zp = \
+                    gen_outlier_mask_magnitude_(data, self.outlier_fraction)
+                self.weight.data = data
+            else:
+                w_flat = w.view(-1)
+                lower = torch.kthvalue(w_flat, int(w_flat.numel() * self.outlier_fraction / 2))[0]
+                upper = torch.kthvalue(w_flat, int(w_flat.numel() * (1 - self.outlier_fraction / 2)))[0]
+                self.outlier_mask = ((w < lower) | (w > upper)).detach()
+                self.binary_scale = w[~self.outlier_mask].abs().mean(-1).view(-1, 1).detach()
+                self._quantize_weights_8bit()
             self.calc_memory_consumption()
             self.invalidate()
 

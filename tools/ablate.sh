@@ -2,7 +2,7 @@
 # Build ablated variants of libpbl.so (performance analysis only) and bench each.
 # usage (on the GPU box): tools/ablate.sh [bench args]
 set -u
-SRC="pb_llm_amd/csrc/pbl_kernels.hip pb_llm_amd/csrc/pbl_gemm.hip pb_llm_amd/csrc/pbl_qat.hip pb_llm_amd/csrc/pbl_host.cpp"
+SRC="pb_llm_amd/csrc/pbl_kernels.hip pb_llm_amd/csrc/pbl_gemm.hip pb_llm_amd/csrc/pbl_qat.hip pb_llm_amd/csrc/pbl_prep.hip pb_llm_amd/csrc/pbl_host.cpp"
 cp pb_llm_amd/libpbl.so /tmp/libpbl_orig.so
 for A in 0 1 2; do
   /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -shared --offload-arch=gfx950 -DPBL_ABLATE=$A $SRC -o pb_llm_amd/libpbl.so 2>/dev/null

@@ -3,7 +3,7 @@
 #   tools/ablate_mfma.sh build "0 2 64 ..."   here (no GPU): builds pb_llm_amd/_ablate/libpbl_<A>.so
 #   tools/ablate_mfma.sh run                  on the GPU box: times every prebuilt variant
 set -u
-SRC="pb_llm_amd/csrc/pbl_kernels.hip pb_llm_amd/csrc/pbl_gemm.hip pb_llm_amd/csrc/pbl_qat.hip pb_llm_amd/csrc/pbl_host.cpp"
+SRC="pb_llm_amd/csrc/pbl_kernels.hip pb_llm_amd/csrc/pbl_gemm.hip pb_llm_amd/csrc/pbl_qat.hip pb_llm_amd/csrc/pbl_prep.hip pb_llm_amd/csrc/pbl_host.cpp"
 D=pb_llm_amd/_ablate
 if [ "${1:-run}" = build ]; then
   rm -rf $D; mkdir -p $D

@@ -1,7 +1,7 @@
 #!/bin/bash
 # FETCH_SIZE of the grouped GEMV at 4 vs 8 waves per workgroup (x staged once per workgroup)
 export TMPDIR=/tmp
-SRC="pb_llm_amd/csrc/pbl_kernels.hip pb_llm_amd/csrc/pbl_gemm.hip pb_llm_amd/csrc/pbl_qat.hip pb_llm_amd/csrc/pbl_host.cpp"
+SRC="pb_llm_amd/csrc/pbl_kernels.hip pb_llm_amd/csrc/pbl_gemm.hip pb_llm_amd/csrc/pbl_qat.hip pb_llm_amd/csrc/pbl_prep.hip pb_llm_amd/csrc/pbl_host.cpp"
 cp pb_llm_amd/libpbl.so /tmp/libpbl_orig.so
 for W in 4 8; do
   /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -shared --offload-arch=gfx950 -DPBL_GROUPED_WPB=$W $SRC -o pb_llm_amd/libpbl.so 2>/dev/null

@@ -1,5 +1,5 @@
 #!/bin/bash
-SRC="pb_llm_amd/csrc/pbl_kernels.hip pb_llm_amd/csrc/pbl_gemm.hip pb_llm_amd/csrc/pbl_qat.hip pb_llm_amd/csrc/pbl_host.cpp"
+SRC="pb_llm_amd/csrc/pbl_kernels.hip pb_llm_amd/csrc/pbl_gemm.hip pb_llm_amd/csrc/pbl_qat.hip pb_llm_amd/csrc/pbl_prep.hip pb_llm_amd/csrc/pbl_host.cpp"
 cp pb_llm_amd/libpbl.so /tmp/libpbl_orig.so
 for W in 4 5 6 7 8; do
   /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -shared --offload-arch=gfx950 -DPBL_MIN_WAVES=$W $SRC -o pb_llm_amd/libpbl.so -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A6 "ILi1ELi4E" | grep -E "VGPRs:|Scratch" | tr '\n' ' '
