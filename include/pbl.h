@@ -261,6 +261,22 @@ int pbl_outlier_mask(const void* W, int w_dtype, size_t n, const float* thr2, ui
  * code_zp[r] = zero point: W_hat[r,j] = code * code_scale[r] + code_zp[r] with an integer code 0..255.  K <= 16384. */
 int pbl_quant8_rows(void* W, int w_dtype, uint32_t N, uint32_t K, float* code_scale, float* code_zp, void* stream);
 
+/* HighQuantizer.calibrate(weight=True) as gptq_pb/run.py:132-137 configures it (per channel, asymmetric, no mse
+ * search; gptq_pb/high_quant.py:29-67,95-102): scale[r] = (max(row,0) - min(row,0)) / maxq, zero[r] = round(-min/scale),
+ * correctly rounded (bit-identical to the reference on the host).  W [N,K] fp32 device. */
+int pbl_high_calibrate(const float* W, uint32_t N, uint32_t K, float maxq, float* scale, float* zero, void* stream);
+
+/* One 128-column block of LowHighGPT.fasterquant's column loop (gptq_pb/gptq.py:129-168), all rows in one launch.
+ * W [N,K] fp32 (columns c0 .. c0+ncols are read, then overwritten with their quantised values); U [K,K] fp32 = upper
+ * Cholesky factor of H^-1 (:76-81); low_mask [N,K] bytes, nonzero = binarized (:83-99); hscale/hzero [N], maxq: the
+ * HighQuantizer (high_quant.py:6-8); mean/scale [N]: the LowQuantizer row parameters of the block's group
+ * (low_quant.py:25-32,75-82); err_out [N,128] receives Err1 (zero padded) for the caller's trailing update
+ * W[:, c0+ncols:] -= Err1 @ U[c0:c0+ncols, c0+ncols:] (a library GEMM); losses [N] += sum_i (w-q)^2/d^2 / 2.
+ * feedback == 0: round-to-nearest branch (:119-127), no error propagation.  ncols <= 128. */
+int pbl_gptq_block(float* W, uint32_t N, uint32_t K, uint32_t c0, uint32_t ncols, const float* U, const uint8_t* low_mask,
+                   const float* hscale, const float* hzero, float maxq, const float* mean, const float* scale,
+                   float* err_out, float* losses, int feedback, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

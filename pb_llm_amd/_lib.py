@@ -44,7 +44,7 @@ _lib = None
 EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_blob_describe",
            "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemm_mfma_f16", "pbl_gemv_f16_grouped",
            "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad",
-           "pbl_prep_workspace_bytes", "pbl_kth_pair", "pbl_outlier_mask", "pbl_quant8_rows"]
+           "pbl_prep_workspace_bytes", "pbl_kth_pair", "pbl_outlier_mask", "pbl_quant8_rows", "pbl_high_calibrate", "pbl_gptq_block"]
 
 
 def lib() -> C.CDLL:
@@ -94,6 +94,10 @@ def lib() -> C.CDLL:
     L.pbl_outlier_mask.argtypes = [vp, C.c_int, sz, vp, vp, vp]
     L.pbl_quant8_rows.restype = C.c_int
     L.pbl_quant8_rows.argtypes = [vp, C.c_int, u32, u32, vp, vp, vp]
+    L.pbl_high_calibrate.restype = C.c_int
+    L.pbl_high_calibrate.argtypes = [vp, u32, u32, C.c_float, vp, vp, vp]
+    L.pbl_gptq_block.restype = C.c_int
+    L.pbl_gptq_block.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, C.c_int, vp]
     _lib = L
     return L
 

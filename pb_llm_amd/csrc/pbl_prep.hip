@@ -164,6 +164,95 @@ __global__ __launch_bounds__(PT) void quant8_rows_kernel(T* __restrict__ W, uint
     }
 }
 
+// ---- GPTQ-PB column block (gptq_pb/gptq.py:129-168) -------------------------------------------------
+// The reference walks the K columns in a Python loop, ~15 small torch launches per column.  Rows are independent
+// inside a 128-column block, so here ONE launch processes a whole block: a wave owns a row, lane l holds columns
+// l and l + 64 of the row's block in registers, the 128 x 128 block of the upper Cholesky factor of H^-1 sits in
+// LDS, and the column recurrence runs 128 wave-uniform steps (v_readlane for the pivot column):
+//   q    = mask ? sign(w - mean) * scale + mean : hscale * (clamp(rint(w / hscale) + hzero, 0, maxq) - hzero)
+//   err  = (w - q) / d;   loss += (w - q)^2 / d^2;   W1[:, j >= i] -= err * U1[i, j]
+// in fp32 with the reference's unfused roundings.  Outputs: the block's quantised columns (into W), Err1 (for the
+// trailing library GEMM  W[:, c1:] -= Err1 @ U[c0:c1, c1:]), per-row loss.  feedback == 0 is the RTN branch (:119-127).
+constexpr int GB = 128;     // block size (gptq.py blocksize default)
+
+__global__ __launch_bounds__(PT) void gptq_block_kernel(float* __restrict__ W, uint32_t N, uint32_t K, uint32_t c0, uint32_t nb,
+                                                         const float* __restrict__ U, const uint8_t* __restrict__ low_mask,
+                                                         const float* __restrict__ hscale, const float* __restrict__ hzero, float maxq,
+                                                         const float* __restrict__ mean, const float* __restrict__ scale,
+                                                         float* __restrict__ Err, float* __restrict__ losses, int feedback) {
+    extern __shared__ float U1[];                   // [GB][GB], rows/cols beyond nb are zero
+    for (uint32_t t = threadIdx.x; t < GB * GB; t += PT) {
+        const uint32_t i = t / GB, j = t % GB;
+        U1[t] = (i < nb && j < nb) ? U[size_t(c0 + i) * K + c0 + j] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * (PT / 64) + (threadIdx.x >> 6);
+    if (r >= N) return;
+    float* wrow = W + size_t(r) * K + c0;
+    const uint8_t* mrow = low_mask + size_t(r) * K + c0;
+    const bool in0 = uint32_t(lane) < nb, in1 = uint32_t(lane) + 64 < nb;
+    float w0 = in0 ? wrow[lane] : 0.f, w1 = in1 ? wrow[lane + 64] : 0.f;
+    const int m0 = in0 ? mrow[lane] : 0, m1 = in1 ? mrow[lane + 64] : 0;
+    const float hs = hscale[r], hz = hzero[r], mu = mean[r], sc = scale[r];
+    float q0 = 0.f, q1 = 0.f, e0 = 0.f, e1 = 0.f, loss = 0.f;
+    for (uint32_t i = 0; i < nb; ++i) {
+        const int li = int(i & 63);
+        const bool hi_half = i >= 64;
+        const float wi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hi_half ? w1 : w0), li));
+        const int mi = __builtin_amdgcn_readlane(hi_half ? m1 : m0, li);
+        const float d = U1[i * GB + i];
+        const float qh = hs * (fminf(fmaxf(rintf(wi / hs) + hz, 0.f), maxq) - hz);          // high_quant.py:6-8
+        const float t = wi - mu;
+        const float sg = t > 0.f ? 1.f : (t < 0.f ? -1.f : 0.f);
+        const float ql = unfused(sg * sc) + mu;                                              // low_quant.py:75-82
+        const float q = mi ? ql : qh;
+        const float diff = wi - q;
+        const float err = diff / d;
+        loss += unfused(diff * diff) / unfused(d * d);                                       // gptq.py:155
+        if (feedback) {                                                                      // gptq.py:159
+            const float u0 = U1[i * GB + lane], u1 = U1[i * GB + 64 + lane];
+            if (!hi_half && lane >= li) w0 -= unfused(err * u0);
+            if (!hi_half || lane >= li) w1 -= unfused(err * u1);
+        }
+        if (lane == li) {
+            if (hi_half) { q1 = q; e1 = err; } else { q0 = q; e0 = err; }
+        }
+    }
+    if (in0) { wrow[lane] = q0; Err[size_t(r) * GB + lane] = e0; }
+    if (in1) { wrow[lane + 64] = q1; Err[size_t(r) * GB + lane + 64] = e1; }
+    if (!in0) Err[size_t(r) * GB + lane] = 0.f;
+    if (!in1) Err[size_t(r) * GB + lane + 64] = 0.f;
+    if (lane == 0) losses[r] += loss * 0.5f;                                                 // gptq.py:164
+}
+
+// HighQuantizer.calibrate(weight=True), per channel, asymmetric, no mse search (gptq_pb/high_quant.py:29-67,95-102):
+// xmin = min(row, 0), xmax = max(row, 0) (both 0 -> -1/+1), scale = (xmax - xmin) / maxq, zero = round(-xmin / scale).
+// One workgroup per row; correctly rounded divisions (torch's GPU division is not, and the codes depend on it).
+__global__ __launch_bounds__(PT) void high_calibrate_kernel(const float* __restrict__ W, uint32_t K, float maxq,
+                                                             float* __restrict__ scale, float* __restrict__ zero) {
+    __shared__ float smin[PT], smax[PT];
+    const float* wr = W + size_t(blockIdx.x) * K;
+    float mn = 0.f, mx = 0.f;
+    for (uint32_t j = threadIdx.x; j < K; j += PT) { const float v = wr[j]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    smin[threadIdx.x] = mn; smax[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = PT / 2; s > 0; s >>= 1) {
+        if (int(threadIdx.x) < s) {
+            smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
+            smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float xmin = smin[0], xmax = smax[0];
+        if (xmin == 0.f && xmax == 0.f) { xmin = -1.f; xmax = 1.f; }
+        const float sc = (xmax - xmin) / maxq;
+        scale[blockIdx.x] = sc;
+        zero[blockIdx.x] = rintf(-xmin / sc);
+    }
+}
+
 inline int launch(const void* k, int grid, int lds, void** argv, void* stream) {
     return hipLaunchKernel(k, dim3(grid), dim3(PT), argv, size_t(lds), static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK
                                                                                                                           : PBL_ERR_LAUNCH;
@@ -224,6 +313,21 @@ int pbl_quant8_rows(void* W, int w_dtype, uint32_t N, uint32_t K, float* code_sc
     if (!k) return PBL_ERR_UNSUPPORTED;
     void* argv[] = {&W, &K, &code_scale, &code_zp};
     return launch(k, int(N), int(K) * 4, argv, stream);
+}
+
+int pbl_high_calibrate(const float* W, uint32_t N, uint32_t K, float maxq, float* scale, float* zero, void* stream) {
+    if (!W || !scale || !zero || !N || !K || !(maxq > 0.f)) return PBL_ERR_INVALID_ARG;
+    void* argv[] = {&W, &K, &maxq, &scale, &zero};
+    return launch(reinterpret_cast<const void*>(high_calibrate_kernel), int(N), 0, argv, stream);
+}
+
+int pbl_gptq_block(float* W, uint32_t N, uint32_t K, uint32_t c0, uint32_t ncols, const float* U, const uint8_t* low_mask,
+                   const float* hscale, const float* hzero, float maxq, const float* mean, const float* scale,
+                   float* err_out, float* losses, int feedback, void* stream) {
+    if (!W || !U || !low_mask || !hscale || !hzero || !mean || !scale || !err_out || !losses) return PBL_ERR_INVALID_ARG;
+    if (!N || !ncols || ncols > GB || c0 + ncols > K) return PBL_ERR_INVALID_ARG;
+    void* argv[] = {&W, &N, &K, &c0, &ncols, &U, &low_mask, &hscale, &hzero, &maxq, &mean, &scale, &err_out, &losses, &feedback};
+    return launch(reinterpret_cast<const void*>(gptq_block_kernel), int((N + PT / 64 - 1) / (PT / 64)), GB * GB * 4, argv, stream);
 }
 
 }  // extern "C"
