@@ -135,3 +135,42 @@ def test_ptq_argument_errors():
         ptq.LowHighGPTQ(layer, groupsize=96)
     with pytest.raises(Exception):
         ptq.LowHighGPTQ(nn.Linear(8, 8))                # CPU layer: no host path
+
+
+def test_quant_sequential_tiny_llama_on_gpu():
+    """gptq_pb/run.py's quant_sequential counterpart on a random-init HF LLaMA (2 layers, hidden 256): every decoder Linear
+    goes through the GPU GPTQ-PB pipeline with its own calibration Hessian; GPTQ lowers the quantisation damage on the
+    calibration tokens relative to round-to-nearest; pack=True yields the same logits through the packed kernels."""
+    import copy
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from pb_llm_amd import harness as H
+    from pb_llm_amd import quant as Q
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=4, vocab_size=500, max_position_embeddings=128)
+    base = LlamaForCausalLM(cfg).half().eval().to(DEV)
+    ids = [torch.from_numpy((synth.uniform01(64, 7, s) * 500).astype(np.int64)).view(1, -1) for s in range(4)]
+    with torch.no_grad():
+        ref = torch.cat([base(i.to(DEV)).logits.float() for i in ids])
+
+    def damage(m):
+        with torch.no_grad():
+            out = torch.cat([m(i.to(DEV)).logits.float() for i in ids])
+        return float((out - ref).norm() / ref.norm())
+
+    m_gptq, m_rtn, m_pack = copy.deepcopy(base), copy.deepcopy(base), copy.deepcopy(base)
+    e = H.quant_sequential_(m_gptq, ids, 0.9, "hessian")
+    assert len(e) == 14 and all(np.isfinite(v) and v > 0 for v in e.values())
+    H.quant_sequential_(m_rtn, ids, 0.9, "hessian", disable_gptq=True)
+    d_gptq, d_rtn = damage(m_gptq), damage(m_rtn)
+    assert 0 < d_gptq < d_rtn, (d_gptq, d_rtn)
+    # every quantised weight row is two-valued off the salient set (spot check) and lm_head is untouched
+    w = m_gptq.model.layers[0].mlp.down_proj.weight.data.float().cpu().numpy()
+    assert torch.equal(m_gptq.lm_head.weight, base.lm_head.weight)
+    assert len(np.unique(w[0])) <= 3 + int(0.1 * w.shape[1] * 3)
+    H.quant_sequential_(m_pack, ids, 0.9, "hessian", pack=True)
+    assert sum(isinstance(x, Q.PBLinear) for x in m_pack.modules()) == 14
+    with torch.no_grad():
+        a = torch.cat([m_pack(i.to(DEV)).logits.float() for i in ids]).cpu().numpy()
+        b = torch.cat([m_gptq(i.to(DEV)).logits.float() for i in ids]).cpu().numpy()
+    assert O.parity_errors(a, b.astype(np.float64))[0] < 5e-3
