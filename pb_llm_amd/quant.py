@@ -256,12 +256,19 @@ class _DenseBacked(nn.Module, BinaryInterface):
         """dense simulated weight WITH the reference's autograd graph (straight-through estimator)"""
         raise NotImplementedError
 
+    def _is_training_step(self, x) -> bool:
+        """train() mode AND autograd is recording for the weight or the input; a train()-mode forward under
+        no_grad (evaluation loops that forget eval()) still takes the packed kernels"""
+        return self.training and torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad)
+
     def forward(self, x):
-        if self.training:
+        if x.shape[-1] != self.weight.shape[1]:
+            raise ValueError(f"in_features mismatch: x has {x.shape[-1]}, layer has {self.weight.shape[1]}")
+        if not x.is_cuda:
+            raise _lib.PblError("PB linear forward needs a GPU tensor: the HIP kernels are the only compute path")
+        if self._is_training_step(x):
             # QAT step: the weights change every step, so nothing is packed; the dense simulated weight is
             # built on the GPU with the straight-through estimator and a library GEMM runs on it
-            if not x.is_cuda:
-                raise _lib.PblError("PB linear forward needs a GPU tensor: there is no CPU path")
             self.invalidate()
             return torch.nn.functional.linear(x, self._train_weight(), self.bias)
         dd = torch.float16 if self.weight.dtype == torch.float16 else torch.float32
@@ -422,7 +429,7 @@ class BinaryXnorExceptOutliersLinear(_DenseBacked):
     def forward(self, x):
         if self.outlier_mask is None:
             self.gen_outlier_mask()
-        if self.training:
+        if self._is_training_step(x):
             # QAT step (quant/outlier_quantizer.py:83-106): fused HIP kernels for binary_scale / w_sim / the
             # straight-through weight gradient, library GEMMs; binary_scale is refreshed from the current
             # weights without a host sync and persists into later eval() like the reference's
@@ -430,6 +437,8 @@ class BinaryXnorExceptOutliersLinear(_DenseBacked):
             self.binary_scale = s.to(self.weight.dtype).view(1, 1)
             self.invalidate()
             return y
+        if self.training:
+            self._refresh_scale()           # train() without autograd: the scale refresh of :90-93, then the packed path
         return super().forward(x)
 
     def to_regular_linear(self):

@@ -44,12 +44,12 @@ def test_g1_binary_linear_gpu():
     b = synth.normal((768,), 1, 3, 0.1)
     x = synth.normal((2, 5, 768), 1, 5, 1.0)
     g = golden("g1_binary_linear")
-    m = Q.BinaryLinear(torch.from_numpy(W), torch.from_numpy(b)).to(DEV)
+    m = Q.BinaryLinear(torch.from_numpy(W), torch.from_numpy(b)).to(DEV).eval()     # eval(): the packed kernels
     y = m(T(x))
     assert y.shape == (2, 5, 768) and y.dtype == torch.float32
     assert_parity(y, g["y"], 2e-5)                       # fp32 module: split-x path
     assert_parity(y, O.binary_linear_forward(x, W, b), 2e-5)
-    m0 = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV)
+    m0 = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV).eval()
     assert_parity(m0(T(x)), g["y_nobias"], 2e-5)
     assert_parity(m0(T(x).half()), O.binary_linear_forward(x.astype(np.float16), W, None))
 
@@ -59,7 +59,7 @@ def test_g2_xnor_binary_linear_gpu():
     b = synth.normal((768,), 1, 3, 0.1)
     x = synth.normal((2, 5, 768), 1, 5, 1.0)
     g = golden("g2_xnor_binary_linear")
-    m = Q.XnorBinaryLinear(torch.from_numpy(W), torch.from_numpy(b)).to(DEV)
+    m = Q.XnorBinaryLinear(torch.from_numpy(W), torch.from_numpy(b)).to(DEV).eval()
     assert_parity(m(T(x)), g["y"], 2e-5)
 
 
@@ -223,7 +223,7 @@ def test_column_groups(N, K, gs, M, bias):
 def test_empty_batch_and_leading_dims():
     W = synth.llm_weight(32, 512, seed=9)
     s = np.sign(W).astype(np.float32)
-    m = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV)
+    m = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV).eval()
     assert m(torch.zeros(0, 512, device=DEV)).shape == (0, 32)
     x = synth.normal((2, 3, 4, 512), 9, 1)
     assert_parity(m(T(x)), O.dense_linear(x, s), 2e-5)
@@ -438,10 +438,12 @@ def test_hipgraph_capture_and_side_stream(llama7b_qproj):
 def test_misuse_raises():
     W = synth.llm_weight(16, 512, seed=1)
     m = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV)
-    with pytest.raises(ValueError):
-        m(torch.zeros(1, 100, device=DEV))
-    with pytest.raises(_lib.PblError):
-        m(torch.zeros(1, 512))
+    for mode in (m.train, m.eval):              # same errors on the training and on the packed path
+        mode()
+        with pytest.raises(ValueError):
+            m(torch.zeros(1, 100, device=DEV))
+        with pytest.raises(_lib.PblError):
+            m(torch.zeros(1, 512))
 
 
 # ---------------------------------------------------------------- model level (HF LLaMA, random init)
