@@ -124,6 +124,21 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     return (out if out_f32 else out.to(x.dtype)).reshape(*lead, packed.N)
 
 
+# The forward as a registered operator ("forward-only op ... with a Meta/fake impl so torch.compile /
+# graph capture work").  Eager module calls go straight to pb_linear_forward; inside a torch.compile region the module
+# emits `pbllm::linear`, whose fake implementation gives the tracer shapes and dtypes without touching the GPU.
+@torch.library.custom_op("pbllm::linear", mutates_args=())
+def _pbllm_linear(blob: torch.Tensor, bias: torch.Tensor | None, x: torch.Tensor, meta: list[int], dense_f16: bool,
+                  out_f32: bool) -> torch.Tensor:
+    return pb_linear_forward(PackedWeight(blob, *meta), bias, x, out_f32=out_f32,
+                             dense_dtype=torch.float16 if dense_f16 else torch.float32)
+
+
+@_pbllm_linear.register_fake
+def _(blob, bias, x, meta, dense_f16, out_f32):
+    return x.new_empty((*x.shape[:-1], meta[0]), dtype=torch.float32 if out_f32 else x.dtype)
+
+
 class PBLinear(nn.Module, BinaryInterface):
     """Packed partially-binarized linear layer.  Holds the PBL1 blob as a buffer so
     .to(device) / state_dict() work; `weight` is a dense view materialised on demand."""
@@ -208,6 +223,11 @@ class PBLinear(nn.Module, BinaryInterface):
         return self.pbl_bias
 
     def forward(self, x):
+        if torch.compiler.is_compiling():
+            m = self._meta
+            return torch.ops.pbllm.linear(self.pbl_blob, self.pbl_bias, x,
+                                          [m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch, m.max_nexc, m.nnz, m.nexc],
+                                          self.weight_dtype == torch.float16, False)
         dd = torch.float16 if self.weight_dtype == torch.float16 else torch.float32
         return pb_linear_forward(self.packed, self.pbl_bias, x, dense_dtype=dd)
 

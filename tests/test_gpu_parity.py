@@ -489,3 +489,33 @@ def test_llama_model_forward_with_pb_linears():
         out = flat(ids[:, :5]).logits.float().cpu().numpy()
         ref5 = dense(ids[:, :5]).logits.float().cpu().numpy()
     assert O.parity_errors(out, ref5)[0] < 5e-3
+
+
+def test_torch_compile_traces_pbllm_linear_op(llama7b_qproj):
+    """inside torch.compile the module emits the registered op pbllm::linear (fake impl for tracing, HIP kernels at run
+    time); fullgraph=True proves there is no graph break.  backend aot_eager: no code generator involved."""
+    W, mask, r = llama7b_qproj
+    lin = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+
+    class Block(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.proj = lin
+
+        def forward(self, x):
+            return torch.nn.functional.silu(self.proj(x)) + 1.0
+
+    blk = Block().eval()
+    seen = []
+
+    def backend(gm, example_inputs):
+        seen.extend(str(n.target) for n in gm.graph.nodes if n.op == "call_function")
+        return gm.forward
+
+    x = T(synth.activations((3, 4096), 5, 21))
+    with torch.no_grad():
+        eager = blk(x)
+        out = torch.compile(blk, backend=backend, fullgraph=True)(x)
+        out2 = torch.compile(blk, backend="aot_eager", fullgraph=True)(x)
+    assert any("pbllm.linear" in t for t in seen), seen
+    assert torch.equal(out, eager) and torch.equal(out2, eager)

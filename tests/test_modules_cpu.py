@@ -111,3 +111,24 @@ def test_replace_save_load_roundtrip(tmp_path):
     assert "q_proj.pbl_blob" in sd and sd["q_proj.pbl_blob"].dtype == torch.uint8
     with pytest.raises(KeyError):
         pbio.load_pb(nn.Sequential(nn.Linear(4, 4)), str(tmp_path / "ckpt"))
+
+
+def test_pbllm_linear_op_fake_impl_gives_shapes_without_a_gpu():
+    """pbllm::linear has a fake (meta) implementation: tracing / torch.compile can infer shapes and dtypes with no GPU;
+    the REAL implementation still refuses host tensors (no CPU compute path)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from pb_llm_amd import _lib
+    W = synth.llm_weight(32, 512, seed=3)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    layer = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
+    m = layer._meta
+    meta = [m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch, m.max_nexc, m.nnz, m.nexc]
+    with FakeTensorMode() as mode:
+        blob = mode.from_tensor(layer.pbl_blob)
+        x = mode.from_tensor(torch.zeros(2, 7, m.K, dtype=torch.float16))
+        y = torch.ops.pbllm.linear(blob, None, x, meta, True, False)
+        assert tuple(y.shape) == (2, 7, m.N) and y.dtype == torch.float16
+        assert torch.ops.pbllm.linear(blob, None, x, meta, True, True).dtype == torch.float32
+    with pytest.raises(_lib.PblError):
+        torch.ops.pbllm.linear(layer.pbl_blob, None, torch.zeros(1, m.K, dtype=torch.float16), meta, True, False)
