@@ -3,8 +3,8 @@
 // 32 tokens (batched decode, short prefill: BASELINE config 4).  Replaces F.linear(x, W_fq, b) of the
 // reference (quant/outlier_quantizer.py:105, gptq_pb/eval_ppl_utils.py:59-60).  Any layer with G == 1.
 //
-// One workgroup (4 waves) owns one 16-row record; its panels are split over the waves and the
-// four partial accumulators are combined at the end in a fixed order.  The record's salient
+// One workgroup (2 waves when the layer has >= 512 records, else 4) owns one 16-row record; its panels are
+// split over the waves and the partial accumulators are combined at the end in a fixed order.  The record's salient
 // chunks are first counting-sorted by 256-column half panel (LDS, whole workgroup), so a half panel
 // touches only its own chunks.  Per half panel, a wave
 //   * copies its half of the 1 KiB sign-plane tile to LDS twice (Wp: as is, and shifted left 8 for rows 8..15);
@@ -70,8 +70,8 @@ __host__ __device__ inline size_t mfma_shared_bytes(int NH, int list_cap, int ma
     return size_t(256) + 128 + ((size_t(max_nch) + 15) & ~size_t(15)) + size_t(2 * (NH + 1)) * 4 + ((size_t(list_cap) * 2 + 15) & ~size_t(15));
 }
 
-template <int NTB, bool SF>
-__global__ __launch_bounds__(4 * GW) void pbl_mfma_kernel(pbl_layer L, const _Float16* __restrict__ x,
+template <int NTB, bool SF, int WPG>
+__global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(pbl_layer L, const _Float16* __restrict__ x,
                                                             void* __restrict__ yv, int M, int y_f32, int list_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(4 * GW) void pbl_mfma_kernel(pbl_layer L, const _Fl
     uint8_t* Mt = reinterpret_cast<uint8_t*>(St + 16 * SSTR);
     uint32_t* Wp = reinterpret_cast<uint32_t*>(Mt + 16 * SSTR);
     uint32_t* Wp8 = Wp + 128;
-    char* shared = smem_g + 4 * MFMA_WAVE_BYTES;
+    char* shared = smem_g + WPG * MFMA_WAVE_BYTES;
     float4* prm = reinterpret_cast<float4*>(shared);                        // [16] {hi, lo, sscale, szero}
     int* rinf = reinterpret_cast<int*>(shared + 256);                       // [16] first full chunk, [16] first tail chunk of each row
     uint8_t* crow_l = reinterpret_cast<uint8_t*>(shared + 384);             // [nch] row of each chunk
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(4 * GW) void pbl_mfma_kernel(pbl_layer L, const _Fl
     uint16_t* span = reinterpret_cast<uint16_t*>(smem_g);                   // [nch] first panel | last panel << 8
 
     // this wave's panels [p_lo, p_hi) -> sub-blocks [b_lo, b_hi); first tile / x loads go out before the sort
-    const int Pq = (P + 3) / 4;
+    const int Pq = (P + WPG - 1) / WPG;
     const int p_lo = min(wave * Pq, P), p_hi = min(p_lo + Pq, P);
     const int b_hi = min(4 * p_hi, NB);
     const int h_lo = 2 * p_lo, h_hi = min(2 * p_hi, NH);
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(4 * GW) void pbl_mfma_kernel(pbl_layer L, const _Fl
     if (p_lo < p_hi) t_cur = __builtin_nontemporal_load(tiles + p_lo * 64);
 
     // ---- one-time, whole workgroup: counting-sort the salient chunks by panel ----
-    for (int i = tid; i < 2 * (NH + 1); i += 4 * GW) bstart[i] = 0;
+    for (int i = tid; i < 2 * (NH + 1); i += WPG * GW) bstart[i] = 0;
     if (tid < 16) {
         prm[tid] = reinterpret_cast<const float4*>(params)[tid];
         rinf[tid] = int(rinfo[tid].start);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(4 * GW) void pbl_mfma_kernel(pbl_layer L, const _Fl
     }
     __syncthreads();
 #pragma unroll 2
-    for (int c = tid; c < ((PBL_MFMA_ABLATE & 1) ? 0 : nch); c += 4 * GW) {      // pass 1: bucket sizes
+    for (int c = tid; c < ((PBL_MFMA_ABLATE & 1) ? 0 : nch); c += WPG * GW) {      // pass 1: bucket sizes
         const u32x4 d4 = deltap[c];                 // padding steps of a tail chunk are 0
         uint32_t last = col0p[c];
         const uint32_t b0 = last / PW;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(4 * GW) void pbl_mfma_kernel(pbl_layer L, const _Fl
     __syncthreads();
     const bool lists_ok = bstart[NH] <= uint32_t(list_cap);    // uniform; else every panel scans every chunk
     if (lists_ok) {
-        for (int c = tid; c < ((PBL_MFMA_ABLATE & 1) ? 0 : nch); c += 4 * GW) {  // pass 2: fill (order inside a bucket is irrelevant)
+        for (int c = tid; c < ((PBL_MFMA_ABLATE & 1) ? 0 : nch); c += WPG * GW) {  // pass 2: fill (order inside a bucket is irrelevant)
             const uint32_t sp = span[c];
             for (uint32_t b = sp & 0xFFu; b <= (sp >> 8); ++b) blist[bstart[b] + atomicAdd(&bfill[b], 1u)] = uint16_t(c);
         }
@@ -320,25 +320,24 @@ __global__ __launch_bounds__(4 * GW) void pbl_mfma_kernel(pbl_layer L, const _Fl
         }
     }
 
-    // ---- combine the 4 K-slices in a fixed order; wave w then decodes accumulator component r = w ----
+    // ---- combine the WPG K-slices in a fixed order; wave w then decodes accumulator components r = w, w + WPG, .. ----
     __syncthreads();                                // tiles are dead: reuse them as the reduction buffer
     float* red = reinterpret_cast<float*>(smem_g);  // [wave][4 * NTB accumulators][4 components][64 lanes]
 #pragma unroll
     for (int t = 0; t < NTB; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            // class decode happens per slice (A, B belong to the PRODUCING lane's row = this lane's row_a... no:
-            // accumulator rows are 4*kblk + r, so only raw sums are exchanged here
+            // accumulator rows are 4*kblk + r: raw sums are exchanged, the class decode follows the combine
             red[((wave * 4 * NTB + 0 * NTB + t) * 4 + r) * GW + lane] = accW[t][r];
             red[((wave * 4 * NTB + 1 * NTB + t) * 4 + r) * GW + lane] = accS[t][r];
             red[((wave * 4 * NTB + 2 * NTB + t) * 4 + r) * GW + lane] = accM[t][r];
             red[((wave * 4 * NTB + 3 * NTB + t) * 4 + r) * GW + lane] = accX[t][r];
         }
     __syncthreads();
-    const int r = wave;                             // lane holds token (lane & 15) of each block, row 4*(lane >> 4) + r
+    for (int r = wave; r < 4; r += WPG) {           // lane holds token (lane & 15) of each block, row 4*(lane >> 4) + r
     const int rho = 4 * kblk + r;
     const uint32_t row = rb * 16 + rho;
-    if (row >= L.N) return;
+    if (row >= L.N) continue;
     const float4 pr = prm[rho];                     // {hi, lo, sscale, szero}
     float A, B;
     uint32_t Cunused;
@@ -354,7 +353,7 @@ __global__ __launch_bounds__(4 * GW) void pbl_mfma_kernel(pbl_layer L, const _Fl
         for (int a = 0; a < 4; ++a) {
             float v = 0.f;
 #pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) v += red[((w4 * 4 * NTB + a * NTB + t) * 4 + r) * GW + lane];
+            for (int w4 = 0; w4 < WPG; ++w4) v += red[((w4 * 4 * NTB + a * NTB + t) * 4 + r) * GW + lane];
             sums[a] = v;
         }
         const float Wv = sums[0], Q = sums[1], Mv = sums[2], X = sums[3];
@@ -371,6 +370,7 @@ __global__ __launch_bounds__(4 * GW) void pbl_mfma_kernel(pbl_layer L, const _Fl
         if (y_f32) static_cast<float*>(yv)[size_t(tok) * L.N + row] = out;
         else static_cast<_Float16*>(yv)[size_t(tok) * L.N + row] = _Float16(out);
     }
+    }
 }
 
 }  // namespace
@@ -385,7 +385,10 @@ extern "C" int pbl_gemm_mfma_f16(const pbl_layer* layer, const void* x, void* y,
     const int NH = (int(layer->K) + PW - 1) / PW;
     if (NH > 255) return PBL_ERR_UNSUPPORTED;
     int list_cap = int(layer->max_nch) * 3 / 2 + 64;
-    const size_t tiles_bytes = 4 * MFMA_WAVE_BYTES;
+    // many records: 2 waves per record (more independent workgroups per CU, one round over the chip);
+    // few records: 4 waves per record (the K split is the only parallelism there is)
+    const int wpg = layer->NRB >= 512 ? 2 : 4;
+    const size_t tiles_bytes = size_t(wpg) * MFMA_WAVE_BYTES;
     if (size_t(layer->max_nch) * 2 > tiles_bytes) return PBL_ERR_UNSUPPORTED;   // sort scratch lives in the tile area
     while (list_cap > 64 && tiles_bytes + mfma_shared_bytes(NH, list_cap, int(layer->max_nch)) > 160 * 1024) list_cap /= 2;
     const size_t lds = tiles_bytes + mfma_shared_bytes(NH, list_cap, int(layer->max_nch));
@@ -394,10 +397,12 @@ extern "C" int pbl_gemm_mfma_f16(const pbl_layer* layer, const void* x, void* y,
     const _Float16* xp = static_cast<const _Float16*>(x);
     void* argv[] = {&L, &xp, &y, &M, &y_f32, &list_cap};
     const bool sf = layer->flags & PBL_FLAG_SAL_F16;
-    const void* k = M <= 16 ? (sf ? reinterpret_cast<const void*>(pbl_mfma_kernel<1, true>) : reinterpret_cast<const void*>(pbl_mfma_kernel<1, false>))
-                            : (sf ? reinterpret_cast<const void*>(pbl_mfma_kernel<2, true>) : reinterpret_cast<const void*>(pbl_mfma_kernel<2, false>));
+#define PBL_MFMA_PICK(W) (M <= 16 ? (sf ? reinterpret_cast<const void*>(pbl_mfma_kernel<1, true, W>) : reinterpret_cast<const void*>(pbl_mfma_kernel<1, false, W>)) \
+                                   : (sf ? reinterpret_cast<const void*>(pbl_mfma_kernel<2, true, W>) : reinterpret_cast<const void*>(pbl_mfma_kernel<2, false, W>)))
+    const void* k = wpg == 2 ? PBL_MFMA_PICK(2) : PBL_MFMA_PICK(4);
+#undef PBL_MFMA_PICK
     if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
         return PBL_ERR_LAUNCH;
-    return hipLaunchKernel(k, dim3(layer->NRB), dim3(4 * GW), argv, lds, static_cast<hipStream_t>(stream)) == hipSuccess
+    return hipLaunchKernel(k, dim3(layer->NRB), dim3(wpg * GW), argv, lds, static_cast<hipStream_t>(stream)) == hipSuccess
                ? PBL_OK : PBL_ERR_LAUNCH;
 }
