@@ -741,14 +741,17 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
 
 // ---------------------------------------------------------------------------------------
 // Device-side unpack: PBL1 -> dense row-major [N,K] (fp16 or fp32); the GEMM-regime path
-// (the dense matrix lives only in a transient workspace).  One workgroup of 4 waves per
-// record: wave w expands panels w, w+4, ... through an LDS transpose so that every global
-// store is 16 bytes per lane (narrow stores cost up to 6x per byte on this part), then the
-// waves scatter the salient code entries lane-per-chunk with 16-byte loads, then exceptions.
+// (the dense matrix lives only in a transient workspace).
 template <typename OutT>
-__global__ __launch_bounds__(4 * PBL_WAVE) void pbl_unpack_kernel(pbl_layer L, OutT* __restrict__ Wout) {
+__global__ __launch_bounds__(4 * PBL_WAVE) void pbl_unpack_kernel(pbl_layer L, OutT* __restrict__ Wout, int seg_panels) {
+    // A workgroup owns 4 rows of a record (grid = 4 * NRB), one per wave; a wave builds its output row in LDS, in
+    // column segments of seg_panels * 512 columns -- sign plane expanded, then the row's salient chunks
+    // (column-sorted) and exceptions written over it -- and streams the finished segment out with contiguous
+    // 16-byte stores.  No global scatter: every HBM line is written whole, once.
+    extern __shared__ __attribute__((aligned(16))) char smem_u[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t rb = blockIdx.x;
+    const uint32_t rb = blockIdx.x >> 2;
+    const int row0 = int(blockIdx.x & 3) * 4;
     const int K = int(L.K), P = int(L.P), G = int(L.G);
     const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
     const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[rb];
@@ -757,67 +760,13 @@ __global__ __launch_bounds__(4 * PBL_WAVE) void pbl_unpack_kernel(pbl_layer L, O
     const int nexc = __builtin_amdgcn_readfirstlane(info.w), nch = nfull + ntail;
     const bool groups = L.flags & PBL_FLAG_HAS_GROUPS, sf16 = L.flags & PBL_FLAG_SAL_F16;
     const uint32_t tiles_off = PBL_TILES_OFF(uint32_t(G));
-    const uint32_t off_sal = tiles_off + uint32_t(P) * 1024u;
     const pbl_rowparams* params = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
     const pbl_rowinfo* rinfo = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF);
     const float2* ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
     const int gwords = groups ? (K / G) / 128 : (1 << 30);   // dwords of a lane per column group
     const int nrows = (L.N - rb * 16) < 16u ? int(L.N - rb * 16) : 16;
-
-    // Sign plane.  The 4 lanes of a quad hold, per dword, 16 rows x 8 CONSECUTIVE columns
-    // (2 each).  Each lane fetches the quad's 4 dwords by DPP broadcast and expands rows
-    // q, q+4, q+8, q+12 (q = lane & 3) to 8 consecutive values -> 16-byte stores (narrow stores
-    // cost up to 6x per byte on this part); a wave-store covers 4 rows x 256 contiguous bytes.
-    const int q = lane & 3, quad = lane >> 2;
-    float hi_r[4], lo_r[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { hi_r[m] = params[q + 4 * m].hi; lo_r[m] = params[q + 4 * m].lo; }
     const u32x4* tiles = reinterpret_cast<const u32x4*>(rec + tiles_off) + lane;
-    for (int p = wave; p < P; p += 4) {
-        const u32x4 t = __builtin_nontemporal_load(tiles + p * 64);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t w4[4];
-            w4[0] = __builtin_amdgcn_update_dpp(0, int(t[i]), 0x00, 0xF, 0xF, false);   // quad_perm [0,0,0,0]
-            w4[1] = __builtin_amdgcn_update_dpp(0, int(t[i]), 0x55, 0xF, 0xF, false);   // [1,1,1,1]
-            w4[2] = __builtin_amdgcn_update_dpp(0, int(t[i]), 0xAA, 0xF, 0xF, false);   // [2,2,2,2]
-            w4[3] = __builtin_amdgcn_update_dpp(0, int(t[i]), 0xFF, 0xF, 0xF, false);   // [3,3,3,3]
-            const int col = p * PBL_PANEL_COLS + i * 128 + 8 * quad;
-            if (col >= K) continue;
-            const int g = (p * 4 + i) / gwords;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int rho = q + 4 * m;
-                if (rho >= nrows) continue;
-                const int pos = rho < 8 ? rho + 8 : rho - 8;
-                float hi = hi_r[m], lo = lo_r[m];
-                if (groups) { const float2 hl = ghl[rho * G + (g < G ? g : G - 1)]; hi = hl.x; lo = hl.y; }
-                OutT v[8];
-#pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    v[2 * sl] = OutT(((w4[sl] >> pos) & 1u) ? hi : lo);
-                    v[2 * sl + 1] = OutT(((w4[sl] >> (16 + pos)) & 1u) ? hi : lo);
-                }
-                OutT* dst = Wout + size_t(rb * 16 + rho) * K + col;
-                if (col + 8 <= K && (K % (16 / sizeof(OutT))) == 0) {
-                    if constexpr (sizeof(OutT) == 2) {
-                        *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(v);
-                    } else {
-                        reinterpret_cast<u32x4*>(dst)[0] = reinterpret_cast<const u32x4*>(v)[0];
-                        reinterpret_cast<u32x4*>(dst)[1] = reinterpret_cast<const u32x4*>(v)[1];
-                    }
-                } else {
-                    for (int e = 0; e < 8 && col + e < K; ++e) dst[e] = v[e];
-                }
-            }
-        }
-    }
-    // the sparse entries below overwrite positions written above by any of the 4 waves
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    const uint8_t* sal = rec + off_sal;
+    const uint8_t* sal = rec + tiles_off + uint32_t(P) * 1024u;
     const uint32_t nchu = uint32_t(nch);
     const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
     const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + PBL_SAL_DELTA_OFF(nchu));
@@ -825,32 +774,71 @@ __global__ __launch_bounds__(4 * PBL_WAVE) void pbl_unpack_kernel(pbl_layer L, O
     const uint8_t* tailcnt = sal + PBL_SAL_TAILCNT_OFF(nchu);
     const bool has_crow = L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16);
     const uint2* exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), has_crow));
-    for (int c = threadIdx.x; c < nch; c += 4 * PBL_WAVE) {
-        // row of chunk c: full chunks are laid out row by row (then the tail chunks likewise) and the
-        // per-row start indices are non-decreasing, so the owner is the last row whose start is <= c
-        int rho = 0;
-        if (c < nfull) { for (int r = 1; r < 16; ++r) rho += int(rinfo[r].start) <= c; }
-        else { const int t_ = c - nfull; for (int r = 1; r < 16; ++r) rho += int(rinfo[r].tailidx) <= t_; }
-        const int cnt = c >= nfull ? int(tailcnt[c - nfull]) : 16;
-        const u32x4 d4 = deltap[c], q4 = codep[c];
-        const float ss = params[rho].sscale, sz = params[rho].szero;
-        OutT* wrow = Wout + size_t(rb * 16 + rho) * K;
-        uint32_t col = col0p[c];
+    const int seg_cols = seg_panels * PBL_PANEL_COLS;
+    OutT* rowbuf = reinterpret_cast<OutT*>(smem_u) + size_t(wave) * seg_cols;   // this wave's row segment under construction
+    const bool vec_ok = (size_t(K) * sizeof(OutT)) % 16 == 0;                    // every row starts 16-byte aligned
+
+    const int rho = row0 + wave;
+    if (rho < nrows) {
+        const int pos = rho < 8 ? rho + 8 : rho - 8;
+        const pbl_rowparams pr = params[rho];
+        const pbl_rowinfo ri = rinfo[rho];
+        const int n_full = int(ri.nfull), n_all = n_full + int(ri.ntail);
+        for (int p0 = 0; p0 < P; p0 += seg_panels) {
+            const int p1 = p0 + seg_panels < P ? p0 + seg_panels : P;
+            const uint32_t c_lo = uint32_t(p0) * PBL_PANEL_COLS, c_n = uint32_t(p1 - p0) * PBL_PANEL_COLS;
+            // 1. sign plane of the row: lane l owns columns 512p + 128i + 2l + {0,1}
+            for (int p = p0; p < p1; ++p) {
+                const u32x4 t = tiles[p * 64];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            col += ((d4[e >> 2] >> (8 * (e & 3))) & 0xFFu) >> 1;
-            float w = ss * (float((q4[e >> 2] >> (8 * (e & 3))) & 0xFFu) - sz);
-            if (sf16) w = float(round_f16_twice(w));
-            if (e < cnt && col < uint32_t(K) && rho < nrows) wrow[col] = OutT(w);
+                for (int i = 0; i < 4; ++i) {
+                    float hi = pr.hi, lo = pr.lo;
+                    if (groups) { const int g = (p * 4 + i) / gwords; const float2 hl = ghl[rho * G + (g < G ? g : G - 1)]; hi = hl.x; lo = hl.y; }
+                    OutT* d = rowbuf + (p - p0) * PBL_PANEL_COLS + i * 128 + 2 * lane;
+                    d[0] = OutT(((t[i] >> pos) & 1u) ? hi : lo);
+                    d[1] = OutT(((t[i] >> (16 + pos)) & 1u) ? hi : lo);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // 2. the row's salient chunks (full chunks [start, start + nfull), then its tail chunks); entries outside
+            //    the segment are skipped
+            for (int j = lane; j < n_all; j += PBL_WAVE) {
+                const int c = j < n_full ? int(ri.start) + j : nfull + int(ri.tailidx) + (j - n_full);
+                const int cnt = c >= nfull ? int(tailcnt[c - nfull]) : 16;
+                const u32x4 d4 = deltap[c], q4 = codep[c];
+                uint32_t col = uint32_t(col0p[c]) - c_lo;                 // wraps for columns left of the segment
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    col += ((d4[e >> 2] >> (8 * (e & 3))) & 0xFFu) >> 1;
+                    float w = pr.sscale * (float((q4[e >> 2] >> (8 * (e & 3))) & 0xFFu) - pr.szero);
+                    if (sf16) w = float(round_f16_twice(w));
+                    if (e < cnt && col < c_n) rowbuf[col] = OutT(w);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // 3. exceptions of the row (explicit values, written last)
+            for (int k = lane; k < nexc; k += PBL_WAVE) {
+                const uint2 ex = exc[k];
+                const uint32_t col = (ex.x & 0xFFFFu) - c_lo;
+                if (int(ex.x >> 16) == rho && col < c_n) rowbuf[col] = OutT(__builtin_bit_cast(float, ex.y));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // 4. stream the segment out
+            OutT* dst = Wout + size_t(rb * 16 + rho) * K + c_lo;
+            const int ncol = int(c_lo + c_n) <= K ? int(c_n) : K - int(c_lo);
+            if (vec_ok) {
+                constexpr int V = 16 / sizeof(OutT);
+                for (int j = lane * V; j < ncol; j += PBL_WAVE * V)
+                    *reinterpret_cast<u32x4*>(dst + j) = *reinterpret_cast<const u32x4*>(rowbuf + j);
+            } else {
+                for (int j = lane; j < ncol; j += PBL_WAVE) dst[j] = rowbuf[j];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int k = threadIdx.x; k < nexc; k += 4 * PBL_WAVE) {
-        const uint2 ex = exc[k];
-        const uint32_t r = rb * 16 + (ex.x >> 16), c = ex.x & 0xFFFFu;
-        if (r < L.N && c < uint32_t(K)) Wout[size_t(r) * K + c] = OutT(__builtin_bit_cast(float, ex.y));
     }
 }
 
@@ -1005,10 +993,15 @@ int pbl_unpack_dev(const pbl_layer* layer, void* W_out, int out_f32, void* strea
     if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     pbl_layer L = *layer;
-    void* argv[] = {&L, &W_out};
+    // one LDS row-segment buffer per wave: at most 16 KiB each, so that several workgroups share a CU
+    const size_t esz = out_f32 ? 4 : 2;
+    int seg_panels = int((16 * 1024) / (PBL_PANEL_COLS * esz));           // 16 (fp16) or 8 (fp32) panels
+    if (seg_panels > int(layer->P)) seg_panels = int(layer->P);
+    const size_t lds = size_t(seg_panels) * PBL_PANEL_COLS * esz * 4;
+    void* argv[] = {&L, &W_out, &seg_panels};
     const void* k = out_f32 ? reinterpret_cast<const void*>(pbl_unpack_kernel<float>)
                             : reinterpret_cast<const void*>(pbl_unpack_kernel<_Float16>);
-    return hipLaunchKernel(k, dim3(layer->NRB), dim3(4 * PBL_WAVE), argv, 0, st) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+    return hipLaunchKernel(k, dim3(4 * layer->NRB), dim3(4 * PBL_WAVE), argv, lds, st) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
 }
 
 int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, void* const* y_dev, int Lc,
