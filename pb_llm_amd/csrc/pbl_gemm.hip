@@ -17,7 +17,7 @@
 //     into a CLASS-CODED fp16 A fragment with one v_and_or per dword -- the GEMV's (w & M_c) | C_c trick, now
 //     indexed by the lane's own row; reads 8 mask bytes and widens them to fp16 {0, 1} with four v_perm_b32;
 //     and runs v_mfma_f32_16x16x32_f16 for  accW += W.x, accM += Mask.x, accS += St.x, accX += 1.x;
-//   * clears St / Mt with wide stores.
+//   * clears Mt with wide stores (St is never cleared: stale entries are multiplied by the 0/1 mask when read).
 // Decode in fp32:  D = A_c*accW - B_c*X (sum of +-1 * x),  S = accM,
 //   y = alpha*D + mu*X + [ss*(Q - sz*S) | Q] - hi*S + exceptions + bias.
 // One pass over the packed weights for up to 32 tokens; x fragments come from L2.
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(pbl_layer L, const _
                     for (int ks = 0; ks < 4; ++ks) {
                         const v8h aW = (PBL_MFMA_ABLATE & 128) ? ones : frag(*reinterpret_cast<const u32x4*>(Wsel + i * 64 + ks * 16 + kblk * 4));
                         const v8h aM = (PBL_MFMA_ABLATE & 128) ? ones : mfrag(*reinterpret_cast<const uint2*>(Mt + row_a * SSTR + i * 128 + ks * 32 + kblk * 8));
-                        const v8h aS = (PBL_MFMA_ABLATE & 128) ? ones : *reinterpret_cast<const v8h*>(St + row_a * SSTR + i * 128 + ks * 32 + kblk * 8);
+                        // St is never cleared: entries left over from earlier half panels are multiplied by the mask (0 / 1, exact)
+                        const v8h aS = (PBL_MFMA_ABLATE & 128) ? ones : *reinterpret_cast<const v8h*>(St + row_a * SSTR + i * 128 + ks * 32 + kblk * 8) * aM;
 #pragma unroll
                         for (int t = 0; t < ((PBL_MFMA_ABLATE & 4) ? 0 : NTB); ++t) {
                             accW[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aW, bx[i][ks][t], accW[t], 0, 0, 0);
@@ -305,8 +306,8 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(pbl_layer L, const _
                 load_x((2 * h + 2) * 128, bx[0]);   // the clear and the next scatter
                 load_x((2 * h + 3) * 128, bx[1]);
             }
-            if (!(PBL_MFMA_ABLATE & 8) && be > bs) {     // clear St and Mt (contiguous; Wp is overwritten)
-                for (int q = lane; q < 16 * SSTR * 3 / 16; q += GW) reinterpret_cast<u32x4*>(St)[q] = u32x4{0, 0, 0, 0};
+            if (!(PBL_MFMA_ABLATE & 8) && be > bs) {     // clear the mask tile only (Wp is overwritten, St is masked when read)
+                for (int q = lane; q < 16 * SSTR / 16; q += GW) reinterpret_cast<u32x4*>(Mt)[q] = u32x4{0, 0, 0, 0};
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
