@@ -187,3 +187,45 @@ def test_forward_on_cpu_fails_loudly():
     layer = PBLinear.from_dense(torch.from_numpy(r["W_fq"]), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
     with pytest.raises(_lib.PblError):
         layer(torch.zeros(1, 512, dtype=torch.float16))
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/pbl.h is the drop-in boundary: it must compile as C99 (no C++-isms, no torch types) and a C program must
+    link against libpbl.so and call the host-side entry points (pack -> describe -> unpack round trip)."""
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "rt.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include "pbl.h"
+int main(void) {
+    enum { N = 20, K = 640 };
+    static float W[N * K], hi[N], lo[N], ss[N], sz[N], back[N * K];
+    static unsigned char sal[N * K];
+    for (int r = 0; r < N; ++r) { hi[r] = 0.5f + r; lo[r] = -0.25f - r; ss[r] = 0.125f; sz[r] = 3.0f; }
+    for (int i = 0; i < N * K; ++i) {
+        int r = i / K;
+        sal[i] = (i % 7) == 0;
+        W[i] = sal[i] ? ss[r] * ((float)(i % 251) - sz[r]) : ((i % 3) ? hi[r] : lo[r]);
+    }
+    size_t need = 0;
+    if (pbl_pack_dense_f32(W, N, K, 1, hi, lo, ss, sz, sal, 0, NULL, 0, &need) != PBL_OK || !need) return 1;
+    void* blob = malloc(need);
+    if (pbl_pack_dense_f32(W, N, K, 1, hi, lo, ss, sz, sal, 0, blob, need, &need) != PBL_OK) return 2;
+    pbl_layer L;
+    if (pbl_blob_describe(blob, need, &L) != PBL_OK || L.N != N || L.K != K || !(L.flags & PBL_FLAG_TAIL_REPEAT)) return 3;
+    if (pbl_unpack_dense_f32(blob, need, back) != PBL_OK) return 4;
+    for (int i = 0; i < N * K; ++i) if (back[i] != W[i]) return 5;
+    printf("ok %s v%d %zu bytes\n", pbl_status_string(PBL_OK), pbl_version(), need);
+    return 0;
+}
+''')
+    exe = tmp_path / "rt"
+    libdir = os.path.join(repo, "pb_llm_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(repo, "include"),
+                           str(src), "-o", str(exe), "-L", libdir, "-lpbl", "-L/opt/rocm/lib", "-lamdhip64",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    assert out.stdout.startswith("ok ")
