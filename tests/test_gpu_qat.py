@@ -162,3 +162,54 @@ def test_qat_step_llama_shape_vs_reference_arithmetic_on_gpu(wdt):
     for got, ref in ((y, yr), (x.grad, xr.grad), (W.grad, Wr.grad)):
         assert relmax(got, ref.detach().float().cpu().numpy().astype(np.float64)) < tol
     assert W.grad.dtype == wdt and not W.grad[mask].any()
+
+
+def test_short_qat_training_run_tracks_reference_arithmetic():
+    """8 SGD steps on a 2-layer MLP of PB layers (bf16 autocast off: fp32): weights after every step == the same
+    steps taken with the reference's forward as written + torch autograd; the loss goes down; eval() afterwards
+    serves the trained weights through the packed kernels."""
+    torch.manual_seed(0)
+    K, Hd, N, B = 256, 384, 128, 32
+    W1 = synth.llm_weight(Hd, K, seed=31, heavy_tail=True) * 4
+    W2 = synth.llm_weight(N, Hd, seed=32, heavy_tail=True) * 4
+    l1 = Q.BinaryXnorExceptOutliersLinear(torch.from_numpy(W1), None, 0.1)
+    l2 = Q.BinaryXnorExceptOutliersLinear(torch.from_numpy(W2), None, 0.1, train_outlier=True)
+    for l in (l1, l2):
+        l.gen_outlier_mask()
+    model = torch.nn.Sequential(l1, torch.nn.ReLU(), l2).to(DEV).train()
+    # the same thing with the reference's arithmetic
+    ref_w = [l.weight.detach().clone().requires_grad_(True) for l in (l1, l2)]
+    masks = [l.outlier_mask for l in (l1, l2)]
+    train_out = [False, True]
+
+    def ref_forward(x):
+        h = x
+        for i, (w, m) in enumerate(zip(ref_w, masks)):
+            s = w[~m].abs().mean(-1).view(-1, 1).detach()
+            sw = w * 1.0 if train_out[i] else (w * 1.0).detach()
+            h = torch.nn.functional.linear(h, torch.where(m, sw, qat.STEBinary.apply(w) * s))
+            if i == 0:
+                h = torch.relu(h)
+        return h
+
+    x = T(synth.normal((B, K), 33, 1, 1.0))
+    target = T(synth.normal((B, N), 33, 2, 1.0))
+    opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+    opt_ref = torch.optim.SGD(ref_w, lr=1e-2)
+    losses = []
+    for step in range(8):
+        opt.zero_grad(); opt_ref.zero_grad()
+        loss = torch.nn.functional.mse_loss(model(x), target)
+        loss.backward(); opt.step()
+        loss_r = torch.nn.functional.mse_loss(ref_forward(x), target)
+        loss_r.backward(); opt_ref.step()
+        losses.append(float(loss.detach()))
+        assert abs(float(loss.detach()) - float(loss_r.detach())) <= 1e-5 * abs(float(loss_r.detach())), step
+        for l, w in zip((l1, l2), ref_w):
+            assert relmax(l.weight, w.detach().cpu().numpy().astype(np.float64)) < 1e-5, step
+    assert losses[-1] < losses[0]
+    model.eval()
+    with torch.no_grad():
+        y = model(x)
+        y_ref = ref_forward(x)
+    assert relmax(y, y_ref.cpu().numpy().astype(np.float64)) < 2e-3
