@@ -381,11 +381,12 @@ extern "C" int pbl_gemm_mfma_f16(const pbl_layer* layer, const void* x, void* y,
     if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
     if (layer->G != 1 || (layer->K & 7) || (reinterpret_cast<uintptr_t>(x) & 15)) return PBL_ERR_UNSUPPORTED;
     if (!(layer->flags & PBL_FLAG_TAIL_REPEAT)) return PBL_ERR_UNSUPPORTED;   // the scatter writes all 16 entries of a chunk
-    // bucket lists: a chunk lands in one panel (two when it straddles a boundary); sized generously, and the
-    // kernel falls back to scanning for a record that still overflows (pathological gaps)
+    // bucket lists: a chunk of 16 salient entries spans about 16 / density columns, i.e. it lands in about
+    // 1 + K / (16 * chunks-per-record) half panels of 256 columns; size for that plus 15 % and let the kernel fall
+    // back to scanning for a record that still overflows (pathological gaps: slow, correct)
     const int NH = (int(layer->K) + PW - 1) / PW;
     if (NH > 255) return PBL_ERR_UNSUPPORTED;
-    int list_cap = int(layer->max_nch) * 3 / 2 + 64;
+    int list_cap = int(1.15 * (double(layer->max_nch) + double(layer->K) / 16.0)) + 64;
     // many records: 2 waves per record (more independent workgroups per CU, one round over the chip);
     // few records: 4 waves per record (the K split is the only parallelism there is)
     const int wpg = layer->NRB >= 512 ? 2 : 4;

@@ -7,8 +7,9 @@ from oracle import pb_oracle as O
 from pb_llm_amd import synth, quant as Q
 from pb_llm_amd.packing import PackedWeight
 
-CACHE = "/tmp/pbl_mfma_cache.pt"
-SHAPES = (("13824x5120", 0.8), ("5120x13824", 0.8), ("4096x4096", 0.9))
+CACHE = os.environ.get("PBL_BENCH_CACHE", "/tmp/pbl_mfma_cache.pt")
+SHAPES = tuple((s_, float(f)) for s_, f in (t.split(":") for t in os.environ.get(
+    "PBL_BENCH_SHAPES", "13824x5120:0.8,5120x13824:0.8,4096x4096:0.9").split(",")))
 if os.path.exists(CACHE):
     blobs = torch.load(CACHE)
 else:
