@@ -281,11 +281,14 @@ class _DenseBacked(nn.Module, BinaryInterface):
         no_grad (evaluation loops that forget eval()) still takes the packed kernels"""
         return self.training and torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad)
 
-    def forward(self, x):
+    def _check_input(self, x):
         if x.shape[-1] != self.weight.shape[1]:
             raise ValueError(f"in_features mismatch: x has {x.shape[-1]}, layer has {self.weight.shape[1]}")
         if not x.is_cuda:
             raise _lib.PblError("PB linear forward needs a GPU tensor: the HIP kernels are the only compute path")
+
+    def forward(self, x):
+        self._check_input(x)
         if self._is_training_step(x):
             # QAT step: the weights change every step, so nothing is packed; the dense simulated weight is
             # built on the GPU with the straight-through estimator and a library GEMM runs on it
@@ -447,6 +450,7 @@ class BinaryXnorExceptOutliersLinear(_DenseBacked):
                           self.outlier_mask.cpu().numpy().astype(np.uint8))
 
     def forward(self, x):
+        self._check_input(x)
         if self.outlier_mask is None:
             self.gen_outlier_mask()
         if self._is_training_step(x):

@@ -132,3 +132,42 @@ def test_pbllm_linear_op_fake_impl_gives_shapes_without_a_gpu():
         assert torch.ops.pbllm.linear(blob, None, x, meta, True, True).dtype == torch.float32
     with pytest.raises(_lib.PblError):
         torch.ops.pbllm.linear(layer.pbl_blob, None, torch.zeros(1, m.K, dtype=torch.float16), meta, True, False)
+
+
+def test_training_and_producer_paths_refuse_host_tensors():
+    """QAT step, salient selection, row quantizer and GPTQ-PB are GPU-only: a host tensor raises instead of silently
+    running somewhere else (the same rule as the forward)."""
+    from pb_llm_amd import _lib, prep, ptq, qat
+    W = torch.from_numpy(synth.llm_weight(16, 256, seed=2))
+    mask = W.abs() > 0.05
+    for call in (lambda: qat.binary_scale(W, mask),
+                 lambda: qat.build_wsim(W, mask, torch.zeros(1), 1.0),
+                 lambda: qat.wgrad_(W.clone(), mask, torch.zeros(1), 1.0, False),
+                 lambda: qat.qat_linear(torch.zeros(2, 256), W, None, mask),
+                 lambda: prep.kth_pair(W, 1, 2),
+                 lambda: prep.outlier_mask(W, torch.zeros(2)),
+                 lambda: prep.quant8_rows_(W.clone()),
+                 lambda: ptq.LowHighGPTQ(nn.Linear(256, 16))):
+        with pytest.raises(_lib.PblError):
+            call()
+    m = Q.BinaryXnorExceptOutliersLinear(W.clone(), None, 0.1)
+    m.train()
+    with pytest.raises(_lib.PblError):
+        m(torch.zeros(2, 256, requires_grad=True))
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 100))
+
+
+def test_decoder_layers_finds_llama_and_opt_layouts():
+    from transformers import LlamaConfig, LlamaForCausalLM, OPTConfig, OPTForCausalLM
+    from pb_llm_amd import harness as H
+    llama = LlamaForCausalLM(LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                         num_key_value_heads=4, vocab_size=100, max_position_embeddings=64))
+    opt = OPTForCausalLM(OPTConfig(hidden_size=64, ffn_dim=128, num_hidden_layers=3, num_attention_heads=4, vocab_size=100,
+                                   max_position_embeddings=64, word_embed_proj_dim=64))
+    assert len(H.decoder_layers(llama)) == 2 and len(H.decoder_layers(opt)) == 3
+    assert len(H.find_layers(H.decoder_layers(llama)[0])) == 7 and len(H.find_layers(H.decoder_layers(opt)[0])) == 6
+    with pytest.raises(RuntimeError):
+        H.quant_sequential_(llama, [torch.zeros(1, 8, dtype=torch.long)], 0.9)       # model on the host: no host path
+    with pytest.raises(NotImplementedError):
+        H.decoder_layers(nn.Linear(4, 4))
