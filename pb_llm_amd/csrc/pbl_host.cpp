@@ -7,8 +7,11 @@
 #include "../../include/pbl.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -68,6 +71,155 @@ const char* pbl_status_string(int s) {
 
 int pbl_version(void) { return PBL_VERSION; }
 
+}  // extern "C" (reopened below)
+
+namespace {
+
+// Everything one 16-row record contributes to the blob, built independently of every other record.
+struct RecImage {
+    std::vector<uint8_t> bytes;     // the record as it lies in the blob (empty in a size query)
+    size_t rec_bytes = 0;
+    uint32_t nfull = 0, ntail = 0, nexc = 0;
+    uint64_t nnz = 0;
+    int status = PBL_OK;
+};
+
+struct PackArgs {
+    const float *W, *hi, *lo, *sscale, *szero;
+    const uint8_t* sal_mask;
+    uint32_t N, K, G, gs, P;
+    bool sal16, want_bytes;
+    size_t fixed, tiles_off;
+};
+
+void build_record(const PackArgs& a, uint32_t b, RecImage& out) {
+    const uint32_t N = a.N, K = a.K, G = a.G, P = a.P;
+    RecBuild rb;
+    rb.clear();
+    std::vector<Entry> ents;
+    std::vector<uint32_t> tile(size_t(P) * 256, 0u);
+    pbl_rowparams params[16];
+    std::memset(params, 0, sizeof(params));
+    std::vector<float> ghl;
+    if (G > 1) ghl.assign(size_t(16) * G * 2, 0.f);
+    uint64_t nnz = 0;
+
+    for (int rho = 0; rho < 16; ++rho) {
+        const uint32_t r = b * 16 + rho;
+        rb.ri[rho].start = uint16_t(rb.col0_full.size());
+        rb.ri[rho].tailidx = uint16_t(rb.col0_tail.size());
+        if (r >= N) continue;
+        const float* w = a.W + size_t(r) * K;
+        const float ss = a.sscale ? a.sscale[r] : 0.f, sz = a.szero ? a.szero[r] : 0.f;
+        params[rho] = {a.hi[size_t(r) * G], a.lo[size_t(r) * G], ss, sz};
+        if (G > 1)
+            for (uint32_t g = 0; g < G; ++g) {
+                ghl[(size_t(rho) * G + g) * 2 + 0] = a.hi[size_t(r) * G + g];
+                ghl[(size_t(rho) * G + g) * 2 + 1] = a.lo[size_t(r) * G + g];
+            }
+        ents.clear();
+        for (uint32_t c = 0; c < K; ++c) {
+            const float v = w[c];
+            const uint32_t g = c / a.gs;
+            const float h = a.hi[size_t(r) * G + g], l = a.lo[size_t(r) * G + g];
+            const bool forced = a.sal_mask && a.sal_mask[size_t(r) * K + c];
+            int bit;
+            if (!forced && v == h) bit = 1;
+            else if (!forced && v == l) bit = 0;
+            else {
+                bit = 1;  // sparse entries correct against `hi`
+                bool coded = false;
+                if (a.sscale && ss != 0.f && std::isfinite(v)) {
+                    float qf = std::nearbyint(v / ss + sz);
+                    for (int dq = 0; dq <= 2 && !coded; ++dq) {
+                        int q = int(qf) + (dq == 0 ? 0 : (dq == 1 ? 1 : -1));
+                        if (q >= 0 && q <= 255 && (a.sal16 ? dequant_f16(ss, sz, q) : dequant(ss, sz, q)) == v) {
+                            ents.push_back({uint16_t(c), uint8_t(q)});
+                            coded = true;
+                        }
+                    }
+                }
+                if (!coded) rb.exc.push_back({uint16_t(c), uint16_t(rho), v});
+            }
+            if (bit) {
+                const uint32_t p = c / 512, cc = c % 512, i = cc / 128, l2 = (cc % 128) / 2, e = cc & 1;
+                tile[(size_t(p) * 64 + l2) * 4 + i] |= 1u << bit_index(rho, int(e));
+            }
+        }
+        nnz += ents.size();
+        // greedy chunking: close at 16 entries or when the next column step exceeds PBL_MAX_GAP
+        size_t i = 0;
+        uint16_t nfull = 0, ntail = 0;
+        while (i < ents.size()) {
+            size_t j = i + 1;
+            while (j < ents.size() && j - i < 16 && ents[j].col - ents[j - 1].col <= PBL_MAX_GAP) ++j;
+            const size_t cnt = j - i;
+            uint8_t d[16] = {0}, q[16] = {0};
+            for (size_t k = 0; k < cnt; ++k) {
+                d[k] = k ? uint8_t(2 * (ents[i + k].col - ents[i + k - 1].col)) : 0;  // byte step in the fp16 x tile
+                q[k] = ents[i + k].code;
+            }
+            for (size_t k = cnt; k < 16; ++k) q[k] = q[cnt - 1];   // PBL_FLAG_TAIL_REPEAT: padding repeats the last entry
+            if (cnt == 16) {
+                rb.col0_full.push_back(ents[i].col);
+                rb.delta_full.insert(rb.delta_full.end(), d, d + 16);
+                rb.code_full.insert(rb.code_full.end(), q, q + 16);
+                rb.crow_full.push_back(uint8_t(rho));
+                ++nfull;
+            } else {
+                rb.col0_tail.push_back(ents[i].col);
+                rb.delta_tail.insert(rb.delta_tail.end(), d, d + 16);
+                rb.code_tail.insert(rb.code_tail.end(), q, q + 16);
+                rb.tailcnt.push_back(uint8_t(cnt));
+                rb.crow_tail.push_back(uint8_t(rho));
+                ++ntail;
+            }
+            i = j;
+        }
+        if (ntail > 255) { out.status = PBL_ERR_UNSUPPORTED; return; }
+        rb.ri[rho].nfull = nfull;
+        rb.ri[rho].ntail = uint8_t(ntail);
+    }
+
+    const size_t nfull = rb.col0_full.size(), ntail = rb.col0_tail.size(), nch = nfull + ntail;
+    if (nch > 65535) { out.status = PBL_ERR_UNSUPPORTED; return; }
+    const bool has_crow = G > 1 || a.sal16;
+    out.rec_bytes = a.fixed + record_sal_bytes(nch, ntail, rb.exc.size(), has_crow);
+    out.nfull = uint32_t(nfull); out.ntail = uint32_t(ntail); out.nexc = uint32_t(rb.exc.size()); out.nnz = nnz;
+    if (!a.want_bytes) return;
+    out.bytes.assign(out.rec_bytes, 0);
+    uint8_t* rec = out.bytes.data();
+    pbl_rec_header h = {uint32_t(nfull), uint32_t(ntail), uint32_t(rb.exc.size()), uint32_t(a.fixed)};
+    std::memcpy(rec, &h, sizeof(h));
+    std::memcpy(rec + 16, rb.ri, sizeof(rb.ri));
+    std::memcpy(rec + 16 + 128, params, sizeof(params));
+    if (G > 1) std::memcpy(rec + PBL_REC_GHL_OFF, ghl.data(), ghl.size() * 4);
+    std::memcpy(rec + a.tiles_off, tile.data(), tile.size() * 4);
+    uint8_t* s = rec + a.fixed;
+    const uint32_t nch32 = uint32_t(nch), ntail32 = uint32_t(ntail);
+    uint16_t* col0 = reinterpret_cast<uint16_t*>(s);
+    for (size_t k = 0; k < nfull; ++k) col0[k] = rb.col0_full[k];
+    for (size_t k = 0; k < ntail; ++k) col0[nfull + k] = rb.col0_tail[k];
+    uint8_t* dl = s + PBL_SAL_DELTA_OFF(nch32);
+    if (nfull) std::memcpy(dl, rb.delta_full.data(), nfull * 16);
+    if (ntail) std::memcpy(dl + nfull * 16, rb.delta_tail.data(), ntail * 16);
+    uint8_t* cd = s + PBL_SAL_CODE_OFF(nch32);
+    if (nfull) std::memcpy(cd, rb.code_full.data(), nfull * 16);
+    if (ntail) std::memcpy(cd + nfull * 16, rb.code_tail.data(), ntail * 16);
+    if (ntail) std::memcpy(s + PBL_SAL_TAILCNT_OFF(nch32), rb.tailcnt.data(), ntail);
+    if (has_crow) {
+        uint8_t* cr = s + PBL_SAL_CROW_OFF(nch32, ntail32);
+        if (nfull) std::memcpy(cr, rb.crow_full.data(), nfull);
+        if (ntail) std::memcpy(cr + nfull, rb.crow_tail.data(), ntail);
+    }
+    if (!rb.exc.empty())
+        std::memcpy(s + PBL_SAL_EXC_OFF(nch32, ntail32, has_crow), rb.exc.data(), rb.exc.size() * sizeof(pbl_exception));
+}
+
+}  // namespace
+
+extern "C" {
+
 int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
                        const float* hi, const float* lo, const float* sscale, const float* szero,
                        const uint8_t* sal_mask, uint32_t flags, void* out, size_t cap, size_t* out_bytes) {
@@ -76,148 +228,54 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
     if (!W || !hi || !lo || !out_bytes || N == 0 || K == 0 || G == 0) return PBL_ERR_INVALID_ARG;
     if (K > 32767 || N > (1u << 24)) return PBL_ERR_UNSUPPORTED;
     if (G > 1 && (K % G != 0 || (K / G) % 128 != 0)) return PBL_ERR_UNSUPPORTED;
-    const uint32_t gs = K / G;
     const uint32_t P = (K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS;
     const uint32_t NRB = (N + 15) / 16;
-
     const size_t rboff_pos = sizeof(pbl_blob_header);
     const size_t rec0 = align128(rboff_pos + size_t(NRB + 1) * sizeof(pbl_rec_info));
-    const size_t fixed = record_fixed_bytes(P, G);
-    const size_t tiles_off = fixed - size_t(P) * 1024;
-
     uint8_t* blob = static_cast<uint8_t*>(out);
+
+    PackArgs a;
+    a.W = W; a.hi = hi; a.lo = lo; a.sscale = sscale; a.szero = szero; a.sal_mask = sal_mask;
+    a.N = N; a.K = K; a.G = G; a.gs = K / G; a.P = P; a.sal16 = sal16; a.want_bytes = blob != nullptr;
+    a.fixed = record_fixed_bytes(P, G);
+    a.tiles_off = a.fixed - size_t(P) * 1024;
+
+    // records are independent: build their images on all host cores, then lay them out in order.  The blob is
+    // byte-identical for any thread count.
+    std::vector<RecImage> imgs(NRB);
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (const char* env = std::getenv("PBL_PACK_THREADS")) nthreads = unsigned(std::max(1, std::atoi(env)));
+    nthreads = std::max(1u, std::min(std::min(nthreads, 64u), NRB / 8u + 1u));
+    std::atomic<uint32_t> next{0};
+    auto work = [&]() {
+        for (uint32_t b = next.fetch_add(1); b < NRB; b = next.fetch_add(1)) build_record(a, b, imgs[b]);
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (unsigned t = 1; t < nthreads; ++t) pool.emplace_back(work);
+    } catch (...) {
+        // thread limit reached: the threads that did start (and this one) share the work
+    }
+    work();
+    for (auto& t : pool) t.join();
+
     std::vector<pbl_rec_info> rb_info(NRB + 1);
     size_t cur = rec0;
     uint64_t nnz = 0, nexc_total = 0;
     uint32_t max_nch = 0, max_nexc = 0;
-    RecBuild rb;
-    std::vector<Entry> ents;
-    std::vector<uint32_t> tile(size_t(P) * 256);
-
     for (uint32_t b = 0; b < NRB; ++b) {
-        rb.clear();
-        std::fill(tile.begin(), tile.end(), 0u);
-        pbl_rowparams params[16];
-        std::memset(params, 0, sizeof(params));
-        std::vector<float> ghl;
-        if (G > 1) ghl.assign(size_t(16) * G * 2, 0.f);
-
-        for (int rho = 0; rho < 16; ++rho) {
-            const uint32_t r = b * 16 + rho;
-            rb.ri[rho].start = uint16_t(rb.col0_full.size());
-            rb.ri[rho].tailidx = uint16_t(rb.col0_tail.size());
-            if (r >= N) continue;
-            const float* w = W + size_t(r) * K;
-            const float ss = sscale ? sscale[r] : 0.f, sz = szero ? szero[r] : 0.f;
-            params[rho] = {hi[size_t(r) * G], lo[size_t(r) * G], ss, sz};
-            if (G > 1)
-                for (uint32_t g = 0; g < G; ++g) {
-                    ghl[(size_t(rho) * G + g) * 2 + 0] = hi[size_t(r) * G + g];
-                    ghl[(size_t(rho) * G + g) * 2 + 1] = lo[size_t(r) * G + g];
-                }
-            ents.clear();
-            for (uint32_t c = 0; c < K; ++c) {
-                const float v = w[c];
-                const uint32_t g = c / gs;
-                const float h = hi[size_t(r) * G + g], l = lo[size_t(r) * G + g];
-                const bool forced = sal_mask && sal_mask[size_t(r) * K + c];
-                int bit;
-                if (!forced && v == h) bit = 1;
-                else if (!forced && v == l) bit = 0;
-                else {
-                    bit = 1;  // sparse entries correct against `hi`
-                    bool coded = false;
-                    if (sscale && ss != 0.f && std::isfinite(v)) {
-                        float qf = std::nearbyint(v / ss + sz);
-                        for (int dq = 0; dq <= 2 && !coded; ++dq) {
-                            int q = int(qf) + (dq == 0 ? 0 : (dq == 1 ? 1 : -1));
-                            if (q >= 0 && q <= 255 && (sal16 ? dequant_f16(ss, sz, q) : dequant(ss, sz, q)) == v) {
-                                ents.push_back({uint16_t(c), uint8_t(q)});
-                                coded = true;
-                            }
-                        }
-                    }
-                    if (!coded) rb.exc.push_back({uint16_t(c), uint16_t(rho), v});
-                }
-                if (bit) {
-                    const uint32_t p = c / 512, cc = c % 512, i = cc / 128, l2 = (cc % 128) / 2, e = cc & 1;
-                    tile[(size_t(p) * 64 + l2) * 4 + i] |= 1u << bit_index(rho, int(e));
-                }
-            }
-            nnz += ents.size();
-            // greedy chunking: close at 16 entries or when the next column step exceeds PBL_MAX_GAP
-            size_t i = 0;
-            uint16_t nfull = 0, ntail = 0;
-            while (i < ents.size()) {
-                size_t j = i + 1;
-                while (j < ents.size() && j - i < 16 && ents[j].col - ents[j - 1].col <= PBL_MAX_GAP) ++j;
-                const size_t cnt = j - i;
-                uint8_t d[16] = {0}, q[16] = {0};
-                for (size_t k = 0; k < cnt; ++k) {
-                    d[k] = k ? uint8_t(2 * (ents[i + k].col - ents[i + k - 1].col)) : 0;  // byte step in the fp16 x tile
-                    q[k] = ents[i + k].code;
-                }
-                for (size_t k = cnt; k < 16; ++k) q[k] = q[cnt - 1];   // PBL_FLAG_TAIL_REPEAT: padding repeats the last entry
-                if (cnt == 16) {
-                    rb.col0_full.push_back(ents[i].col);
-                    rb.delta_full.insert(rb.delta_full.end(), d, d + 16);
-                    rb.code_full.insert(rb.code_full.end(), q, q + 16);
-                    rb.crow_full.push_back(uint8_t(rho));
-                    ++nfull;
-                } else {
-                    rb.col0_tail.push_back(ents[i].col);
-                    rb.delta_tail.insert(rb.delta_tail.end(), d, d + 16);
-                    rb.code_tail.insert(rb.code_tail.end(), q, q + 16);
-                    rb.tailcnt.push_back(uint8_t(cnt));
-                    rb.crow_tail.push_back(uint8_t(rho));
-                    ++ntail;
-                }
-                i = j;
-            }
-            if (ntail > 255) return PBL_ERR_UNSUPPORTED;
-            rb.ri[rho].nfull = nfull;
-            rb.ri[rho].ntail = uint8_t(ntail);
-        }
-
-        const size_t nfull = rb.col0_full.size(), ntail = rb.col0_tail.size(), nch = nfull + ntail;
-        if (nch > 65535) return PBL_ERR_UNSUPPORTED;
-        const size_t rec_bytes = fixed + record_sal_bytes(nch, ntail, rb.exc.size(), G > 1 || sal16);
-        rb_info[b] = {uint32_t(cur / 16), uint32_t(nfull), uint32_t(ntail), uint32_t(rb.exc.size())};
-        max_nch = std::max<uint32_t>(max_nch, uint32_t(nch));
-        max_nexc = std::max<uint32_t>(max_nexc, uint32_t(rb.exc.size()));
-        nexc_total += rb.exc.size();
+        const RecImage& im = imgs[b];
+        if (im.status != PBL_OK) return im.status;
+        rb_info[b] = {uint32_t(cur / 16), im.nfull, im.ntail, im.nexc};
+        max_nch = std::max(max_nch, im.nfull + im.ntail);
+        max_nexc = std::max(max_nexc, im.nexc);
+        nexc_total += im.nexc;
+        nnz += im.nnz;
         if (blob) {
-            if (cur + rec_bytes > cap) return PBL_ERR_CAPACITY;
-            uint8_t* rec = blob + cur;
-            std::memset(rec, 0, rec_bytes);
-            pbl_rec_header h = {uint32_t(nfull), uint32_t(ntail), uint32_t(rb.exc.size()), uint32_t(fixed)};
-            std::memcpy(rec, &h, sizeof(h));
-            std::memcpy(rec + 16, rb.ri, sizeof(rb.ri));
-            std::memcpy(rec + 16 + 128, params, sizeof(params));
-            if (G > 1) std::memcpy(rec + PBL_REC_GHL_OFF, ghl.data(), ghl.size() * 4);
-            std::memcpy(rec + tiles_off, tile.data(), tile.size() * 4);
-            uint8_t* s = rec + fixed;
-            const uint32_t nch32 = uint32_t(nch), ntail32 = uint32_t(ntail);
-            const bool has_crow = G > 1 || sal16;
-            uint16_t* col0 = reinterpret_cast<uint16_t*>(s);
-            for (size_t k = 0; k < nfull; ++k) col0[k] = rb.col0_full[k];
-            for (size_t k = 0; k < ntail; ++k) col0[nfull + k] = rb.col0_tail[k];
-            uint8_t* dl = s + PBL_SAL_DELTA_OFF(nch32);
-            if (nfull) std::memcpy(dl, rb.delta_full.data(), nfull * 16);
-            if (ntail) std::memcpy(dl + nfull * 16, rb.delta_tail.data(), ntail * 16);
-            uint8_t* cd = s + PBL_SAL_CODE_OFF(nch32);
-            if (nfull) std::memcpy(cd, rb.code_full.data(), nfull * 16);
-            if (ntail) std::memcpy(cd + nfull * 16, rb.code_tail.data(), ntail * 16);
-            if (ntail) std::memcpy(s + PBL_SAL_TAILCNT_OFF(nch32), rb.tailcnt.data(), ntail);
-            if (has_crow) {
-                uint8_t* cr = s + PBL_SAL_CROW_OFF(nch32, ntail32);
-                if (nfull) std::memcpy(cr, rb.crow_full.data(), nfull);
-                if (ntail) std::memcpy(cr + nfull, rb.crow_tail.data(), ntail);
-            }
-            if (!rb.exc.empty())
-                std::memcpy(s + PBL_SAL_EXC_OFF(nch32, ntail32, has_crow), rb.exc.data(), rb.exc.size() * sizeof(pbl_exception));
+            if (cur + im.rec_bytes > cap) return PBL_ERR_CAPACITY;
+            std::memcpy(blob + cur, im.bytes.data(), im.rec_bytes);
         }
-        cur += rec_bytes;
+        cur += im.rec_bytes;
     }
     rb_info[NRB] = {uint32_t(cur / 16), 0, 0, 0};
     *out_bytes = cur;
