@@ -22,3 +22,11 @@ def golden(name):
 @pytest.fixture(scope="session")
 def load_golden():
     return golden
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _libpbl_built():
+    """Every test needs libpbl.so (the packer lives in it): build it once if it is missing or stale (hipcc cross-compiles
+    gfx950 without a GPU; the build is lock-protected, so xdist workers do not race)."""
+    import __graft_entry__ as g
+    g.build()
