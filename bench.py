@@ -2,21 +2,31 @@
 """bench.py -- PB-linear GEMV stream benchmark (BASELINE.json metric).
 
 A "step" is one pass of the hot path over one batch of synthetic input: L
-(default 224 = the number of linears in llama-7b) independent llama-7b q_proj-shaped
+(default 224 = the number of linears in llama-7b) llama-7b q_proj-shaped
 partially-binarized linears (4096x4096, xnor low_frac=0.9 + 10 % int8 salient,
 groupsize -1, RTN structure from the oracle's restatement of gptq_pb) each applied to
-its own bs=1 fp16 activation vector, executed as ONE grouped HIP launch.  All inputs
-are resident in HBM before the timed region; the L layer blobs live at distinct HBM
-addresses (> 1.2 GB, beyond the 256 MiB Infinity Cache), so the stream is served by
-HBM, not by cache.
+its own bs=1 fp16 activation vector.  All inputs are resident in HBM before the timed
+region; the L layer blobs live at distinct HBM addresses (> 1.2 GB, beyond the 256 MiB
+Infinity Cache), so the stream is served by HBM, not by cache.
 
-value = layer-tokens/s = n_gpus * L * M * steps / t  (whole job).
-roofline.achieved = ALGORITHMIC bytes per launch / average launch duration, where
-B_alg(N,K,nnz,M) is SURVEY.md 8(d)'s formula (1 bit/weight sign plane + uint8 code
-and 8-bit index per salient + row params + row pointers + fp16 x and y).
+value = layer-tokens/s = L * M * steps / t  (whole job).
+roofline.achieved = ALGORITHMIC bytes per launch / average launch duration (HIP events on the
+launch stream), where B_alg(N,K,nnz,M) is SURVEY.md 8(d)'s formula (1 bit/weight sign plane +
+uint8 code and 8-bit index per salient + row params + row pointers + fp16 x and y).
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): each rank streams its own
-L layers and tokens (independent requests; no data-path collective): weak scaling.
+--gpus 1: ONE grouped HIP launch per step (BASELINE configs[1]).
+--gpus N > 1 (BASELINE configs[4]): the SAME L layers are sharded over N ranks with the
+LLaMA tensor-parallel mapping -- layer i plays role i % 7 of a decoder layer: q, k, v, gate, up are
+N-split (each rank owns a slice of the output rows, no exchange), o and down are K-split (each rank
+owns a slice of the input columns; the fp32 partial outputs of all K-split layers are summed by ONE
+all-reduce per step: RCCL, or the library's one-shot peer-to-peer all-reduce with --collective p2p).
+Total work is fixed: strong scaling.  `--parallel dp` keeps round 1's independent streams per rank.
+Run directly, `bench.py --gpus N` starts the N ranks itself (torch.distributed.run); started by
+torch.distributed.run it checks WORLD_SIZE == N.
+
+Clock pre-heat: a cold MI355X needs ~1 s of load before its clocks settle (20 timed steps are 6 ms);
+the SAME launch is therefore repeated for --preheat-s seconds (default 2.0, reported as `preheat_s`)
+before the W warm-up and K timed steps.  steps / warmup are exactly what the command line says.
 """
 import argparse
 import json
@@ -31,6 +41,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_PROFILE = os.path.join("profiles", "traffic_r02.json")
 
 
 def build_base_layers(n_distinct, N, K, low_frac, seed0):
@@ -38,35 +49,72 @@ def build_base_layers(n_distinct, N, K, low_frac, seed0):
     (structure only -- the oracle is not timed here and not on the product path)."""
     from oracle import pb_oracle as O
     from pb_llm_amd import synth
-    from pb_llm_amd.packing import pack_dense
     out = []
     for i in range(n_distinct):
         W = synth.llm_weight(N, K, seed=seed0 + i)
         mask = O.ptq_low_mask(W, low_frac, "magnitude", None, -1)
         r = O.ptq_rtn(W, mask, 8, -1)
-        p = pack_dense(r["W_fq"], r["scale"][0] + r["mean"][0], -r["scale"][0] + r["mean"][0],
-                       r["hscale"], r["hzero"], (~mask).astype(np.uint8))
-        out.append((p, r["W_fq"]))
+        out.append(dict(W=r["W_fq"], hi=(r["scale"][0] + r["mean"][0]).reshape(-1), lo=(-r["scale"][0] + r["mean"][0]).reshape(-1),
+                        ss=np.asarray(r["hscale"], np.float32).reshape(-1), sz=np.asarray(r["hzero"], np.float32).reshape(-1),
+                        sal=(~mask).astype(np.uint8)))
     return out
 
 
-def cpu_baseline(dense_layers, K, M, budget_s=12.0):
+def pack_slice(b, rows=None, cols=None):
+    """PBL1 blob of rows [r0, r1) x columns [c0, c1) of a base layer (levels / code grid are per ROW,
+    so every slice reproduces the full layer's values exactly)."""
+    from pb_llm_amd.packing import pack_dense
+    r0, r1 = rows if rows else (0, b["W"].shape[0])
+    c0, c1 = cols if cols else (0, b["W"].shape[1])
+    return pack_dense(b["W"][r0:r1, c0:c1], b["hi"][r0:r1], b["lo"][r0:r1], b["ss"][r0:r1], b["sz"][r0:r1],
+                      np.ascontiguousarray(b["sal"][r0:r1, c0:c1]))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(dense_layers, K, M, budget_s=8.0):
     """The reference's CPU path on this box's host cores, via the oracle's statement of it
-    (oracle/pb_oracle.py: torch_dense_linear = F.linear over the dense fake-quant fp32 weight, what
-    gptq_pb/run.py / eval_after_qat.py execute per layer), on a bounded
-    sample.  Also the QAT layer as written (weight re-simulated on every call, item 2)."""
+    (oracle/pb_oracle.py: torch_dense_linear = F.linear over the dense fake-quant weight, what
+    gptq_pb/run.py / eval_after_qat.py execute per layer; SURVEY 8(d) last row), on a bounded sample:
+    fp32 with every host thread (the headline `value`), fp16 with every thread, fp32 on one thread, and
+    the QAT layer as written (weight re-simulated on every call)."""
     from oracle import pb_oracle as O
     from pb_llm_amd import synth
     Ws = [torch.from_numpy(w) for w in dense_layers]
     xs = [torch.from_numpy(synth.activations((M, K), 900 + i, 21)).float() for i in range(len(Ws))]
-    for w, x in zip(Ws, xs):
-        O.torch_dense_linear(x, w)
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s:
-        for w, x in zip(Ws, xs):
+
+    def timed(ws, xv, budget):
+        for w, x in zip(ws, xv):
             O.torch_dense_linear(x, w)
-        n += len(Ws)
-    dt = time.perf_counter() - t0
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget:
+            for w, x in zip(ws, xv):
+                O.torch_dense_linear(x, w)
+            n += len(ws)
+        return n, time.perf_counter() - t0
+
+    threads = torch.get_num_threads()
+    n, dt = timed(Ws, xs, budget_s)
+    out = dict(value=n * M / dt, unit="layer-tokens/s", cores=threads, kind="port", cpu_model=cpu_model(),
+               sample=f"{n} fp32 F.linear calls (oracle.torch_dense_linear) over {len(Ws)} distinct dense "
+                      f"{Ws[0].shape[0]}x{K} fake-quant weights (cache-cold rotation), {dt:.1f} s",
+               ms_per_layer=1e3 * dt / n)
+    try:  # fp16 operands, as the reference's fp16 checkpoints would run on a CPU
+        W16, x16 = [w.half() for w in Ws], [x.half() for x in xs]
+        n16, dt16 = timed(W16, x16, budget_s / 2)
+        out["fp16_ms_per_layer"] = 1e3 * dt16 / n16
+        out["fp16_layer_tokens_per_s"] = n16 * M / dt16
+    except RuntimeError as e:  # no fp16 CPU kernel in this torch build
+        out["fp16_ms_per_layer"] = None
+        out["fp16_note"] = str(e)[:120]
     # as-written QAT forward: a few calls are enough (tens of ms each)
     w = Ws[0]
     mask = w.abs() > w.abs().flatten().kthvalue(int(0.9 * w.numel()))[0]
@@ -76,11 +124,19 @@ def cpu_baseline(dense_layers, K, M, budget_s=12.0):
     nq = 5
     for _ in range(nq):
         O.torch_qat_forward_as_written(xs[0], w, mask, scale)
-    qat_ms = 1e3 * (time.perf_counter() - t1) / nq
-    return dict(value=n * M / dt, unit="layer-tokens/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} fp32 F.linear calls (oracle.torch_dense_linear) over {len(Ws)} distinct dense "
-                       f"{Ws[0].shape[0]}x{K} fake-quant weights (cache-cold rotation), {dt:.1f} s",
-                ms_per_layer=1e3 * dt / n, qat_forward_as_written_ms_per_layer=qat_ms)
+    out["qat_forward_as_written_ms_per_layer"] = 1e3 * (time.perf_counter() - t1) / nq
+    torch.set_num_threads(1)
+    try:
+        n1, dt1 = timed(Ws, xs, budget_s / 2)
+        out["one_thread_fp32_ms_per_layer"] = 1e3 * dt1 / n1
+        out["one_thread_fp32_layer_tokens_per_s"] = n1 * M / dt1
+    finally:
+        torch.set_num_threads(threads)
+    return out
+
+
+# role of layer i in a llama decoder layer (SURVEY 8(e) "LLaMA layer mapping"): True = K-split (+ all-reduce)
+TP_KSPLIT_ROLE = (False, False, False, True, False, False, True)   # q k v o gate up down
 
 
 def main():
@@ -88,6 +144,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--preheat-s", type=float, default=2.0,
+                    help="seconds of the same launch before warm-up, so that clocks have settled (reported)")
     ap.add_argument("--layers", type=int, default=224)
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic weight sets (replicated to L blobs)")
     ap.add_argument("--N", type=int, default=4096)
@@ -96,24 +154,39 @@ def main():
     ap.add_argument("--low-frac", type=float, default=0.9)
     ap.add_argument("--mode", choices=["grouped", "graph", "eager"], default="grouped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--parallel", choices=["dp", "tp"], default="dp",
-                    help="dp: independent layer streams per rank (weak scaling, no collective); "
-                         "tp: every layer K-split across ranks + one RCCL all-reduce of the stacked fp32 partial "
-                         "outputs per step (strong scaling)")
+    ap.add_argument("--parallel", choices=["auto", "dp", "tp"], default="auto",
+                    help="auto: tp when --gpus > 1; tp: LLaMA tensor-parallel mapping of the layer stream + one "
+                         "all-reduce of the K-split partial outputs per step (strong scaling); dp: independent "
+                         "layer streams per rank (weak scaling, no collective)")
+    ap.add_argument("--collective", choices=["rccl", "p2p"], default="rccl",
+                    help="tp all-reduce: RCCL (torch.distributed) or libpbl's one-shot peer-to-peer all-reduce")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # started directly: become the launcher of N ranks, one per GPU (RCCL over xGMI)
+        if torch.cuda.device_count() < a.gpus:
+            sys.exit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+        port = os.environ.get("MASTER_PORT", "29511")
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                   f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", port,
+                                   os.path.abspath(__file__), *sys.argv[1:]])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ  # launched by torch.distributed.run (any world size, incl. 1)
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
-    dev = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == a.gpus
 
     import __graft_entry__ as ge
     ge.build()
@@ -121,42 +194,65 @@ def main():
     from pb_llm_amd.quant import PBLinear
     from pb_llm_amd.runtime import GroupedGemv
 
-    tp = a.parallel == "tp" and use_dist
+    parallel = a.parallel if a.parallel != "auto" else ("tp" if world > 1 else "dp")
+    tp = parallel == "tp" and world > 1
     base = build_base_layers(a.distinct, a.N, a.K, a.low_frac, seed0=1000 + (0 if tp else 17 * rank))
-    Kloc, c0 = a.K, 0
-    if tp:  # K-split every layer: this rank keeps columns [c0, c1)
-        from pb_llm_amd.packing import infer_levels, pack_dense
-        from pb_llm_amd.parallel import split_points, COL_ALIGN
+    xs_host = [synth.activations((a.M, a.K), 5000 + i + (0 if tp else 1000 * rank), 21) for i in range(a.layers)]
+
+    groups = []          # (GroupedGemv, needs_allreduce)
+    if tp:
+        from pb_llm_amd.parallel import split_points, COL_ALIGN, ROW_ALIGN
+        r0, r1 = split_points(a.N, world, ROW_ALIGN)[rank:rank + 2]
         c0, c1 = split_points(a.K, world, COL_ALIGN)[rank:rank + 2]
-        Kloc = c1 - c0
-        shards = []
-        for p_full, Wd in base:
-            hi, lo = infer_levels(Wd)
-            full = p_full.unpack().numpy()
-            assert np.array_equal(full, Wd)
-            # per-row levels / code grid are those of the FULL row, identical on every rank
-            from pb_llm_amd.packing import infer_code_grid
-            ss, sz = infer_code_grid(Wd, hi, lo)
-            shards.append((pack_dense(Wd[:, c0:c1], hi, lo, ss, sz), Wd))
-        base = shards
-    packed = [base[i % a.distinct][0].to(dev) for i in range(a.layers)]
-    # .to(dev) of a host blob allocates a fresh device buffer per call: L distinct HBM regions
-    assert len({p.blob.data_ptr() for p in packed}) == a.layers
-    grp = GroupedGemv(packed, None, M=a.M, device=dev, out_f32=tp)
-    for i, t in enumerate(grp.x):
-        xi = synth.activations((a.M, a.K), 5000 + i + (0 if tp else 1000 * rank), 21)
-        t.copy_(torch.from_numpy(np.ascontiguousarray(xi[:, c0:c0 + Kloc])))
+        nsh = [pack_slice(b, rows=(r0, r1)) for b in base]
+        ksh = [pack_slice(b, cols=(c0, c1)) for b in base]
+        n_ids = [i for i in range(a.layers) if not TP_KSPLIT_ROLE[i % 7]]
+        k_ids = [i for i in range(a.layers) if TP_KSPLIT_ROLE[i % 7]]
+        gn = GroupedGemv([nsh[i % a.distinct].to(dev) for i in n_ids], None, M=a.M, device=dev)
+        gk = GroupedGemv([ksh[i % a.distinct].to(dev) for i in k_ids], None, M=a.M, device=dev, out_f32=True)
+        for t, i in zip(gn.x, n_ids):
+            t.copy_(torch.from_numpy(xs_host[i]))
+        for t, i in zip(gk.x, k_ids):
+            t.copy_(torch.from_numpy(np.ascontiguousarray(xs_host[i][:, c0:c1])))
+        groups = [(gn, False), (gk, True)]
+        comm = None
+        if a.collective == "p2p":
+            from pb_llm_amd.parallel import P2PAllReduce
+            comm = P2PAllReduce(gk.y_all.numel(), dev)
+    else:
+        full = [pack_slice(b) for b in base]
+        packed = [full[i % a.distinct].to(dev) for i in range(a.layers)]
+        # .to(dev) of a host blob allocates a fresh device buffer per call: L distinct HBM regions
+        assert len({p.blob.data_ptr() for p in packed}) == a.layers
+        g = GroupedGemv(packed, None, M=a.M, device=dev)
+        for t, xh in zip(g.x, xs_host):
+            t.copy_(torch.from_numpy(xh))
+        groups = [(g, False)]
     torch.cuda.synchronize()
 
-    singles = [PBLinear(p, None) for p in packed] if a.mode != "grouped" else None
+    singles = None
+    if a.mode != "grouped":
+        singles = [(PBLinear(p, None), x) for g, _ in groups for p, x in zip(g.packed, g.x)]
+    kev = []            # (start, end) events around the GEMV launches of a step (tp only: the timed region also holds the collective)
 
-    def step():
+    def step(record=False):
         if a.mode == "grouped":
-            grp.launch()
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            for g, _ in groups:
+                g.launch()
+            if record:
+                e1.record()
+                kev.append((e0, e1))
             if tp:
-                dist.all_reduce(grp.y_all)
+                gk = groups[1][0]
+                if comm is not None:
+                    comm.all_reduce_(gk.y_all)
+                else:
+                    dist.all_reduce(gk.y_all)
         else:
-            for m, x in zip(singles, grp.x):
+            for m, x in singles:
                 m(x)
 
     graph = None
@@ -172,6 +268,23 @@ def main():
     else:
         run = step
 
+    # clock pre-heat: the same launch, for a fixed time (disclosed in the JSON line)
+    t_pre = time.perf_counter()
+    n_pre = 0
+    while a.preheat_s > 0:
+        for _ in range(32):
+            run()
+        n_pre += 32
+        torch.cuda.synchronize()
+        done = time.perf_counter() - t_pre >= a.preheat_s
+        if use_dist:   # every rank must leave the loop after the same number of collectives
+            flag = torch.tensor([int(done)], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            done = bool(flag.item())
+        if done:
+            break
+    preheat_s = time.perf_counter() - t_pre if a.preheat_s > 0 else 0.0
+
     for _ in range(a.warmup):
         run()
     torch.cuda.synchronize()
@@ -179,10 +292,14 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    rec = tp and a.mode == "grouped"
     t0 = time.perf_counter()
     e0.record()
     for _ in range(a.steps):
-        run()
+        if rec:
+            step(True)
+        else:
+            run()
     e1.record()
     torch.cuda.synchronize()
     if use_dist:
@@ -190,49 +307,57 @@ def main():
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_s = e0.elapsed_time(e1) * 1e-3
+    kern_s = sum(s.elapsed_time(e) for s, e in kev) * 1e-3 if kev else dev_s
     if use_dist:
-        tt = torch.tensor([wall, dev_s], device=dev, dtype=torch.float64)
+        tt = torch.tensor([wall, dev_s, kern_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, dev_s = tt.tolist()
+        wall, dev_s, kern_s = tt.tolist()
 
-    traffic = None
-    try:  # HBM bytes per launch from the committed PMC profile of this exact workload (never measured here)
-        tj = json.load(open(os.path.join(REPO, "profiles", "traffic_r01.json")))
-        key = f"N{a.N}_K{a.K}_L{a.layers}_M{a.M}_lf{a.low_frac}_{a.mode}"
-        if tj.get("workload_key") == key and not tp:
-            traffic = tj["hbm_bytes_per_launch"]
+    traffic, traffic_source = None, None
+    key = f"N{a.N}_K{a.K}_L{a.layers}_M{a.M}_lf{a.low_frac}_{a.mode}"
+    try:  # HBM bytes per launch: PMC passes cannot run inside this process; the value is read from the committed
+        # rocprofv3 profile of this exact workload and labelled with its source
+        tj = json.load(open(os.path.join(REPO, TRAFFIC_PROFILE)))
+        if tj.get("workload_key") == key and world == 1:
+            traffic, traffic_source = tj["hbm_bytes_per_launch"], TRAFFIC_PROFILE
     except (OSError, ValueError, KeyError):
         pass
     if rank == 0:
-        b_alg = grp.algorithmic_bytes()
-        launches = a.steps * (1 if a.mode == "grouped" else a.layers)
-        per_launch_s = dev_s / launches
-        b_launch = b_alg / (1 if a.mode == "grouped" else a.layers)
-        achieved = b_launch / per_launch_s / 1e9
+        b_alg = sum(g.algorithmic_bytes() for g, _ in groups)          # this rank's shards (the whole stream at N=1)
+        packed_b = sum(g.packed_bytes() for g, _ in groups)
+        nl = 1 if a.mode == "grouped" else a.layers
+        per_launch_s = kern_s / (a.steps * nl)
+        achieved = b_alg / nl / per_launch_s / 1e9
+        if tp:
+            par = (f"tp{world}: llama mapping, q/k/v/gate/up N-split (no exchange), o/down K-split + one "
+                   f"{'libpbl one-shot p2p' if a.collective == 'p2p' else 'RCCL'} all-reduce of "
+                   f"[{len(groups[1][0].packed)},{a.M},{a.N}] fp32 per step")
+        else:
+            par = f"dp{world} (independent layer streams, no collective)"
         out = {
             "metric": "PB-linear GEMV tokens/sec + achieved HBM GB/s, llama-7b 4096x4096 low_frac=0.9",
             "value": (1 if tp else world) * a.layers * a.M * a.steps / wall,
             "unit": "layer-tokens/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "preheat_s": round(preheat_s, 3),
             "ms_per_step": 1e3 * wall / a.steps,
             "higher_is_better": True, "scaling": "strong" if tp else "weak", "vs_baseline": None,
             "dtype": "f16 (x, y) / 1-bit + u8 weights, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"llama-7b q_proj {a.N}x{a.K} xnor low_frac={a.low_frac} + int8 salient, "
                                    f"bs={a.M} GEMV, stream of {a.layers} layer blobs at distinct HBM addresses "
                                    f"({a.distinct} distinct weight sets), mode={a.mode}",
-                       "layers_per_step": a.layers, "tokens": a.M,
-                       "parallelism": (f"tp{world} (every layer K-split, one RCCL all-reduce of [L,M,N] fp32 per step)" if tp
-                                       else f"dp{world} (independent layer streams, no collective)")},
+                       "layers_per_step": a.layers, "tokens": a.M, "parallelism": par},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "pbl_gemv_kernel<1,4>" if a.mode == "grouped" else "pbl_gemv_kernel<1,1>",
-                         "algorithmic_bytes_per_launch": b_launch,
-                         "packed_bytes_per_launch": grp.packed_bytes() / (1 if a.mode == "grouped" else a.layers),
+                         "algorithmic_bytes_per_launch": b_alg / nl,
+                         "packed_bytes_per_launch": packed_b / nl,
                          "us_per_launch": 1e6 * per_launch_s,
-                         "us_per_layer": 1e6 * dev_s / (a.steps * a.layers)},
+                         "us_per_layer": 1e6 * kern_s / (a.steps * a.layers),
+                         "note": ("per rank: bytes of rank 0's shards / the GEMV launches of a step" if tp else
+                                  "one grouped launch = the whole stream")},
         }
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline([b[1] for b in base], a.K, a.M)
+            out["cpu_baseline"] = cpu_baseline([b["W"] for b in base], a.K, a.M)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

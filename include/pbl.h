@@ -47,7 +47,8 @@
  *   +T    tiles[P]     1 KiB each: the sign plane of 16 rows x 512 columns (T = PBL_TILES_OFF(G) = 512 for G == 1)
  *   +off_sal: col0[nch] (u16, nch = nfull+ntail), delta[nch][16] (u8),
  *             code[nch][16] (u8), tailcnt[ntail_pad16] (u8), [flags & (HAS_GROUPS|SAL_F16)] crow[nch_pad16]
- *             (u8, row-in-block of each chunk), exc[nexc] (pbl_exception, 8 B)
+ *             (u8, row-in-block of each chunk), exc[nexc] (pbl_exception, 8 B),
+ *             slab[16][NS] (u32, version 2): the column-slab index of the salient lists, NS = ceil(K/256)
  *
  * Sign-plane tile p: lane l (0..63) owns 4 dwords at byte ((p*64+l)*4+i)*4, i=0..3.
  *   dword i covers columns c = 512p + 128i + 2l + e, e in {0,1}.
@@ -68,6 +69,17 @@
  *   0..nfull-1), then the tail chunks of row 0, row 1, ... (indices nfull..nch-1).
  *   rowinfo[r]: full chunks [start, start+nfull), tail chunks
  *   [hdr.nfull + tailidx, hdr.nfull + tailidx + ntail).
+ *
+ * Slab index (version 2, PBL_FLAG_SLABS): the GEMV walks a row's chunks from left to right; the matrix-core kernels
+ *   walk the COLUMNS in slabs of 256 and need, per (row, slab), the row's chunks that overlap the slab.  The chunks of
+ *   a row cover disjoint, ordered column intervals, so that is one contiguous range of its full chunks and one of its
+ *   tail chunks, and at most one chunk straddles a slab boundary.  slab[rho][s] packs
+ *     bits  0..15  fe: number of the row's full chunks whose first column is < 256 (s+1)
+ *     bits 16..23  te: the same for its tail chunks
+ *     bit  24      fback: a full chunk that starts left of column 256 s reaches into the slab
+ *     bit  25      tback: the same for a tail chunk
+ *   Full chunks overlapping slab s: [fe(s-1) - fback(s), fe(s)) relative to rowinfo.start, fe(-1) = 0; tails likewise
+ *   relative to rowinfo.tailidx.  (Computed by the kernel in round 1 with a per-launch counting sort.)
  */
 #ifndef PBL_H_
 #define PBL_H_
@@ -80,7 +92,8 @@ extern "C" {
 #endif
 
 #define PBL_MAGIC 0x314C4250u /* "PBL1" */
-#define PBL_VERSION 1
+#define PBL_VERSION 2
+#define PBL_SLAB_COLS 256
 #define PBL_ROWS_PER_BLOCK 16
 #define PBL_PANEL_COLS 512
 #define PBL_CHUNK 16
@@ -102,7 +115,14 @@ extern "C" {
 #define PBL_SAL_TAILCNT_OFF(nch) (PBL_SAL_CODE_OFF(nch) + PBL_ALIGN128((nch) * 16u))
 #define PBL_SAL_CROW_OFF(nch, ntail) (PBL_SAL_TAILCNT_OFF(nch) + PBL_ALIGN16(ntail))
 #define PBL_SAL_EXC_OFF(nch, ntail, has_crow) (PBL_SAL_CROW_OFF(nch, ntail) + ((has_crow) ? PBL_ALIGN16(nch) : 0u))
-#define PBL_SAL_BYTES(nch, ntail, nexc, has_crow) PBL_ALIGN128(PBL_SAL_EXC_OFF(nch, ntail, has_crow) + (nexc) * 8u)
+#define PBL_NSLABS(K) (((K) + PBL_SLAB_COLS - 1u) / PBL_SLAB_COLS)
+#define PBL_SAL_SLAB_OFF(nch, ntail, nexc, has_crow) PBL_ALIGN16(PBL_SAL_EXC_OFF(nch, ntail, has_crow) + (nexc) * 8u)
+#define PBL_SAL_BYTES(nch, ntail, nexc, has_crow, K) \
+    PBL_ALIGN128(PBL_SAL_SLAB_OFF(nch, ntail, nexc, has_crow) + 16u * PBL_NSLABS(K) * 4u)
+#define PBL_SLAB_FE(e) ((e) & 0xFFFFu)
+#define PBL_SLAB_TE(e) (((e) >> 16) & 0xFFu)
+#define PBL_SLAB_FBACK(e) (((e) >> 24) & 1u)
+#define PBL_SLAB_TBACK(e) (((e) >> 25) & 1u)
 
 typedef enum {
     PBL_OK = 0,
@@ -122,6 +142,10 @@ typedef enum {
                                     apply the fp16 rounding (v_cvt_pk_f16_f32), so the layer is reproduced
                                     bit-exactly. */
 #define PBL_FLAG_TAIL_REPEAT 0x4u /* tail-chunk padding repeats the last entry (step 0, same code); set by this packer */
+#define PBL_FLAG_SLABS 0x8u       /* the records carry the column-slab index; with PBL_FLAG_SAL_F16 it also promises that no
+                                     CODED salient has the value 0 (those are exception entries), so "fp16 value != 0" marks
+                                     the salient positions of an expanded tile */
+#define PBL_FLAG_KNOWN 0xFu
 
 typedef struct {
     uint32_t magic, version;
@@ -175,7 +199,11 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
                        const uint8_t* sal_mask, uint32_t flags /* PBL_FLAG_SAL_F16 or 0 */,
                        void* out, size_t out_capacity, size_t* out_bytes);
 
-/* Validate a host blob and fill a pbl_layer (blob/bias pointers are left NULL). */
+/* Validate a host blob and fill a pbl_layer (blob/bias pointers are left NULL).  The WHOLE structure is checked, not
+ * only the header: record offsets monotone, 128-byte aligned and inside the blob; every record's header equal to its
+ * rb_info entry and its size equal to the layout macros; rowinfo ranges consistent with the chunk counts; every chunk's
+ * columns, every exception's row / column and every slab entry in range; header maxima >= the per-record values.  A
+ * blob that passes cannot make pbl_unpack_dense_f32 or a kernel read outside it.  PBL_ERR_BAD_BLOB otherwise. */
 int pbl_blob_describe(const void* host_blob, size_t bytes, pbl_layer* out);
 
 /* Reconstruct the dense simulated weight (fp32 [N,K]) from a host blob
@@ -204,12 +232,25 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
  * fp16-representable to be exact (true for layers packed from an fp16 checkpoint). */
 int pbl_unpack_dev(const pbl_layer* layer, void* W_out, int out_f32, void* stream);
 
-/* Matrix-core kernel for 1 <= M <= 32 tokens, any layer with G == 1, K % 8 == 0, PBL_FLAG_TAIL_REPEAT and x
- * 16-B aligned (else PBL_ERR_UNSUPPORTED): ONE pass over the packed weights for all tokens; per 256-column
- * half panel the class-coded sign plane, the salient operand and a salient mask are expanded in LDS and
- * contracted with v_mfma_f32_16x16x32_f16; fp32 decode identical to the GEMV.  y fp16 (y_f32 == 0) or fp32.
+/* Matrix-core kernel for 1 <= M <= 32 tokens, any layer with G == 1, K % 8 == 0, PBL_FLAG_TAIL_REPEAT | PBL_FLAG_SLABS
+ * and x 16-B aligned (else PBL_ERR_UNSUPPORTED): ONE pass over the packed weights for all tokens.  A workgroup of 4
+ * waves owns 4 records and walks the columns in 256-column slabs; the slab of x is staged in LDS once for the 4 waves;
+ * per slab a wave builds class-coded sign-plane A fragments in registers, scatters its record's salient entries of the
+ * slab (found through the slab index) into an fp16 tile, derives the salient mask from that tile, and contracts with
+ * v_mfma_f32_16x16x32_f16; fp32 decode identical to the GEMV.  y fp16 (y_f32 == 0) or fp32.
  * pbl_linear_f16 routes M > 4 here by itself. */
 int pbl_gemm_mfma_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream);
+
+/* The same kernel with a K split: a layer with few records (N = 4096: 256) cannot fill 1024 SIMDs with one wave per
+ * record, so the column slabs are divided over up to KS workgroups per record group; each writes an fp32 partial
+ * y to `workspace` ([KS][M][N] floats, device, 16-B aligned) and a second small kernel adds them in a FIXED order
+ * (deterministic, no atomics).  pbl_mfma_workspace_bytes() is what this layer needs for M tokens (0: no split is used);
+ * workspace == NULL or too small: runs unsplit.  pbl_linear_f16_ws is pbl_linear_f16 with that workspace handed through. */
+size_t pbl_mfma_workspace_bytes(const pbl_layer* layer, int M);
+int pbl_gemm_mfma_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int pbl_linear_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* L independent layers in ONE launch (decode-time fused QKV / gate+up, and the
  * stream benchmark of SURVEY.md 8(d)).  layers_dev: DEVICE array of L pbl_layer;
@@ -276,6 +317,28 @@ int pbl_high_calibrate(const float* W, uint32_t N, uint32_t K, float maxq, float
 int pbl_gptq_block(float* W, uint32_t N, uint32_t K, uint32_t c0, uint32_t ncols, const float* U, const uint8_t* low_mask,
                    const float* hscale, const float* hzero, float maxq, const float* mean, const float* scale,
                    float* err_out, float* losses, int feedback, void* stream);
+
+/* ---------------- multi-GPU: one-shot all-reduce of K-split partial outputs -----------------------
+ * The reference has no multi-GPU path (evaluate.py:56-62).  One process per GPU; every rank creates one communication
+ * buffer with pbl_comm_alloc (THE exception to "nothing here allocates": a peer-mapped buffer must be its own
+ * allocation), exports it (pbl_ipc_export -> 64-byte handle, exchanged by the host layer, e.g. torch.distributed
+ * all_gather), opens the other ranks' handles (pbl_ipc_open) and then calls pbl_p2p_allreduce_f32 with the table of
+ * mapped pointers: x[0:n] (fp32, device) <- sum over ranks, in rank order (bit-identical on every rank), as ONE kernel:
+ * push to the peers' slots over xGMI, flag, bounded wait, local sum (csrc/pbl_comm.hip).  seq: 1, 2, 3, ... the same on
+ * every rank; max_elems: the capacity the buffers were sized for.  Asynchronous on `stream`, graph-capturable for a
+ * fixed seq parity pattern only (seq is a launch argument), so eager launches are the intended use. */
+#define PBL_P2P_MAX_WORLD 16
+#define PBL_P2P_MAX_BLOCKS 64
+#define PBL_IPC_HANDLE_BYTES 64
+size_t pbl_p2p_buffer_bytes(size_t max_elems);
+int pbl_comm_alloc(size_t bytes, void** dev_ptr_out);          /* zero-filled device memory, uncached where supported */
+int pbl_comm_free(void* dev_ptr);
+int pbl_ipc_export(void* dev_ptr, void* handle64_out);
+int pbl_ipc_open(const void* handle64, void** dev_ptr_out);
+int pbl_ipc_close(void* dev_ptr);
+int pbl_p2p_allreduce_f32(void* const* peer_bufs, int rank, int world, float* x, size_t n, size_t max_elems, uint32_t seq,
+                          void* stream);
+int pbl_p2p_check(const void* own_buf);                        /* SYNCHRONOUS debugging aid: 1 if a wait ever timed out */
 
 #ifdef __cplusplus
 }

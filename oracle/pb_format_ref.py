@@ -27,7 +27,7 @@ def read_header(blob: np.ndarray) -> dict:
     keys = ["magic", "version", "N", "K", "P", "G", "NRB", "flags", "max_nch", "max_nexc",
             "nnz", "nexc", "blob_bytes", "rb_off_pos", "r0", "r1", "r2"]
     h = dict(zip(keys, f))
-    assert h["magic"] == 0x314C4250 and h["version"] == 1, "bad PBL1 blob"
+    assert h["magic"] == 0x314C4250 and h["version"] == 2, "bad PBL1 (version 2) blob"
     assert h["blob_bytes"] == blob.size
     return h
 
@@ -93,9 +93,27 @@ def decode(blob: np.ndarray) -> np.ndarray:
                 assert (crow[int(ri["start"]): int(ri["start"]) + int(ri["nfull"])] == rho).all()
                 assert (crow[nfull + int(ri["tailidx"]): nfull + int(ri["tailidx"]) + int(ri["ntail"])] == rho).all()
         exc = rec[s: s + 8 * nexc].view(np.dtype([("col", "<u2"), ("row", "<u2"), ("value", "<f4")]))
+        s = _a16(s + 8 * nexc)
+        NS = (K + 255) // 256
+        assert h["flags"] & 0x8, "version 2 blobs carry the slab index (PBL_FLAG_SLABS)"
+        slab = rec[s: s + 16 * NS * 4].view(np.uint32).reshape(16, NS).astype(np.int64)
+        assert _a128(s + 16 * NS * 4) == rec.size, "record size disagrees with the layout"
         assert not (delta & 1).any(), "deltas are stored doubled"
         cols = col0[:, None] + np.cumsum(delta // 2, axis=1)
         sal16 = bool(h["flags"] & 0x2)   # PBL_FLAG_SAL_F16: values went through an fp16 round trip
+        # slab index, re-derived from the chunk lists: per (row, 256-column slab) the cumulative count of chunks that
+        # START left of the slab's right edge, and whether a chunk from the left reaches into the slab
+        for rho in range(16):
+            ri = rowinfo[rho]
+            fidx = np.arange(int(ri["start"]), int(ri["start"]) + int(ri["nfull"]))
+            tidx = nfull + np.arange(int(ri["tailidx"]), int(ri["tailidx"]) + int(ri["ntail"]))
+            for q in range(NS):
+                lo_c, hi_c = 256 * q, 256 * (q + 1)
+                e = int(slab[rho, q])
+                assert (e & 0xFFFF) == int((col0[fidx] < hi_c).sum()) and ((e >> 16) & 0xFF) == int((col0[tidx] < hi_c).sum())
+                assert ((e >> 24) & 1) == int(((col0[fidx] < lo_c) & (cols[fidx, -1] >= lo_c)).any())
+                assert ((e >> 25) & 1) == int(((col0[tidx] < lo_c) & (cols[tidx, -1] >= lo_c)).any())
+                assert (e >> 26) == 0
 
         def deq(ss, code_vals, sz):
             v = (ss * (code_vals - sz)).astype(np.float32)
@@ -111,6 +129,14 @@ def decode(blob: np.ndarray) -> np.ndarray:
                 W[b * 16 + rho, cols[ch, :n]] = deq(ss, code[ch, :n], sz)
                 if h["flags"] & 0x4:   # PBL_FLAG_TAIL_REPEAT: padding repeats the last entry with step 0
                     assert 1 <= n < 16 and (delta[ch, n:] == 0).all() and (code[ch, n:] == code[ch, n - 1]).all()
+        if sal16:   # PBL_FLAG_SLABS promise for fp16-checkpoint layers: no coded salient is zero
+            for rho in range(16):
+                ri = rowinfo[rho]
+                ss, sz = np.float32(params[rho, 2]), np.float32(params[rho, 3])
+                for ch in range(int(ri["start"]), int(ri["start"]) + int(ri["nfull"])):
+                    assert (deq(ss, code[ch], sz) != 0).all()
+                for t in range(int(ri["tailidx"]), int(ri["tailidx"]) + int(ri["ntail"])):
+                    assert (deq(ss, code[nfull + t, :tailcnt[t]], sz) != 0).all()
         for e in exc:
             W[b * 16 + int(e["row"]), int(e["col"])] = e["value"]
     return W[:N, :K].copy()

@@ -16,7 +16,10 @@ PBL_MAX_TOKENS_PER_LAUNCH = 4
 PBL_FLAG_HAS_GROUPS = 0x1
 PBL_FLAG_SAL_F16 = 0x2
 PBL_FLAG_TAIL_REPEAT = 0x4
+PBL_FLAG_SLABS = 0x8
 PBL_DTYPE_F32, PBL_DTYPE_F16, PBL_DTYPE_BF16 = 0, 1, 2
+(PBL_OK, PBL_ERR_INVALID_ARG, PBL_ERR_BAD_BLOB, PBL_ERR_UNSUPPORTED, PBL_ERR_MISALIGNED, PBL_ERR_CAPACITY, PBL_ERR_LAUNCH,
+ PBL_ERR_NOT_REPRESENTABLE) = (0, -1, -2, -3, -4, -5, -6, -7)
 
 
 class PblLayer(C.Structure):
@@ -42,9 +45,12 @@ class PblError(RuntimeError):
 _lib = None
 
 EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_blob_describe",
-           "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_gemm_mfma_f16", "pbl_gemv_f16_grouped",
+           "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_linear_f16_ws", "pbl_gemm_mfma_f16",
+           "pbl_gemm_mfma_f16_ws", "pbl_mfma_workspace_bytes", "pbl_gemv_f16_grouped",
            "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad",
-           "pbl_prep_workspace_bytes", "pbl_kth_pair", "pbl_outlier_mask", "pbl_quant8_rows", "pbl_high_calibrate", "pbl_gptq_block"]
+           "pbl_prep_workspace_bytes", "pbl_kth_pair", "pbl_outlier_mask", "pbl_quant8_rows", "pbl_high_calibrate", "pbl_gptq_block",
+           "pbl_p2p_buffer_bytes", "pbl_comm_alloc", "pbl_comm_free", "pbl_ipc_export", "pbl_ipc_open", "pbl_ipc_close",
+           "pbl_p2p_allreduce_f32", "pbl_p2p_check"]
 
 
 def lib() -> C.CDLL:
@@ -76,6 +82,12 @@ def lib() -> C.CDLL:
     L.pbl_linear_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
     L.pbl_gemm_mfma_f16.restype = C.c_int
     L.pbl_gemm_mfma_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
+    L.pbl_linear_f16_ws.restype = C.c_int
+    L.pbl_linear_f16_ws.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, sz, vp]
+    L.pbl_gemm_mfma_f16_ws.restype = C.c_int
+    L.pbl_gemm_mfma_f16_ws.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, sz, vp]
+    L.pbl_mfma_workspace_bytes.restype = sz
+    L.pbl_mfma_workspace_bytes.argtypes = [C.POINTER(PblLayer), C.c_int]
     L.pbl_gemv_f16_grouped.restype = C.c_int
     L.pbl_gemv_f16_grouped.argtypes = [vp, vp, vp, C.c_int, C.c_int, u32, u32, u32, u32, C.c_int, C.c_int, vp]
     L.pbl_qat_workspace_bytes.restype = sz
@@ -98,6 +110,22 @@ def lib() -> C.CDLL:
     L.pbl_high_calibrate.argtypes = [vp, u32, u32, C.c_float, vp, vp, vp]
     L.pbl_gptq_block.restype = C.c_int
     L.pbl_gptq_block.argtypes = [vp, u32, u32, u32, u32, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, C.c_int, vp]
+    L.pbl_p2p_buffer_bytes.restype = sz
+    L.pbl_p2p_buffer_bytes.argtypes = [sz]
+    L.pbl_comm_alloc.restype = C.c_int
+    L.pbl_comm_alloc.argtypes = [sz, C.POINTER(vp)]
+    L.pbl_comm_free.restype = C.c_int
+    L.pbl_comm_free.argtypes = [vp]
+    L.pbl_ipc_export.restype = C.c_int
+    L.pbl_ipc_export.argtypes = [vp, vp]
+    L.pbl_ipc_open.restype = C.c_int
+    L.pbl_ipc_open.argtypes = [vp, C.POINTER(vp)]
+    L.pbl_ipc_close.restype = C.c_int
+    L.pbl_ipc_close.argtypes = [vp]
+    L.pbl_p2p_allreduce_f32.restype = C.c_int
+    L.pbl_p2p_allreduce_f32.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp, sz, sz, u32, vp]
+    L.pbl_p2p_check.restype = C.c_int
+    L.pbl_p2p_check.argtypes = [vp]
     _lib = L
     return L
 

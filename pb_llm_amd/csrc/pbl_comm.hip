@@ -1,0 +1,157 @@
+// pbl_comm.hip -- one-shot all-reduce of the K-split partial outputs over peer-mapped buffers.
+//
+// The reference has no multi-GPU code (evaluate.py:56-62 "TODO: fix multi-gpu").  A K-split PB linear ends in a sum of
+// [M, N] fp32 partials over the ranks; at decode time that is 16 KB - 1 MB, far below the size where a ring collective
+// is bandwidth bound: RCCL's all-reduce costs tens of microseconds of protocol latency next to a ~1 us GEMV.  xGMI is
+// point to point (every GPU has a direct link to each of its 7 peers), so the latency-optimal exchange is ONE hop:
+//
+//   every rank r owns a buffer  { flags[2][P][B], data[2][P][cap] }  that all ranks have mapped (hipIpc, one process
+//   per GPU).  all-reduce number `seq` (set = seq & 1), block b of the launch, slice [lo, hi) of the vector:
+//     1. push:   for every peer p:  p.data[set][r][lo:hi] <- x[lo:hi]            (7 direct xGMI writes + 1 local)
+//     2. signal: system-scope release, then  p.flags[set][r][b] <- seq            (one 4-byte store per peer)
+//     3. wait:   until  own.flags[set][p][b] == seq  for every p                  (bounded spin, system-scope acquire)
+//     4. reduce: x[i] <- sum_p own.data[set][p][i]   in rank order                (identical bits on every rank)
+//   A slot of set s is rewritten at seq + 2; a peer can only be there after it has seen THIS rank's flag of seq + 1,
+//   which this rank raises after finishing step 4 of seq -- two sets are enough, no extra barrier.
+//   Blocks are independent (block b waits only for block b of the peers), so nothing requires co-residency.
+//
+// The buffers are allocated here (the one place libpbl allocates: a peer-mapped buffer must be its own hipMalloc
+// allocation so that its IPC handle maps exactly it), uncached, so peer writes and local polls never sit in an L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pbl.h"
+
+namespace {
+
+constexpr int MAXB = PBL_P2P_MAX_BLOCKS;
+constexpr int MAXW = PBL_P2P_MAX_WORLD;
+constexpr size_t HDR_BYTES = 4096;                       // flags[2][MAXW][MAXB] u32 = 4 KiB at 8 x 64; status word behind them
+
+__host__ __device__ inline size_t flags_bytes() { return size_t(2) * MAXW * MAXB * 4; }
+
+struct P2PArgs {
+    uint8_t* peer[MAXW];     // this process's mapping of every rank's buffer (peer[rank] = own)
+    float* x;                // in / out
+    size_t n, cap;
+    uint32_t seq;
+    int rank, world, nblk;
+};
+
+__device__ __forceinline__ uint32_t* flag_ptr(uint8_t* buf, int set, int src, int b) {
+    return reinterpret_cast<uint32_t*>(buf) + (size_t(set) * MAXW + src) * MAXB + b;
+}
+__device__ __forceinline__ float* slot_ptr(uint8_t* buf, int set, int src, size_t cap) {
+    return reinterpret_cast<float*>(buf + HDR_BYTES + flags_bytes()) + (size_t(set) * MAXW + src) * cap;
+}
+
+__global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
+    const int b = blockIdx.x, set = int(a.seq & 1u);
+    const size_t per = ((a.n + a.nblk - 1) / a.nblk + 3) & ~size_t(3);           // slice length, multiple of 4 floats
+    const size_t lo = size_t(b) * per, hi = lo + per < a.n ? lo + per : a.n;
+    const bool vec = ((reinterpret_cast<uintptr_t>(a.x) | (a.cap * 4)) & 15) == 0;
+    // 1. push my slice to every rank's slot [set][rank]
+    for (int p = 0; p < a.world; ++p) {
+        float* dst = slot_ptr(a.peer[p], set, a.rank, a.cap);
+        if (vec) {
+            for (size_t i = lo + size_t(threadIdx.x) * 4; i < hi; i += 1024) {
+                if (i + 4 <= hi) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(a.x + i);
+                else for (size_t j = i; j < hi; ++j) dst[j] = a.x[j];
+            }
+        } else {
+            for (size_t i = lo + threadIdx.x; i < hi; i += 256) dst[i] = a.x[i];
+        }
+    }
+    // 2. make the slice visible system wide, then raise my flag at every rank
+    __threadfence_system();
+    __syncthreads();
+    if (int(threadIdx.x) < a.world)
+        __hip_atomic_store(flag_ptr(a.peer[threadIdx.x], set, a.rank, b), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // 3. wait for every rank's flag (bounded: a lost peer must not hang the GPU; the status word records it)
+    if (int(threadIdx.x) < a.world) {
+        const uint32_t* f = flag_ptr(a.peer[a.rank], set, int(threadIdx.x), b);
+        const uint64_t t0 = wall_clock64();                                          // 100 MHz
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.seq) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 300000000ull) {                                  // 3 s
+                atomicExch(reinterpret_cast<uint32_t*>(a.peer[a.rank] + flags_bytes()), 1u);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    // 4. sum the P slots in rank order
+    const uint8_t* own = a.peer[a.rank];
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        float s = 0.f;
+        for (int p = 0; p < a.world; ++p)
+            s += __builtin_nontemporal_load(slot_ptr(const_cast<uint8_t*>(own), set, p, a.cap) + i);
+        a.x[i] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pbl_p2p_buffer_bytes(size_t max_elems) {
+    const size_t cap = (max_elems + 3) & ~size_t(3);
+    return HDR_BYTES + flags_bytes() + size_t(2) * MAXW * cap * sizeof(float);
+}
+
+int pbl_comm_alloc(size_t bytes, void** out) {
+    if (!out || !bytes) return PBL_ERR_INVALID_ARG;
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&p, bytes) != hipSuccess) return PBL_ERR_CAPACITY;
+    }
+    if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return PBL_ERR_LAUNCH; }
+    *out = p;
+    return PBL_OK;
+}
+
+int pbl_comm_free(void* p) { return (!p || hipFree(p) == hipSuccess) ? PBL_OK : PBL_ERR_INVALID_ARG; }
+
+int pbl_ipc_export(void* dev_ptr, void* handle64) {
+    static_assert(sizeof(hipIpcMemHandle_t) == PBL_IPC_HANDLE_BYTES, "handle size");
+    if (!dev_ptr || !handle64) return PBL_ERR_INVALID_ARG;
+    return hipIpcGetMemHandle(static_cast<hipIpcMemHandle_t*>(handle64), dev_ptr) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+int pbl_ipc_open(const void* handle64, void** out) {
+    if (!handle64 || !out) return PBL_ERR_INVALID_ARG;
+    hipIpcMemHandle_t h;
+    __builtin_memcpy(&h, handle64, sizeof(h));
+    return hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+int pbl_ipc_close(void* p) { return (p && hipIpcCloseMemHandle(p) == hipSuccess) ? PBL_OK : PBL_ERR_INVALID_ARG; }
+
+int pbl_p2p_allreduce_f32(void* const* peer_bufs, int rank, int world, float* x, size_t n, size_t max_elems, uint32_t seq,
+                          void* stream) {
+    if (!peer_bufs || !x || world < 1 || world > MAXW || rank < 0 || rank >= world || !n || seq == 0) return PBL_ERR_INVALID_ARG;
+    const size_t cap = (max_elems + 3) & ~size_t(3);
+    if (n > cap) return PBL_ERR_CAPACITY;
+    P2PArgs a;
+    for (int p = 0; p < MAXW; ++p) a.peer[p] = p < world ? static_cast<uint8_t*>(peer_bufs[p]) : nullptr;
+    for (int p = 0; p < world; ++p) if (!a.peer[p]) return PBL_ERR_INVALID_ARG;
+    a.x = x; a.n = n; a.cap = cap; a.seq = seq; a.rank = rank; a.world = world;
+    a.nblk = int((n + 4095) / 4096);
+    if (a.nblk > MAXB) a.nblk = MAXB;
+    if (a.nblk < 1) a.nblk = 1;
+    void* argv[] = {&a};
+    return hipLaunchKernel(reinterpret_cast<const void*>(p2p_allreduce_kernel), dim3(a.nblk), dim3(256), argv, 0,
+                           static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+int pbl_p2p_check(const void* own_buf) {
+    // debugging aid, SYNCHRONOUS: reads the status word behind the flags (1 = a wait timed out since the buffer was created)
+    if (!own_buf) return PBL_ERR_INVALID_ARG;
+    uint32_t w = 0;
+    if (hipMemcpy(&w, static_cast<const uint8_t*>(own_buf) + flags_bytes(), 4, hipMemcpyDeviceToHost) != hipSuccess) return PBL_ERR_LAUNCH;
+    return int(w);
+}
+
+}  // extern "C"

@@ -31,8 +31,10 @@ struct RecBuild {
     std::vector<uint16_t> col0_full, col0_tail;
     std::vector<uint8_t> delta_full, code_full, delta_tail, code_tail, tailcnt, crow_full, crow_tail;
     std::vector<pbl_exception> exc;
+    std::vector<uint32_t> slab;     // [16][NS]
     pbl_rowinfo ri[16];
     void clear() {
+        slab.clear();
         col0_full.clear(); col0_tail.clear(); delta_full.clear(); code_full.clear();
         delta_tail.clear(); code_tail.clear(); tailcnt.clear(); exc.clear(); crow_full.clear(); crow_tail.clear();
         std::memset(ri, 0, sizeof(ri));
@@ -47,8 +49,8 @@ inline int bit_index(int rho, int e) {
 
 size_t record_fixed_bytes(uint32_t P, uint32_t G) { return size_t(PBL_TILES_OFF(G)) + size_t(P) * 1024; }
 
-size_t record_sal_bytes(size_t nch, size_t ntail, size_t nexc, bool has_crow) {
-    return PBL_SAL_BYTES(uint32_t(nch), uint32_t(ntail), uint32_t(nexc), has_crow);
+size_t record_sal_bytes(size_t nch, size_t ntail, size_t nexc, bool has_crow, uint32_t K) {
+    return PBL_SAL_BYTES(uint32_t(nch), uint32_t(ntail), uint32_t(nexc), has_crow, K);
 }
 
 }  // namespace
@@ -134,6 +136,9 @@ void build_record(const PackArgs& a, uint32_t b, RecImage& out) {
                     for (int dq = 0; dq <= 2 && !coded; ++dq) {
                         int q = int(qf) + (dq == 0 ? 0 : (dq == 1 ? 1 : -1));
                         if (q >= 0 && q <= 255 && (a.sal16 ? dequant_f16(ss, sz, q) : dequant(ss, sz, q)) == v) {
+                            // PBL_FLAG_SLABS promise: in an fp16-checkpoint layer no CODED salient is zero (the
+                            // matrix-core kernels read "value != 0" as "salient"); a zero goes to the exception list
+                            if (a.sal16 && v == 0.f) break;
                             ents.push_back({uint16_t(c), uint8_t(q)});
                             coded = true;
                         }
@@ -150,10 +155,19 @@ void build_record(const PackArgs& a, uint32_t b, RecImage& out) {
         // greedy chunking: close at 16 entries or when the next column step exceeds PBL_MAX_GAP
         size_t i = 0;
         uint16_t nfull = 0, ntail = 0;
+        const uint32_t NS = PBL_NSLABS(K);
+        if (rb.slab.empty()) rb.slab.assign(size_t(16) * NS, 0u);
+        std::vector<uint32_t> fe(NS, 0u), te(NS, 0u), fb(NS, 0u), tb(NS, 0u);
         while (i < ents.size()) {
             size_t j = i + 1;
             while (j < ents.size() && j - i < 16 && ents[j].col - ents[j - 1].col <= PBL_MAX_GAP) ++j;
             const size_t cnt = j - i;
+            {   // slab index: the chunk covers columns [first, last]
+                const uint32_t s0 = ents[i].col / PBL_SLAB_COLS, s1 = ents[j - 1].col / PBL_SLAB_COLS;
+                const bool full = cnt == 16;
+                for (uint32_t s = s0; s < NS; ++s) (full ? fe : te)[s] += 1;          // first column < 256 (s+1)
+                for (uint32_t s = s0 + 1; s <= s1; ++s) (full ? fb : tb)[s] = 1;     // reaches in from the left
+            }
             uint8_t d[16] = {0}, q[16] = {0};
             for (size_t k = 0; k < cnt; ++k) {
                 d[k] = k ? uint8_t(2 * (ents[i + k].col - ents[i + k - 1].col)) : 0;  // byte step in the fp16 x tile
@@ -179,12 +193,14 @@ void build_record(const PackArgs& a, uint32_t b, RecImage& out) {
         if (ntail > 255) { out.status = PBL_ERR_UNSUPPORTED; return; }
         rb.ri[rho].nfull = nfull;
         rb.ri[rho].ntail = uint8_t(ntail);
+        for (uint32_t s = 0; s < NS; ++s) rb.slab[size_t(rho) * NS + s] = fe[s] | (te[s] << 16) | (fb[s] << 24) | (tb[s] << 25);
     }
+    if (rb.slab.empty()) rb.slab.assign(size_t(16) * PBL_NSLABS(K), 0u);
 
     const size_t nfull = rb.col0_full.size(), ntail = rb.col0_tail.size(), nch = nfull + ntail;
     if (nch > 65535) { out.status = PBL_ERR_UNSUPPORTED; return; }
     const bool has_crow = G > 1 || a.sal16;
-    out.rec_bytes = a.fixed + record_sal_bytes(nch, ntail, rb.exc.size(), has_crow);
+    out.rec_bytes = a.fixed + record_sal_bytes(nch, ntail, rb.exc.size(), has_crow, K);
     out.nfull = uint32_t(nfull); out.ntail = uint32_t(ntail); out.nexc = uint32_t(rb.exc.size()); out.nnz = nnz;
     if (!a.want_bytes) return;
     out.bytes.assign(out.rec_bytes, 0);
@@ -214,6 +230,7 @@ void build_record(const PackArgs& a, uint32_t b, RecImage& out) {
     }
     if (!rb.exc.empty())
         std::memcpy(s + PBL_SAL_EXC_OFF(nch32, ntail32, has_crow), rb.exc.data(), rb.exc.size() * sizeof(pbl_exception));
+    std::memcpy(s + PBL_SAL_SLAB_OFF(nch32, ntail32, uint32_t(rb.exc.size()), has_crow), rb.slab.data(), rb.slab.size() * 4);
 }
 
 }  // namespace
@@ -284,7 +301,7 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
         pbl_blob_header h;
         std::memset(&h, 0, sizeof(h));
         h.magic = PBL_MAGIC; h.version = PBL_VERSION; h.N = N; h.K = K; h.P = P; h.G = G; h.NRB = NRB;
-        h.flags = (G > 1 ? PBL_FLAG_HAS_GROUPS : 0) | (sal16 ? PBL_FLAG_SAL_F16 : 0) | PBL_FLAG_TAIL_REPEAT;
+        h.flags = (G > 1 ? PBL_FLAG_HAS_GROUPS : 0) | (sal16 ? PBL_FLAG_SAL_F16 : 0) | PBL_FLAG_TAIL_REPEAT | PBL_FLAG_SLABS;
         h.max_nch = max_nch; h.max_nexc = max_nexc; h.nnz = nnz; h.nexc = nexc_total;
         h.blob_bytes = cur; h.rb_off_pos = uint32_t(rboff_pos);
         std::memcpy(blob, &h, sizeof(h));
@@ -299,7 +316,80 @@ int pbl_blob_describe(const void* host_blob, size_t bytes, pbl_layer* out) {
     pbl_blob_header h;
     std::memcpy(&h, host_blob, sizeof(h));
     if (h.magic != PBL_MAGIC || h.version != PBL_VERSION || h.blob_bytes != bytes) return PBL_ERR_BAD_BLOB;
+    if (h.N == 0 || h.K == 0 || h.K > 32767 || h.N > (1u << 24)) return PBL_ERR_BAD_BLOB;
     if (h.P != (h.K + 511) / 512 || h.NRB != (h.N + 15) / 16 || h.G == 0) return PBL_ERR_BAD_BLOB;
+    if (h.G > 1 && (h.K % h.G != 0 || (h.K / h.G) % 128 != 0)) return PBL_ERR_BAD_BLOB;
+    if ((h.flags & ~PBL_FLAG_KNOWN) || !(h.flags & PBL_FLAG_SLABS) || !(h.flags & PBL_FLAG_TAIL_REPEAT)) return PBL_ERR_BAD_BLOB;
+    if (bool(h.flags & PBL_FLAG_HAS_GROUPS) != (h.G > 1) || h.rb_off_pos != sizeof(pbl_blob_header)) return PBL_ERR_BAD_BLOB;
+    {   // walk every record: nothing below trusts a count or an offset it has not bounded first
+        const uint8_t* blob = static_cast<const uint8_t*>(host_blob);
+        const size_t rec0 = align128(sizeof(pbl_blob_header) + size_t(h.NRB + 1) * sizeof(pbl_rec_info));
+        if (rec0 > bytes) return PBL_ERR_BAD_BLOB;
+        const pbl_rec_info* info = reinterpret_cast<const pbl_rec_info*>(blob + h.rb_off_pos);
+        const size_t fixed = record_fixed_bytes(h.P, h.G);
+        const bool has_crow = h.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16);
+        const uint32_t NS = PBL_NSLABS(h.K);
+        uint64_t nnz = 0, nexc = 0;
+        size_t expect = rec0;
+        for (uint32_t b = 0; b < h.NRB; ++b) {
+            const pbl_rec_info ri = info[b];
+            const size_t off = size_t(ri.off16) * 16;
+            if (off != expect) return PBL_ERR_BAD_BLOB;                       // contiguous, hence monotone and 128-aligned
+            const uint64_t nch = uint64_t(ri.nfull) + ri.ntail;
+            if (nch > 65535 || nch > h.max_nch || ri.nexc > h.max_nexc) return PBL_ERR_BAD_BLOB;
+            const size_t rbytes = fixed + record_sal_bytes(nch, ri.ntail, ri.nexc, has_crow, h.K);
+            if (off + rbytes > bytes || off + rbytes < off) return PBL_ERR_BAD_BLOB;
+            expect = off + rbytes;
+            const uint8_t* rec = blob + off;
+            pbl_rec_header rh;
+            std::memcpy(&rh, rec, sizeof(rh));
+            if (rh.nfull != ri.nfull || rh.ntail != ri.ntail || rh.nexc != ri.nexc || rh.off_sal != fixed) return PBL_ERR_BAD_BLOB;
+            const pbl_rowinfo* row = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF);
+            uint32_t sf = 0, st = 0;
+            for (int r = 0; r < 16; ++r) {                                    // rows own consecutive ranges of both lists
+                if (row[r].start != sf || row[r].tailidx != st) return PBL_ERR_BAD_BLOB;
+                sf += row[r].nfull; st += row[r].ntail;
+            }
+            if (sf != ri.nfull || st != ri.ntail) return PBL_ERR_BAD_BLOB;
+            const uint8_t* s = rec + fixed;
+            const uint32_t nch32 = uint32_t(nch);
+            const uint16_t* col0 = reinterpret_cast<const uint16_t*>(s);
+            const uint8_t* delta = s + PBL_SAL_DELTA_OFF(nch32);
+            const uint8_t* tailcnt = s + PBL_SAL_TAILCNT_OFF(nch32);
+            const uint8_t* crow = s + PBL_SAL_CROW_OFF(nch32, ri.ntail);
+            for (uint32_t c = 0; c < nch32; ++c) {
+                const uint32_t cnt = c < ri.nfull ? 16u : tailcnt[c - ri.nfull];
+                if (cnt < 1 || cnt > 16 || (c >= ri.nfull && cnt == 16) || delta[size_t(c) * 16] != 0) return PBL_ERR_BAD_BLOB;
+                uint32_t col = col0[c];
+                for (uint32_t k = 1; k < 16; ++k) {
+                    const uint32_t d = delta[size_t(c) * 16 + k];
+                    if ((d & 1u) || (k < cnt ? d == 0 : d != 0)) return PBL_ERR_BAD_BLOB;   // doubled steps, strictly rising, padding steps 0
+                    col += d / 2;
+                }
+                if (col >= h.K) return PBL_ERR_BAD_BLOB;
+                if (has_crow && crow[c] > 15) return PBL_ERR_BAD_BLOB;
+                nnz += cnt;
+            }
+            const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(s + PBL_SAL_EXC_OFF(nch32, ri.ntail, has_crow));
+            for (uint32_t k = 0; k < ri.nexc; ++k)
+                if (exc[k].col >= h.K || exc[k].row > 15) return PBL_ERR_BAD_BLOB;
+            nexc += ri.nexc;
+            const uint32_t* slab = reinterpret_cast<const uint32_t*>(s + PBL_SAL_SLAB_OFF(nch32, ri.ntail, ri.nexc, has_crow));
+            for (int r = 0; r < 16; ++r) {
+                uint32_t pf = 0, pt = 0;
+                for (uint32_t q = 0; q < NS; ++q) {
+                    const uint32_t e = slab[size_t(r) * NS + q];
+                    const uint32_t f = PBL_SLAB_FE(e), t = PBL_SLAB_TE(e);
+                    if ((e >> 26) || f < pf || t < pt || f > row[r].nfull || t > row[r].ntail) return PBL_ERR_BAD_BLOB;
+                    if (PBL_SLAB_FBACK(e) > pf || PBL_SLAB_TBACK(e) > pt) return PBL_ERR_BAD_BLOB;
+                    pf = f; pt = t;
+                }
+                if (pf != row[r].nfull || pt != row[r].ntail) return PBL_ERR_BAD_BLOB;   // the last slab has seen every chunk
+            }
+        }
+        if (expect != bytes || size_t(info[h.NRB].off16) * 16 != bytes) return PBL_ERR_BAD_BLOB;
+        if (nnz != h.nnz || nexc != h.nexc) return PBL_ERR_BAD_BLOB;
+    }
     out->blob = nullptr; out->bias = nullptr;
     out->N = h.N; out->K = h.K; out->P = h.P; out->G = h.G; out->NRB = h.NRB; out->flags = h.flags;
     out->max_nch = h.max_nch; out->max_nexc = h.max_nexc;

@@ -941,6 +941,11 @@ size_t pbl_gemv_lds_bytes(const pbl_layer* layer, int m) {
 }
 
 int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream) {
+    return pbl_linear_f16_ws(layer, x, y, M, y_f32, nullptr, 0, stream);
+}
+
+int pbl_linear_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* workspace, size_t workspace_bytes,
+                      void* stream) {
     if (!layer || !layer->blob || !x || !y || M < 1) return PBL_ERR_INVALID_ARG;
     if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -958,12 +963,12 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
     // more than one GEMV pass: the matrix-core kernel streams the weights once per 32 tokens instead of once
     // per 4 (tiny layers at M <= 8 stay on the GEMV: both are launch-latency bound and the GEMV starts faster)
     if (M > mb_max && (M > 8 || layer->NRB >= 128) && !(layer->K & 7) &&
-        (layer->flags & PBL_FLAG_TAIL_REPEAT) && !(reinterpret_cast<uintptr_t>(x) & 15)) {
+        (layer->flags & PBL_FLAG_TAIL_REPEAT) && (layer->flags & PBL_FLAG_SLABS) && !(reinterpret_cast<uintptr_t>(x) & 15)) {
         int m0 = 0, rc = PBL_OK;
         for (; m0 < M && rc == PBL_OK; m0 += 32) {
             const int mb = M - m0 < 32 ? M - m0 : 32;
-            rc = pbl_gemm_mfma_f16(layer, static_cast<const _Float16*>(x) + size_t(m0) * layer->K,
-                                   static_cast<char*>(y) + size_t(m0) * layer->N * esz, mb, y_f32, stream);
+            rc = pbl_gemm_mfma_f16_ws(layer, static_cast<const _Float16*>(x) + size_t(m0) * layer->K,
+                                      static_cast<char*>(y) + size_t(m0) * layer->N * esz, mb, y_f32, workspace, workspace_bytes, stream);
         }
         if (rc != PBL_ERR_UNSUPPORTED) return rc;   // unsupported (LDS budget): every slab failed the same way, fall through
     }

@@ -23,6 +23,9 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+import ctypes as C
+
+from . import _lib
 from .quant import PBLinear, pb_linear_forward
 
 ROW_ALIGN = 16     # records are 16 rows
@@ -63,12 +66,13 @@ def shard_linear(W_fq: torch.Tensor, bias, low_mask, mode: str, rank: int, world
             from .packing import infer_levels, infer_code_grid, pack_dense
             Wn = W_fq.detach().cpu().float().numpy()
             hi_l, lo_l = infer_levels(Wn, -1, None)
+            f16 = W_fq.dtype == torch.float16      # fp16 checkpoint: salients are fl16(scale*(q-zero)), like from_dense
             if high_scale is None:
-                ss, sz = infer_code_grid(Wn, hi_l, lo_l, -1)
+                ss, sz = infer_code_grid(Wn, hi_l, lo_l, -1, sal_f16=f16)
             else:
                 ss = np.asarray(high_scale, np.float32).reshape(-1)
                 sz = np.asarray(high_zero, np.float32).reshape(-1)
-            shard = PBLinear(pack_dense(Wn[:, sl], hi_l, lo_l, ss, sz), bias if rank == 0 else None, W_fq.dtype)
+            shard = PBLinear(pack_dense(Wn[:, sl], hi_l, lo_l, ss, sz, sal_f16=f16), bias if rank == 0 else None, W_fq.dtype)
         else:
             shard = PBLinear.from_dense(W_fq[:, sl], bias if rank == 0 else None,
                                         None if low_mask is None else low_mask[:, sl], groupsize,
@@ -76,6 +80,70 @@ def shard_linear(W_fq: torch.Tensor, bias, low_mask, mode: str, rank: int, world
     else:
         raise ValueError("mode must be 'n' or 'k'")
     return shard, (lo, hi)
+
+
+class P2PAllReduce:
+    """One-shot fp32 sum all-reduce over peer-mapped buffers (libpbl, csrc/pbl_comm.hip): the native
+    collective for the small messages of K-split decode, where RCCL's all-reduce is latency bound.  One process per GPU.
+    Every rank allocates one communication buffer through libpbl, the 64-byte IPC handles travel through
+    torch.distributed (any backend: gloo in the one-GPU test, RCCL on a node), every rank maps the others' buffers.
+    all_reduce_(t) then is a single kernel launch on the current stream: push to 7 peers over xGMI, flag, wait, local
+    sum in rank order (bit-identical on every rank).  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC)."""
+
+    def __init__(self, max_numel: int, device, group=None):
+        self.group, self.device = group, torch.device(device)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > 16:
+            raise ValueError("at most 16 ranks")
+        self.max_numel = int(max_numel)
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            own = C.c_void_p()
+            _lib.check(L.pbl_comm_alloc(L.pbl_p2p_buffer_bytes(self.max_numel), C.byref(own)), "comm_alloc")
+            self._own = own.value
+            handle = (C.c_ubyte * 64)()
+            _lib.check(L.pbl_ipc_export(self._own, handle), "ipc_export")
+            handles = [None] * self.world
+            dist.all_gather_object(handles, bytes(handle), group=group)
+            self._ptrs = (C.c_void_p * self.world)()
+            self._opened = []
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    self._ptrs[r] = self._own
+                    continue
+                ptr = C.c_void_p()
+                buf = (C.c_ubyte * 64).from_buffer_copy(h)
+                _lib.check(L.pbl_ipc_open(buf, C.byref(ptr)), f"ipc_open(rank {r})")
+                self._ptrs[r] = ptr.value
+                self._opened.append(ptr.value)
+        self.seq = 0
+        dist.barrier(group=group)            # nobody launches before everybody has mapped everybody
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+            raise _lib.PblError("P2PAllReduce: contiguous fp32 tensor on the communicator's device")
+        if t.numel() > self.max_numel:
+            raise _lib.PblError(f"P2PAllReduce sized for {self.max_numel} elements, got {t.numel()}")
+        self.seq += 1
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib().pbl_p2p_allreduce_f32(self._ptrs, self.rank, self.world, t.data_ptr(), t.numel(), self.max_numel,
+                                                    self.seq, st), "p2p_allreduce")
+        return t
+
+    def check(self) -> None:
+        """synchronous: raises if any wait timed out since construction (a peer died or never launched)"""
+        if _lib.lib().pbl_p2p_check(self._own) != 0:
+            raise _lib.PblError("P2PAllReduce: a peer's flag did not arrive within the bounded wait")
+
+    def close(self):
+        L = _lib.lib()
+        if getattr(self, "_own", None):
+            torch.cuda.synchronize(self.device)
+            dist.barrier(group=self.group)   # no peer may still be writing into a buffer that is about to go
+            for p in self._opened:
+                L.pbl_ipc_close(p)
+            L.pbl_comm_free(self._own)
+            self._own, self._opened = None, []
 
 
 class PBLinearNSplit(nn.Module):
@@ -107,9 +175,17 @@ class PBLinearNSplit(nn.Module):
 class PBLinearKSplit(nn.Module):
     """Input columns split across ranks; partial outputs summed by one all-reduce (fp32)."""
 
-    def __init__(self, shard: PBLinear, cols: tuple[int, int], group=None, input_is_sharded: bool = False):
+    def __init__(self, shard: PBLinear, cols: tuple[int, int], group=None, input_is_sharded: bool = False,
+                 collective: str = "rccl", max_tokens: int = 64):
+        """collective: "rccl" = torch.distributed all_reduce (RCCL over xGMI on a node); "p2p" = libpbl's one-shot
+        peer-to-peer all-reduce (P2PAllReduce) for up to `max_tokens` rows, RCCL above that."""
         super().__init__()
         self.shard, self.cols, self.group, self.input_is_sharded = shard, cols, group, input_is_sharded
+        if collective not in ("rccl", "p2p"):
+            raise ValueError("collective must be 'rccl' or 'p2p'")
+        self.comm = None
+        if collective == "p2p":
+            self.comm = P2PAllReduce(max_tokens * shard.out_features, shard.pbl_blob.device, group)
 
     def local_forward(self, x_local):
         """fp32 partial y of this rank's column slice (bias lives on rank 0 only)."""
@@ -118,5 +194,8 @@ class PBLinearKSplit(nn.Module):
     def forward(self, x):
         xl = x if self.input_is_sharded else x[..., self.cols[0]:self.cols[1]]
         y = self.local_forward(xl).float().contiguous()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        if self.comm is not None and y.numel() <= self.comm.max_numel:
+            self.comm.all_reduce_(y)
+        else:
+            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         return y.to(x.dtype)

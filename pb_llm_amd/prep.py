@@ -12,14 +12,12 @@ import torch
 from . import _lib
 from .qat import _DT, _need_gpu, _stream, binary_scale
 
-_workspaces: dict = {}
+QUANT8_MAX_K = 16384     # pbl_quant8_rows stages a whole row in LDS
 
 
 def _ws(device) -> torch.Tensor:
-    ws = _workspaces.get(str(device))
-    if ws is None:
-        ws = _workspaces[str(device)] = torch.empty(_lib.lib().pbl_prep_workspace_bytes(), dtype=torch.uint8, device=device)
-    return ws
+    """radix-select scratch, per call from the caching allocator (stream-ordered: no state shared between streams)"""
+    return torch.empty(_lib.lib().pbl_prep_workspace_bytes(), dtype=torch.uint8, device=device)
 
 
 def kth_pair(W: torch.Tensor, k_lo: int, k_hi: int) -> torch.Tensor:
@@ -63,5 +61,15 @@ def gen_outlier_mask_magnitude_(W: torch.Tensor, outlier_fraction: float):
     thr = kth_pair(W, int(n * outlier_fraction / 2), int(n * (1 - outlier_fraction / 2)))
     mask = outlier_mask(W, thr)
     s = binary_scale(W, mask).to(W.dtype).view(1, 1)
-    sc, zp = quant8_rows_(W)
+    if W.shape[1] <= QUANT8_MAX_K:
+        sc, zp = quant8_rows_(W)
+    else:
+        # rows longer than the kernel stages in LDS (K = 17920 / 28672 down_proj layers): the same arithmetic in torch on
+        # the device.  torch's GPU division is not correctly rounded, so a code can differ from the host reference by 1 in
+        # rare ties; the kernel path is the bit-exact one.
+        rng = (W.max(-1, keepdim=True)[0] - W.min(-1, keepdim=True)[0]).type(torch.float32)
+        zp2 = torch.round(W.min(-1, keepdim=True)[0])
+        q = torch.round((W - zp2) / rng * 255).to(torch.int64).bitwise_and(255).to(torch.uint8)   # the wrapping uint8 cast
+        W.copy_((q * (rng / 255) + zp2).to(W.dtype))
+        sc, zp = (rng / 255).reshape(-1), zp2.float().reshape(-1)
     return mask, s, sc, zp

@@ -18,7 +18,6 @@ import torch.nn.functional as F
 from . import _lib
 
 _DT = {torch.float32: _lib.PBL_DTYPE_F32, torch.float16: _lib.PBL_DTYPE_F16, torch.bfloat16: _lib.PBL_DTYPE_BF16}
-_workspaces: dict = {}
 
 
 def _need_gpu(*ts):
@@ -41,10 +40,9 @@ def binary_scale(W: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
     """mean |W[~mask]| as a float32 DEVICE scalar [1] (quant/outlier_quantizer.py:90-93)."""
     _need_gpu(W, mask)
     W, mask = W.detach().contiguous(), _mask_u8(mask)
-    key = str(W.device)
-    ws = _workspaces.get(key)
-    if ws is None:
-        ws = _workspaces[key] = torch.empty(_lib.lib().pbl_qat_workspace_bytes(), dtype=torch.uint8, device=W.device)
+    # scratch for the two-stage reduction: a few KiB from the caching allocator per call (stream-ordered, so concurrent
+    # streams never share it -- the C ABI's "no global state" holds above it as well)
+    ws = torch.empty(_lib.lib().pbl_qat_workspace_bytes(), dtype=torch.uint8, device=W.device)
     out = torch.empty(1, dtype=torch.float32, device=W.device)
     _lib.check(_lib.lib().pbl_qat_scale(W.data_ptr(), _DT[W.dtype], mask.data_ptr(), W.numel(), ws.data_ptr(),
                                         out.data_ptr(), _stream(W)), "qat_scale")

@@ -41,44 +41,73 @@ class BinaryInterface:
 # Layers the matrix-core kernel cannot take (column groups, K % 8) switch to the dense path at GEMM_THRESHOLD.
 MFMA_MAX = 32
 GEMM_THRESHOLD = 12
-_workspaces: dict = {}
 
 
-def _dense_workspace(device, numel: int, dtype) -> torch.Tensor:
-    """One reusable scratch buffer per (device, dtype): the dense weight exists only while a
-    large-M forward runs, so a model never holds more than one unpacked layer."""
-    key = (str(device), dtype)
-    buf = _workspaces.get(key)
-    if buf is None or buf.numel() < numel:
-        buf = torch.empty(numel, dtype=dtype, device=device)
-        _workspaces[key] = buf
-    return buf[:numel]
-
-
-def unpack_on_device(packed: PackedWeight, dtype=torch.float16) -> torch.Tensor:
-    """Dense [N, K] view of the packed layer in the transient workspace (pbl_unpack_dev)."""
-    W = _dense_workspace(packed.blob.device, packed.N * packed.K, dtype).view(packed.N, packed.K)
+def unpack_on_device(packed: PackedWeight, dtype=torch.float16, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Dense [N, K] copy of the packed layer (pbl_unpack_dev).  The buffer comes from torch's caching allocator
+    per call (stream-ordered, so two streams never share it and a captured graph keeps its own block); it is
+    released as soon as the caller drops it, so a model never holds more than the layers in flight unpacked.
+    `out`: write into a caller-owned [N, K] buffer instead (the prefill pipeline's double buffer)."""
+    W = out if out is not None else torch.empty(packed.N, packed.K, dtype=dtype, device=packed.blob.device)
     layer = packed.layer_struct(None)
     stream = torch.cuda.current_stream(packed.blob.device).cuda_stream
     _lib.check(_lib.lib().pbl_unpack_dev(C.byref(layer), W.data_ptr(), int(dtype == torch.float32), stream), "unpack_dev")
     return W
 
 
-def mfma_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False) -> torch.Tensor:
-    """pbl_gemm_mfma_f16: x2 [M<=32, K] fp16 contiguous on the GPU -> [M, N] (fp16 or fp32)."""
+def _mfma_workspace(layer, M: int, device):
+    """fp32 scratch for the matrix-core kernel's K split ([KS][M][N] partial outputs), per call from the caching allocator
+    (stream-ordered); (None, 0) when the layer is large enough to run unsplit."""
+    nbytes = _lib.lib().pbl_mfma_workspace_bytes(C.byref(layer), M)
+    if not nbytes:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
+def mfma_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False, split: bool = True) -> torch.Tensor:
+    """pbl_gemm_mfma_f16(_ws): x2 [M<=32, K] fp16 contiguous on the GPU -> [M, N] (fp16 or fp32)."""
     M = x2.shape[0]
     y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
     layer = packed.layer_struct(bias_f32)
     stream = torch.cuda.current_stream(x2.device).cuda_stream
-    _lib.check(_lib.lib().pbl_gemm_mfma_f16(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), stream), "gemm_mfma")
+    ws, nb = _mfma_workspace(layer, M, x2.device) if split else (None, 0)
+    _lib.check(_lib.lib().pbl_gemm_mfma_f16_ws(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32),
+                                                 ws.data_ptr() if ws is not None else None, nb, stream), "gemm_mfma")
     return y
+
+
+class _PackedLinearFn(torch.autograd.Function):
+    """The packed forward with its input gradient.  The packed weight is frozen (no dL/dW), but the reference's
+    fake-quant nn.Linear is differentiable in x -- prompt tuning / LoRA on a PB model, input-gradient analysis -- so
+    dx = dy @ W is provided: W is re-unpacked into a private scratch buffer in the backward (nothing dense is saved)."""
+
+    @staticmethod
+    def forward(ctx, x, holder, out_f32, dense_dtype):
+        ctx.packed, ctx.x_dtype = holder[0], x.dtype
+        return _pb_linear_forward(holder[0], holder[1], x, out_f32, dense_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p = ctx.packed
+        wdt = torch.float16 if (dy.dtype == torch.float16 and p.flags & _lib.PBL_FLAG_SAL_F16) else torch.float32
+        W = unpack_on_device(p, wdt)
+        dx = (dy.reshape(-1, p.N).to(wdt) @ W).reshape(*dy.shape[:-1], p.K).to(ctx.x_dtype)
+        return dx, None, None, None
 
 
 def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: torch.Tensor,
                       out_f32: bool = False, dense_dtype=None) -> torch.Tensor:
     """y = F.linear(x, w_sim, bias) through libpbl (pbl_linear_f16).  x [..., K] on
     the GPU, fp16 (native) or fp32/bf16 (split into two fp16 terms, fp32 output).
-    out_f32: return the fp32 accumulator unrounded (tensor-parallel partial sums)."""
+    out_f32: return the fp32 accumulator unrounded (tensor-parallel partial sums).
+    Differentiable in x (see _PackedLinearFn); the kernels themselves never run under autograd."""
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _PackedLinearFn.apply(x, (packed, bias_f32), out_f32, dense_dtype)
+    with torch.no_grad():
+        return _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype)
+
+
+def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
     if not x.is_cuda:
         raise _lib.PblError("PB linear forward needs a GPU tensor: the HIP kernel is the only compute path")
     if x.shape[-1] != packed.K:
@@ -93,7 +122,13 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     L = _lib.lib()
     if M == 0:
         return x.new_zeros(*lead, packed.N)
-    mfma_ok = packed.G == 1 and packed.K % 8 == 0 and bool(packed.flags & _lib.PBL_FLAG_TAIL_REPEAT)
+    mfma_ok = packed.G == 1 and packed.K % 8 == 0 and bool(packed.flags & _lib.PBL_FLAG_SLABS)
+
+    def run(layer_s, xin, yout, rows, f32):
+        ws, nb = _mfma_workspace(layer_s, rows, x.device) if (rows > _lib.PBL_MAX_TOKENS_PER_LAUNCH and mfma_ok) else (None, 0)
+        _lib.check(L.pbl_linear_f16_ws(C.byref(layer_s), xin.data_ptr(), yout.data_ptr(), rows, int(f32),
+                                       ws.data_ptr() if ws is not None else None, nb, stream), "linear")
+
     rows = M if x.dtype == torch.float16 else 2 * M     # fp32 / bf16 x runs as two fp16 terms
     if (rows > MFMA_MAX) if mfma_ok else (M >= GEMM_THRESHOLD):
         # GEMM regime: dense weight in the workspace + library GEMM, i.e. exactly what the
@@ -107,7 +142,7 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     if x.dtype == torch.float16:
         xc = x2.contiguous()
         y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
-        _lib.check(L.pbl_linear_f16(C.byref(layer), xc.data_ptr(), y.data_ptr(), M, int(out_f32), stream), "linear")
+        run(layer, xc, y, M, out_f32)
         return y.reshape(*lead, packed.N)
     # fp32 / bf16 activations: x = x_hi + x_lo with both terms fp16; the kernel is
     # linear in x, so y = W x_hi + W x_lo accumulated in fp32 (bias added once).
@@ -117,7 +152,7 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     xx = torch.cat([x_hi, x_lo], 0).contiguous()
     y = torch.empty(2 * M, packed.N, dtype=torch.float32, device=x.device)
     layer_nb = packed.layer_struct(None)
-    _lib.check(L.pbl_linear_f16(C.byref(layer_nb), xx.data_ptr(), y.data_ptr(), 2 * M, 1, stream), "linear")
+    run(layer_nb, xx, y, 2 * M, True)
     out = y[:M] + y[M:]
     if bias_f32 is not None:
         out = out + bias_f32
@@ -147,6 +182,7 @@ class PBLinear(nn.Module, BinaryInterface):
         super().__init__()
         self.in_features, self.out_features = packed.K, packed.N
         self._meta = packed
+        self._meta_version = packed.blob._version
         self.register_buffer("pbl_blob", packed.blob)
         self.register_buffer("pbl_bias", bias.detach().float().clone() if bias is not None else None)
         self.weight_dtype = dtype
@@ -209,9 +245,16 @@ class PBLinear(nn.Module, BinaryInterface):
     @property
     def packed(self) -> PackedWeight:
         m = self._meta
-        if m.blob is not self.pbl_blob:  # the buffer moved (.to / .cuda / load_state_dict)
+        if self.pbl_blob._version != self._meta_version:
+            # written in place (load_state_dict copies into the buffer): the header fields the kernels size their
+            # LDS with (max_nch, max_nexc, flags) must come from the NEW blob, which is validated again
+            m = PackedWeight.from_blob(self.pbl_blob)
+            if (m.N, m.K) != (self.out_features, self.in_features):
+                raise _lib.PblError(f"loaded blob is {m.N}x{m.K}, module is {self.out_features}x{self.in_features}")
+            self._meta, self._meta_version = m, self.pbl_blob._version
+        elif m.blob is not self.pbl_blob:  # the buffer moved (.to / .cuda)
             m = PackedWeight(self.pbl_blob, m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch, m.max_nexc, m.nnz, m.nexc)
-            self._meta = m
+            self._meta, self._meta_version = m, self.pbl_blob._version
         return m
 
     @property
@@ -224,7 +267,7 @@ class PBLinear(nn.Module, BinaryInterface):
 
     def forward(self, x):
         if torch.compiler.is_compiling():
-            m = self._meta
+            m = self.packed
             return torch.ops.pbllm.linear(self.pbl_blob, self.pbl_bias, x,
                                           [m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch, m.max_nexc, m.nnz, m.nexc],
                                           self.weight_dtype == torch.float16, False)
@@ -257,10 +300,17 @@ class _DenseBacked(nn.Module, BinaryInterface):
     def _pack(self) -> PackedWeight:
         raise NotImplementedError
 
+    def _cache_key(self):
+        """Everything the packed blob was derived from: a `weight.data` edit, load_state_dict, .half()/.float() or a new
+        mask / scale changes the key, so a stale blob is never served."""
+        w = self.weight
+        return (w.data_ptr(), w._version, w.dtype, tuple(w.shape))
+
     def _packed_on(self, device) -> PackedWeight:
-        p = getattr(self, "_packed", None)
-        if p is None:
+        p, key = getattr(self, "_packed", None), self._cache_key()
+        if p is None or getattr(self, "_packed_key", None) != key:
             p = self._pack()
+            self._packed_key = key
         if p.blob.device != device:
             p = p.to(device)
         self._packed = p
@@ -268,6 +318,7 @@ class _DenseBacked(nn.Module, BinaryInterface):
 
     def invalidate(self):
         self._packed = None
+        self._packed_key = None
 
     def _bias_f32(self, device):
         return self.bias.detach().float().to(device) if self.bias is not None else None
@@ -277,9 +328,10 @@ class _DenseBacked(nn.Module, BinaryInterface):
         raise NotImplementedError
 
     def _is_training_step(self, x) -> bool:
-        """train() mode AND autograd is recording for the weight or the input; a train()-mode forward under
-        no_grad (evaluation loops that forget eval()) still takes the packed kernels"""
-        return self.training and torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad)
+        """train() mode never packs: the weights change every step, and a train()-mode forward under no_grad is the
+        first pass of reentrant activation checkpointing (utils.py:49 gradient_checkpointing_enable, called from
+        qat/run_qat.py) -- it must cost, and round, exactly like its recompute.  Packing is for eval()."""
+        return self.training
 
     def _check_input(self, x):
         if x.shape[-1] != self.weight.shape[1]:
@@ -292,7 +344,6 @@ class _DenseBacked(nn.Module, BinaryInterface):
         if self._is_training_step(x):
             # QAT step: the weights change every step, so nothing is packed; the dense simulated weight is
             # built on the GPU with the straight-through estimator and a library GEMM runs on it
-            self.invalidate()
             return torch.nn.functional.linear(x, self._train_weight(), self.bias)
         dd = torch.float16 if self.weight.dtype == torch.float16 else torch.float32
         return pb_linear_forward(self._packed_on(x.device), self._bias_f32(x.device), x, dense_dtype=dd)
@@ -389,8 +440,17 @@ class BinaryXnorExceptOutliersLinear(_DenseBacked):
                 moved = fn(t)
                 if name == "outlier_mask":
                     moved = moved.bool() if moved.dtype != torch.bool else moved
+                elif name in ("_code_scale", "_code_zp"):
+                    # the code grid is fp32 whatever the module is cast to: in fp16 the salient values would fall off
+                    # the grid and turn into 8-byte exceptions
+                    moved = t.to(moved.device)
                 setattr(self, name, moved)
         return self
+
+    def _cache_key(self):
+        s, m = self.binary_scale, self.outlier_mask
+        return super()._cache_key() + (None if m is None else (m.data_ptr(), m._version),
+                                       None if s is None else (s.data_ptr(), s._version), float(self.outlier_scale))
 
     def gen_outlier_mask(self):
         with torch.no_grad():
@@ -415,6 +475,13 @@ class BinaryXnorExceptOutliersLinear(_DenseBacked):
 
     def _quantize_weights_8bit(self):
         w = self.weight.data
+        if w.is_cuda:
+            from .prep import QUANT8_MAX_K, quant8_rows_
+            if w.shape[1] <= QUANT8_MAX_K:      # the HIP row quantizer: bit-identical to the reference's host arithmetic
+                data = w.contiguous()
+                self._code_scale, self._code_zp = quant8_rows_(data)
+                self.weight.data = data
+                return
         rng = (w.max(-1, keepdim=True)[0] - w.min(-1, keepdim=True)[0]).type(torch.float32)
         zp = torch.round(w.min(-1, keepdim=True)[0])
         self._code_scale = (rng / 255).reshape(-1)
@@ -446,8 +513,9 @@ class BinaryXnorExceptOutliersLinear(_DenseBacked):
         with np.errstate(divide="ignore", invalid="ignore"):
             sz = np.where(self._code_scale.cpu().numpy() != 0,
                           -self._code_zp.cpu().numpy() / self._code_scale.cpu().numpy(), 0.0).astype(np.float32)
+        # an fp16 module holds fl16(code*scale + zp) at the salient positions: pack it like an fp16 checkpoint
         return pack_dense(w_sim, a.reshape(N, 1), (-a).reshape(N, 1), ss, sz,
-                          self.outlier_mask.cpu().numpy().astype(np.uint8))
+                          self.outlier_mask.cpu().numpy().astype(np.uint8), sal_f16=self.weight.dtype == torch.float16)
 
     def forward(self, x):
         self._check_input(x)
@@ -457,12 +525,10 @@ class BinaryXnorExceptOutliersLinear(_DenseBacked):
             # QAT step (quant/outlier_quantizer.py:83-106): fused HIP kernels for binary_scale / w_sim / the
             # straight-through weight gradient, library GEMMs; binary_scale is refreshed from the current
             # weights without a host sync and persists into later eval() like the reference's
+            # (under no_grad -- the first pass of reentrant checkpointing -- the same kernels run without a graph)
             y, s = qat_linear(x, self.weight, self.bias, self.outlier_mask, self.outlier_scale, self.train_outlier)
             self.binary_scale = s.to(self.weight.dtype).view(1, 1)
-            self.invalidate()
             return y
-        if self.training:
-            self._refresh_scale()           # train() without autograd: the scale refresh of :90-93, then the packed path
         return super().forward(x)
 
     def to_regular_linear(self):

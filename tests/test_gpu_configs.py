@@ -1,0 +1,331 @@
+"""-m gpu: BASELINE.json configs[2] (llama-7b linears, low_frac 0.95 hessian, M = 2048) and configs[4] (the same layers
+row-sharded over 2/4/8 ranks) through the HIP path, plus the rows round 1 left at CPU-only coverage: the on-disk format
+(utils.py:65-124), the Hessian-mask module (a8, quant/outlier_quantizer.py:126-143), the input gradient
+of the packed forward and the staleness of the packed cache.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pb_oracle as O
+from pb_llm_amd import _lib, synth
+from pb_llm_amd import io as pbio
+from pb_llm_amd import parallel as PP
+from pb_llm_amd import quant as Q
+from pb_llm_amd.packing import PackedWeight, pack_dense
+from cfg_shapes import LLAMA7B, LLAMA7B_DISTINCT, hessian_layer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available()
+
+
+def T(a, dev=DEV):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def assert_parity(y, ref, tol=1e-3):
+    y = y.detach().float().cpu().numpy() if isinstance(y, torch.Tensor) else y
+    rel, ratio = O.parity_errors(y, ref)
+    assert rel < tol and ratio < 1.0, f"rel_max={rel:.3e} allclose_ratio={ratio:.3f}"
+
+
+_cache = {}
+
+
+def cfg3_layer(name):
+    """packed llama-7b linear `name` at low_frac 0.95 with hessian salients (fp16 checkpoint, as gptq_pb writes it)"""
+    if name not in _cache:
+        N, K = LLAMA7B[name]
+        W, mask, r = hessian_layer(N, K, 0.95, seed=300 + len(_cache))
+        W16 = torch.from_numpy(r["W_fq"]).half()
+        layer = Q.PBLinear.from_dense(W16, None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+        _cache[name] = (layer, W16, mask)
+    return _cache[name]
+
+
+# ------------------------------------------------------------------------------------------- config 3
+@pytest.mark.parametrize("name", list(LLAMA7B_DISTINCT))
+def test_config3_llama7b_linears_hessian_m2048(name):
+    """configs[2]: every decoder linear of llama-7b (seven, three distinct shapes), low_frac 0.95, hessian salients from a
+    column-concentrated Hessian, seq 2048 -- the HIP path against the float64 oracle on a sample of output rows."""
+    assert sorted(sum(LLAMA7B_DISTINCT.values(), ())) == sorted(LLAMA7B)          # the three shapes cover all seven linears
+    layer, W16, mask = cfg3_layer(name)
+    N, K = LLAMA7B[name]
+    p = layer.packed
+    assert (p.N, p.K) == (N, K) and p.flags & _lib.PBL_FLAG_SAL_F16
+    sal_frac = 1.0 - mask.mean()
+    assert abs(sal_frac - 0.05) < 2e-3 and p.nexc < 1e-3 * N * K
+    # hessian saliency is column concentrated: some input channels are salient for (nearly) every row
+    col_frac = (~mask).mean(0)
+    assert (col_frac > 0.9).sum() >= 0.005 * K
+    x = synth.activations((2048, K), 77, 21)
+    y = layer(T(x))
+    assert y.shape == (2048, N) and y.dtype == torch.float16
+    rows = np.unique(np.concatenate([np.arange(0, N, max(1, N // 192)), [N - 1, N - 16, 15, 16]]))
+    ref = O.dense_linear(x, W16.numpy()[rows])
+    assert_parity(y[:, torch.from_numpy(rows).to(DEV)], ref)
+    # the decode-time regimes of the same layer: GEMV (1 token) and the matrix-core kernel (32 tokens)
+    for M in (1, 32):
+        assert_parity(layer(T(x[:M])), O.dense_linear(x[:M], W16.numpy()))
+
+
+# ------------------------------------------------------------------------------------------- config 5
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_config5_ksplit_shards_on_one_gpu(world):
+    """configs[4], K split (o_proj / down_proj: "row-sharded ... all-reduce"): all P shards of llama-7b down_proj built
+    on cuda:0, the HIP kernel run on each with fp32 partial outputs, partials summed in rank order = what the
+    all-reduce computes; equals the unsharded HIP result and the oracle.  K = 11008 = 86 x 128 does not divide evenly."""
+    layer, W16, mask = cfg3_layer("down_proj")
+    N, K = LLAMA7B["down_proj"]
+    pts = PP.split_points(K, world, PP.COL_ALIGN)
+    assert pts[-1] == K and all(p % 128 == 0 for p in pts[:-1]) and len(set(np.diff(pts))) <= 2
+    for M in (1, 8):
+        x = synth.activations((M, K), 5 + world, 21)
+        xt = T(x)
+        total = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        for rank in range(world):
+            shard, (c0, c1) = PP.shard_linear(W16, None, torch.from_numpy(mask), "k", rank, world)
+            assert (c0, c1) == (pts[rank], pts[rank + 1])
+            mod = PP.PBLinearKSplit(shard.to(DEV), (c0, c1))
+            part = mod.local_forward(xt[:, c0:c1].contiguous())
+            assert part.dtype == torch.float32 and part.shape == (M, N)
+            total += part
+        ref = O.dense_linear(x, W16.numpy())
+        assert_parity(total, ref, 2e-4)                                    # fp32 sum of fp32 partials
+        assert_parity(total.half(), layer(xt).float().cpu().numpy().astype(np.float64), 2e-3)   # vs the unsharded HIP result
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_config5_nsplit_shards_on_one_gpu(world):
+    """configs[4], N split (q/k/v/gate/up): each rank owns a slice of the output rows; concatenated shard outputs are the
+    unsharded output BIT FOR BIT (a record is 16 rows and rows never interact)."""
+    layer, W16, mask = cfg3_layer("gate_proj")
+    N, K = LLAMA7B["gate_proj"]
+    x = T(synth.activations((2, K), 9, 21))
+    full = layer(x)
+    parts = []
+    for rank in range(world):
+        shard, (r0, r1) = PP.shard_linear(W16, None, torch.from_numpy(mask), "n", rank, world)
+        assert r0 % 16 == 0
+        parts.append(PP.PBLinearNSplit(shard.to(DEV), (r0, r1), N, gather_output=False)(x))
+    assert torch.equal(torch.cat(parts, -1), full)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tp_worker(rank, world, port, collective, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dev = torch.device(f"cuda:{rank % torch.cuda.device_count()}")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl" if torch.cuda.device_count() >= world else "gloo", rank=rank, world_size=world)
+    try:
+        N, K = 256, 2048
+        W = synth.llm_weight(N, K, seed=41, heavy_tail=True)
+        mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        W16 = torch.from_numpy(r["W_fq"]).half()
+        x = torch.from_numpy(synth.activations((3, K), 6, 21)).to(dev)
+        shard, cols = PP.shard_linear(W16, None, torch.from_numpy(mask), "k", rank, world)
+        mod = PP.PBLinearKSplit(shard.to(dev), cols, collective=collective)
+        y = mod(x)
+        y2 = mod(x)                       # second call: the p2p buffers alternate, results must repeat
+        ref = O.dense_linear(x.cpu().numpy(), W16.numpy())
+        rel, ratio = O.parity_errors(y.float().cpu().numpy(), ref)
+        same = bool(torch.equal(y, y2))
+        if mod.comm is not None:
+            for _ in range(5):            # more calls than buffer sets
+                same = same and bool(torch.equal(mod(x), y))
+            mod.comm.check()
+            mod.comm.close()
+        out[rank] = (rel, ratio, same)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_config5_ksplit_rccl_all_reduce(world):
+    """one process per GPU, RCCL all-reduce of the fp32 partials (needs `world` GPUs; the driver's multi-GPU box)"""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, {torch.cuda.device_count()} visible")
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    mp.spawn(_tp_worker, args=(world, _free_port(), "rccl", out), nprocs=world, join=True)
+    for rank in range(world):
+        rel, ratio, same = out[rank]
+        assert rel < 1e-3 and ratio < 1.0 and same
+
+
+def test_config5_ksplit_p2p_all_reduce_two_processes():
+    """libpbl's one-shot peer-to-peer all-reduce between two PROCESSES.  On a one-GPU box both ranks use cuda:0: the
+    hipIpc mapping, the slot / flag protocol and the rank-ordered sum are exactly what runs over xGMI; only the link
+    differs.  (Handles travel over gloo there, RCCL refuses two ranks on one device.)"""
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    mp.spawn(_tp_worker, args=(2, _free_port(), "p2p", out), nprocs=2, join=True)
+    for rank in range(2):
+        rel, ratio, same = out[rank]
+        assert rel < 1e-3 and ratio < 1.0 and same
+    assert out[0][0] == out[1][0]                    # both ranks hold the same bits
+
+
+# ------------------------------------------------------------------------------------------- (f1) on-disk format
+class _TwoLinears(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.q_proj = torch.nn.Linear(1024, 256, bias=False)
+        self.fc = torch.nn.Linear(1024, 128, bias=True)
+
+
+def test_checkpoint_roundtrip_bit_for_bit(tmp_path):
+    """save_pb -> load_pb (utils.py:65-124 save_bnn / load_bnn): the HIP forward of the loaded model equals the forward
+    before saving bit for bit, for the GEMV, the matrix-core kernel and the GEMM regime"""
+    torch.manual_seed(0)
+    model = _TwoLinears()
+    side = {}
+    for name, lin in (("q_proj", model.q_proj), ("fc", model.fc)):
+        W = synth.llm_weight(*lin.weight.shape, seed=len(side) + 60, heavy_tail=True)
+        mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        lin.weight.data = torch.from_numpy(r["W_fq"]).half().float()
+        side[name] = dict(low_mask=torch.from_numpy(mask), hscale=r["hscale"], hzero=r["hzero"])
+    from pb_llm_amd.harness import to_pb_
+    model = to_pb_(model.half(), side, skip=()).to(DEV)
+    xs = [T(synth.activations((M, 1024), 3 + M, 21)) for M in (1, 16, 70)]
+    before = [(model.q_proj(x), model.fc(x)) for x in xs]
+    meta = pbio.save_pb(model, str(tmp_path / "ckpt"))
+    assert set(meta) == {"q_proj", "fc"} and meta["fc"]["class"] == "PBLinear"
+    fresh = pbio.load_pb(_TwoLinears().half(), str(tmp_path / "ckpt")).to(DEV)
+    assert isinstance(fresh.q_proj, Q.PBLinear) and fresh.fc.pbl_bias is not None
+    for x, (a, b) in zip(xs, before):
+        assert torch.equal(fresh.q_proj(x), a) and torch.equal(fresh.fc(x), b)
+    # load_state_dict copies INTO the blob buffer: the module must re-derive its launch metadata from the new blob
+    W2 = synth.llm_weight(256, 1024, seed=99, heavy_tail=True)
+    m2 = O.ptq_low_mask(W2, 0.8, "magnitude", None, -1)               # denser salients: larger max_nch
+    r2 = O.ptq_rtn(W2, m2, 8, -1)
+    other = Q.PBLinear.from_dense(torch.from_numpy(r2["W_fq"]).half(), None, torch.from_numpy(m2), -1, r2["hscale"], r2["hzero"])
+    if other.pbl_blob.numel() == fresh.q_proj.pbl_blob.numel():
+        fresh.q_proj.load_state_dict(other.state_dict())
+        assert fresh.q_proj.packed.max_nch == other.packed.max_nch
+    # a corrupt file must be rejected by the loader, not fed to the kernels
+    w = torch.load(str(tmp_path / "ckpt" / "weights.pth"), weights_only=True)
+    blob = w["q_proj_blob"].clone()
+    blob[80 + 4] ^= 0x40                                                  # rb_info[0].nfull
+    w["q_proj_blob"] = blob
+    torch.save(w, str(tmp_path / "ckpt" / "weights.pth"))
+    with pytest.raises(_lib.PblError):
+        pbio.load_pb(_TwoLinears().half(), str(tmp_path / "ckpt"))
+
+
+# ------------------------------------------------------------------------------------------- (a8) Hessian-mask module
+def test_hessian_mask_module_on_gpu(tmp_path, monkeypatch):
+    """BinaryXnorExceptOutliersLinearHessian (quant/outlier_quantizer.py:126-143) with a gptq_pb mask file: outlier_mask =
+    ~mask, binary_scale stays None (an eval() forward fails like the reference's `sign(W) * None`), the first train()
+    forward computes it, and it persists into eval()."""
+    monkeypatch.chdir(tmp_path)
+    N, K = 96, 1024
+    W = synth.llm_weight(N, K, seed=71, heavy_tail=True)
+    low = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    pbio.save_low_mask(torch.from_numpy(low), 0.9, "model/layers/0/q_proj")
+    m = Q.BinaryXnorExceptOutliersLinearHessian(torch.from_numpy(W).clone(), None, 0.1).to(DEV)
+    m.global_name = "model/layers/0/q_proj"
+    m.gen_outlier_mask()
+    assert m.outlier_mask.is_cuda and torch.equal(m.outlier_mask.cpu(), ~torch.from_numpy(low)) and m.binary_scale is None
+    W_hat = O.weight_quant_8bit(W)
+    np.testing.assert_array_equal(m.weight.data.cpu().numpy(), W_hat)
+    x = synth.normal((3, K), 4, 5, 1.0)
+    m.eval()
+    with pytest.raises(TypeError):
+        m(T(x))
+    m.train()
+    with torch.no_grad():
+        y_train = m(T(x))
+    s = O.refresh_binary_scale(W_hat, ~low)
+    np.testing.assert_allclose(m.binary_scale.float().cpu().numpy().reshape(-1), np.asarray(s).reshape(-1), rtol=3e-6)
+    ref = O.pb_qat_forward(x, W_hat, ~low, np.asarray(s, np.float32).reshape(1, 1))
+    assert_parity(y_train, ref, 1e-4)
+    m.eval()
+    assert_parity(m(T(x)), ref, 2e-5)                     # packed kernels, fp32 module: split-x path
+
+
+# ------------------------------------------------------------------------------------------- autograd / cache
+def test_packed_forward_input_gradient():
+    """the reference's fake-quant nn.Linear is differentiable in x: dx = dy @ W through the packed path, for every regime"""
+    N, K = 192, 1024
+    W = synth.llm_weight(N, K, seed=81, heavy_tail=True)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    W16 = torch.from_numpy(r["W_fq"]).half()
+    layer = Q.PBLinear.from_dense(W16, None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+    for M in (1, 20, 64):
+        x = T(synth.activations((M, K), 8 + M, 21)).requires_grad_(True)
+        y = layer(x)
+        assert y.requires_grad
+        dy = T(synth.activations((M, N), 9 + M, 22))
+        y.backward(dy)
+        ref = dy.float().cpu().numpy().astype(np.float64) @ W16.float().numpy().astype(np.float64)
+        assert_parity(x.grad, ref, 2e-3)
+    with torch.no_grad():
+        assert not layer(x).requires_grad
+
+
+def test_packed_cache_follows_the_weight():
+    """eval() forwards serve a cached blob; weight.data edits, load_state_dict and dtype casts must invalidate it"""
+    W = synth.llm_weight(64, 512, seed=91)
+    m = Q.XnorBinaryLinear(torch.from_numpy(W), None).to(DEV).eval()
+    x = T(synth.normal((2, 512), 3, 5, 1.0))
+    y0 = m(x)
+    with torch.no_grad():
+        m.weight.mul_(-1.0)                  # (an edit through `.data` bypasses the version counter: call invalidate())
+    assert_parity(m(x), -y0.float().cpu().numpy().astype(np.float64), 1e-5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["weight"] = torch.from_numpy(W).to(DEV)
+    m.load_state_dict(sd)
+    assert torch.equal(m(x), y0)
+    q = Q.BinaryXnorExceptOutliersLinear(torch.from_numpy(W), None, 0.1).to(DEV).eval()
+    q.gen_outlier_mask()
+    yq = q(x)
+    q.half()
+    assert q._code_scale.dtype == torch.float32               # the code grid stays fp32 through .half()
+    yh = q(x.half())
+    assert yh.dtype == torch.float16
+    assert_parity(yh, yq.float().cpu().numpy().astype(np.float64), 4e-3)
+    assert q._packed.nexc <= 0.01 * q._packed.nnz + 4            # salients still on the code grid, not exceptions
+
+
+def test_mfma_k_split_equals_unsplit():
+    """the K-split matrix-core launch (fp32 partials + fixed-order reduce) against the unsplit one and the oracle"""
+    N, K = 512, 4096
+    W = synth.llm_weight(N, K, seed=95, heavy_tail=True)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    b = T(synth.normal((N,), 2, 3, 0.1))
+    p = pack_dense(r["W_fq"], r["scale"][0] + r["mean"][0], -r["scale"][0] + r["mean"][0], r["hscale"], r["hzero"],
+                   (~mask).astype(np.uint8)).to(DEV)
+    layer = p.layer_struct(b)
+    import ctypes as C
+    assert _lib.lib().pbl_mfma_workspace_bytes(C.byref(layer), 32) > 0          # 32 records: the split is in use
+    for M in (5, 16, 32):
+        x = synth.activations((M, K), 4 + M, 21)
+        ref = O.dense_linear(x, r["W_fq"], b.cpu().numpy())
+        ys = Q.mfma_forward(p, b, T(x), out_f32=True, split=True)
+        yu = Q.mfma_forward(p, b, T(x), out_f32=True, split=False)
+        assert_parity(ys, ref, 2e-4)
+        assert_parity(yu, ref, 2e-4)
+        assert torch.equal(ys, Q.mfma_forward(p, b, T(x), out_f32=True, split=True))    # deterministic

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in pbl.h but not exported"
     assert set(_lib.EXPORTS) == declared
-    assert L.pbl_version() == 1
+    assert L.pbl_version() == 2
     assert L.pbl_status_string(-3).decode() == "unsupported shape or option"
 
 

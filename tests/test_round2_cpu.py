@@ -1,0 +1,161 @@
+"""CPU tests for round 2: format version 2 (slab index, the fp16 "no coded zero" promise), structural blob validation
+(corrupt-blob fuzz), host-side module logic that needs no GPU, bench.py's launcher checks."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pb_format_ref as F
+from oracle import pb_oracle as O
+from pb_llm_amd import _lib, synth
+from pb_llm_amd import quant as Q
+from pb_llm_amd.packing import PackedWeight, pack_dense
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _layer(N=80, K=1536, lf=0.9, seed=5, f16=False):
+    W = synth.llm_weight(N, K, seed=seed, heavy_tail=True)
+    mask = O.ptq_low_mask(W, lf, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    Wd = r["W_fq"].astype(np.float16).astype(np.float32) if f16 else r["W_fq"]
+    hi, lo = r["scale"][0] + r["mean"][0], -r["scale"][0] + r["mean"][0]
+    if f16:
+        hi, lo = hi.astype(np.float16).astype(np.float32), lo.astype(np.float16).astype(np.float32)
+    return Wd, pack_dense(Wd, hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8), sal_f16=f16)
+
+
+def test_slab_index_matches_independent_decoder():
+    """the decoder re-derives every slab entry from the chunk lists (asserts inside decode); dense, sparse and ragged K"""
+    for N, K, lf in ((80, 1536, 0.9), (33, 520, 0.8), (16, 4096, 0.995), (40, 264, 0.5)):
+        Wd, p = _layer(N, K, lf, seed=N + K)
+        assert p.flags & _lib.PBL_FLAG_SLABS
+        np.testing.assert_array_equal(F.decode(p.blob.numpy()), Wd)
+
+
+def test_slab_index_chunk_spanning_several_slabs():
+    """a row with 3 salient entries 700 columns apart... cannot share a chunk (gap > 127); entries 100 apart can: one
+    16-entry chunk then covers 1500 columns = 6 slabs, each of which must list it (fback), and only it"""
+    N, K = 16, 2048
+    W = np.full((N, K), 0.5, np.float32)
+    W[:, ::2] = -0.5
+    cols = 20 + 100 * np.arange(16)
+    W[3, cols] = 0.25 * np.arange(3, 19)            # codes 3..18 on a grid of 0.25 (none equals a level)
+    hi, lo = np.full(N, 0.5, np.float32), np.full(N, -0.5, np.float32)
+    p = pack_dense(W, hi, lo, np.full(N, 0.25, np.float32), np.zeros(N, np.float32))
+    assert p.nnz == 16 and p.nexc == 0
+    np.testing.assert_array_equal(F.decode(p.blob.numpy()), W)       # includes the slab-index cross check
+    np.testing.assert_array_equal(p.unpack().numpy(), W)
+
+
+def test_fp16_layers_hold_no_coded_zero():
+    """PBL_FLAG_SLABS promise for fp16-checkpoint layers: a salient whose value is 0 is stored as an exception"""
+    N, K = 16, 512
+    W = np.full((N, K), 0.5, np.float32)
+    W[:, 1::2] = -0.5
+    sal = np.zeros((N, K), np.uint8)
+    W[2, 10], W[2, 11], W[5, 300] = 0.0, 0.75, 0.0
+    sal[2, 10] = sal[2, 11] = sal[5, 300] = 1
+    hi, lo = np.full(N, 0.5, np.float32), np.full(N, -0.5, np.float32)
+    ss, sz = np.full(N, 0.25, np.float32), np.full(N, 4.0, np.float32)          # value = 0.25 (q - 4): q = 4 -> 0
+    p16 = pack_dense(W, hi, lo, ss, sz, sal, sal_f16=True)
+    assert (p16.nnz, p16.nexc) == (1, 2)
+    p32 = pack_dense(W, hi, lo, ss, sz, sal, sal_f16=False)
+    assert (p32.nnz, p32.nexc) == (3, 0)                                           # code mode stores 0x6400 | q: never 0
+    for p in (p16, p32):
+        np.testing.assert_array_equal(F.decode(p.blob.numpy()), W)
+
+
+def test_corrupt_blobs_are_rejected():
+    """pbl_blob_describe walks the whole structure: every single-byte corruption of the tables either leaves a
+    structurally valid blob (payload bytes: codes, sign bits, values) or is rejected with BAD_BLOB -- and a blob it
+    accepts can be unpacked without touching memory outside it"""
+    Wd, p = _layer(48, 1024, 0.9, seed=9, f16=True)
+    good = p.blob.numpy().copy()
+    L = _lib.lib()
+    layer = _lib.PblLayer()
+    assert L.pbl_blob_describe(good.ctypes.data, good.size, C.byref(layer)) == 0
+    h = F.read_header(good)
+    rng = np.random.default_rng(0)
+    # 1. header and record-info table: every byte matters
+    rejected = 0
+    for off in list(range(8, 80 - 12)) + list(range(80, 80 + 16 * (h["NRB"] + 1))):
+        bad = good.copy()
+        bad[off] ^= 1 << int(rng.integers(8))
+        if L.pbl_blob_describe(bad.ctypes.data, bad.size, C.byref(layer)) != 0:
+            rejected += 1
+    assert rejected >= 0.8 * (60 + 16 * (h["NRB"] + 1))       # (header maxima may grow: they are upper bounds)
+    # 2. random corruption anywhere: accepted blobs must unpack in bounds (run under the allocator's guard: a buffer
+    #    exactly the blob's size; numpy would not catch an overrun, so the bound is re-checked through the decoder too)
+    out = np.empty((h["N"], h["K"]), np.float32)
+    accepted = 0
+    for _ in range(400):
+        bad = good.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            bad[int(rng.integers(bad.size))] ^= 1 << int(rng.integers(8))
+        if L.pbl_blob_describe(bad.ctypes.data, bad.size, C.byref(layer)) == 0:
+            accepted += 1
+            assert L.pbl_unpack_dense_f32(bad.ctypes.data, bad.size, out.ctypes.data) == 0
+    assert accepted > 0
+    # 3. truncation and trailing garbage
+    assert L.pbl_blob_describe(good.ctypes.data, good.size - 128, C.byref(layer)) == _lib.PBL_ERR_BAD_BLOB
+    longer = np.concatenate([good, np.zeros(128, np.uint8)])
+    assert L.pbl_blob_describe(longer.ctypes.data, longer.size, C.byref(layer)) == _lib.PBL_ERR_BAD_BLOB
+    # 4. targeted: a chunk whose columns run past K, a slab entry pointing past the row's chunks, a bad exception row
+    rb = good[80:80 + 16].view(np.uint32)
+    rec = int(rb[0]) * 16
+    nfull, ntail, nexc, off_sal = good[rec:rec + 16].view(np.uint32)
+    nch = int(nfull + ntail)
+    a128 = lambda v: (v + 127) & ~127       # noqa: E731
+    bad = good.copy()
+    bad[rec + off_sal: rec + off_sal + 2].view(np.uint16)[0] = 1020          # col0 of chunk 0: its 16 entries overrun K = 1024
+    assert L.pbl_blob_describe(bad.ctypes.data, bad.size, C.byref(layer)) == _lib.PBL_ERR_BAD_BLOB
+    bad = good.copy()
+    bad[rec + off_sal + a128(2 * nch) + 1] = 255                              # a delta of 255: odd (steps are stored doubled)
+    assert L.pbl_blob_describe(bad.ctypes.data, bad.size, C.byref(layer)) == _lib.PBL_ERR_BAD_BLOB
+    with pytest.raises(_lib.PblError):
+        PackedWeight.from_blob(torch.from_numpy(bad))
+
+
+def test_status_codes_exposed():
+    assert _lib.PBL_ERR_BAD_BLOB == -2
+
+
+def test_train_mode_never_packs_and_cache_key_tracks_weight():
+    """train(): no packing whatever the grad mode (the first pass of reentrant checkpointing runs under no_grad);
+    the eval() cache is keyed on the weight's storage / version / dtype"""
+    W = torch.from_numpy(synth.llm_weight(32, 256, seed=3))
+    m = Q.XnorBinaryLinear(W, None)
+    k0 = m._cache_key()
+    with torch.no_grad():
+        m.weight.mul_(2.0)
+    k1 = m._cache_key()
+    assert k0 != k1
+    m.weight.data = m.weight.data.clone()
+    assert m._cache_key() != k1
+    m.train()
+    assert m._is_training_step(torch.zeros(1, 256))
+    with torch.no_grad():
+        assert m._is_training_step(torch.zeros(1, 256))
+    m.eval()
+    assert not m._is_training_step(torch.zeros(1, 256))
+    q = Q.BinaryXnorExceptOutliersLinear(W.clone(), None, 0.1)
+    q.gen_outlier_mask()
+    ka = q._cache_key()
+    q.binary_scale = q.binary_scale.clone()
+    assert q._cache_key() != ka
+    q.half()
+    assert q._code_scale.dtype == torch.float32 and q._code_zp.dtype == torch.float32 and q.weight.dtype == torch.float16
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    """bench.py --gpus N started as one plain process must not print a 1-rank line labelled N: with WORLD_SIZE set to
+    something else it exits non-zero before touching the GPU"""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
