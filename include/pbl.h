@@ -142,9 +142,7 @@ typedef enum {
                                     apply the fp16 rounding (v_cvt_pk_f16_f32), so the layer is reproduced
                                     bit-exactly. */
 #define PBL_FLAG_TAIL_REPEAT 0x4u /* tail-chunk padding repeats the last entry (step 0, same code); set by this packer */
-#define PBL_FLAG_SLABS 0x8u       /* the records carry the column-slab index; with PBL_FLAG_SAL_F16 it also promises that no
-                                     CODED salient has the value 0 (those are exception entries), so "fp16 value != 0" marks
-                                     the salient positions of an expanded tile */
+#define PBL_FLAG_SLABS 0x8u       /* the records carry the column-slab index (format version 2) */
 #define PBL_FLAG_KNOWN 0xFu
 
 typedef struct {

@@ -129,14 +129,6 @@ def decode(blob: np.ndarray) -> np.ndarray:
                 W[b * 16 + rho, cols[ch, :n]] = deq(ss, code[ch, :n], sz)
                 if h["flags"] & 0x4:   # PBL_FLAG_TAIL_REPEAT: padding repeats the last entry with step 0
                     assert 1 <= n < 16 and (delta[ch, n:] == 0).all() and (code[ch, n:] == code[ch, n - 1]).all()
-        if sal16:   # PBL_FLAG_SLABS promise for fp16-checkpoint layers: no coded salient is zero
-            for rho in range(16):
-                ri = rowinfo[rho]
-                ss, sz = np.float32(params[rho, 2]), np.float32(params[rho, 3])
-                for ch in range(int(ri["start"]), int(ri["start"]) + int(ri["nfull"])):
-                    assert (deq(ss, code[ch], sz) != 0).all()
-                for t in range(int(ri["tailidx"]), int(ri["tailidx"]) + int(ri["ntail"])):
-                    assert (deq(ss, code[nfull + t, :tailcnt[t]], sz) != 0).all()
         for e in exc:
             W[b * 16 + int(e["row"]), int(e["col"])] = e["value"]
     return W[:N, :K].copy()

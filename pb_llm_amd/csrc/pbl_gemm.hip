@@ -19,8 +19,8 @@
 //     entries of each into the fp16 tile St[16][256] -- the code as 1024 + q (0x6400 | q: one OR, exact), or for
 //     fp16 checkpoints the double-rounded fp16 weight; entries left or right of the slab are clamped into pad columns;
 //   * derives the salient MASK fragment from the tile it has just read: v_pk_min_u16(s, 0x3C00) for codes (every
-//     stored half is >= 0x6400), "any bit below the sign" for fp16 values (PBL_FLAG_SLABS: no coded salient is zero);
-//     no byte mask tile, no second scatter;
+//     stored half is >= 0x6400), min(s, 1) * 0x3C00 for fp16 values (a salient of value 0 is stored as -0, so every
+//     stored half has a bit set); no byte mask tile, no second scatter;
 //   * runs v_mfma_f32_16x16x32_f16:  accW += W.x, accS += St.x, accM += Mask.x;
 //   * clears St with nine ds_write_b128.
 // X, the plain sum of a token's x over the split's columns, is the same for every record: the threads that stage x
@@ -150,26 +150,36 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
             const int idx = tid + j * (WPG * GW), tok = idx >> 5;
             *reinterpret_cast<u32x4*>(Xs + (size_t(buf) * XT + tok) * SSTR + (idx & 31) * 8) = xr[j];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                xsum[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2v, xr[j][q]), h2v{_Float16(1.f), _Float16(1.f)}, xsum[j], false);
+            for (int q = 0; q < 4; ++q) {
+                // (through a scalar: hipcc 7.2 miscompiles __builtin_bit_cast applied directly to a vector ELEMENT -- it
+                // reads element 0 whatever the subscript)
+                const uint32_t w = xr[j][q];
+                xsum[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2v, w), h2v{_Float16(1.f), _Float16(1.f)}, xsum[j], false);
+            }
         }
     };
 
     // ---- the lane's row: chunk ranges per slab from the packer's slab index ---------------------------------
+    // Memory latency is what bounds this kernel (two workgroups per CU), so nothing the inner loop needs is loaded
+    // where it is used: slab-index entries are fetched three slabs ahead, chunk data (two passes = 8 chunks per row)
+    // and the x slab one slab ahead, all issued at the top of an iteration with no dependent wait.
     const pbl_rowinfo ri = rinfo[rho_s];
-    auto slab_seq = [&](int s, int& fb, int& fn, int& tb, int& tn) {
-        const uint32_t e = slabtab[rho_s * NS + s];
-        const uint32_t pe = s > 0 ? slabtab[rho_s * NS + s - 1] : 0u;
-        fb = int(PBL_SLAB_FE(pe)) - int(PBL_SLAB_FBACK(e)); fn = int(PBL_SLAB_FE(e)) - fb;
-        tb = int(PBL_SLAB_TE(pe)) - int(PBL_SLAB_TBACK(e)); tn = int(PBL_SLAB_TE(e)) - tb;
+    const uint32_t* tabrow = slabtab + rho_s * NS;
+    auto tab = [&](int s) -> uint32_t { return (s >= 0 && s < NS) ? tabrow[s] : 0u; };
+    struct Seq { int fb, fn, tb, tn; };
+    auto seq_of = [&](uint32_t pe, uint32_t e) -> Seq {          // chunks of the row that overlap a slab: entries of slab s-1, s
+        Seq q;
+        q.fb = int(PBL_SLAB_FE(pe)) - int(PBL_SLAB_FBACK(e)); q.fn = int(PBL_SLAB_FE(e)) - q.fb;
+        q.tb = int(PBL_SLAB_TE(pe)) - int(PBL_SLAB_TBACK(e)); q.tn = int(PBL_SLAB_TE(e)) - q.tb;
+        return q;
     };
     // q-th chunk of the row's sequence for the slab (its full chunks, then its tail chunks)
-    auto load_chunk = [&](int q, int fb, int fn, int tb, int tn) -> ChunkRegs {
+    auto load_chunk = [&](int q, const Seq& sq) -> ChunkRegs {
         ChunkRegs r;
         r.col0 = PBL_NO_CHUNK; r.d4 = u32x4{0, 0, 0, 0}; r.q4 = u32x4{0, 0, 0, 0};
         int c = -1;
-        if (q < fn) c = int(ri.start) + fb + q;
-        else if (q - fn < tn) c = nfull + int(ri.tailidx) + tb + (q - fn);
+        if (q < sq.fn) c = int(ri.start) + sq.fb + q;
+        else if (q - sq.fn < sq.tn) c = nfull + int(ri.tailidx) + sq.tb + (q - sq.fn);
         if (c >= 0) { r.d4 = deltap[c]; r.q4 = codep[c]; r.col0 = int(col0p[c]); }
         return r;
     };
@@ -187,8 +197,12 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
             const uint32_t cc = min(uint32_t(col), padcol);
             const uint32_t q = (r.q4[e >> 2] >> (8 * (e & 3))) & 0xFFu;
             uint16_t bits;
-            if constexpr (SF) bits = __builtin_bit_cast(uint16_t, round_f16_twice(prs.z * (float(q) - prs.w)));
-            else bits = uint16_t(0x6400u | q);                 // fp16 1024 + q, exact
+            if constexpr (SF) {
+                bits = __builtin_bit_cast(uint16_t, round_f16_twice(prs.z * (float(q) - prs.w)));
+                if (!(bits & 0x7FFFu)) bits = 0x8000u;         // a salient of value 0 is stored as -0: "any bit set" = salient
+            } else {
+                bits = uint16_t(0x6400u | q);                  // fp16 1024 + q, exact
+            }
             strow[cc] = bits;
         }
     };
@@ -208,16 +222,17 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         for (int q = 0; q < 4; ++q) o[q] = (d[q] & Mcl) | Ccl;
         return __builtin_bit_cast(v8h, o);
     };
-    uint32_t c_one2 = 0x3C003C00u;                    // fp16x2 (1.0, 1.0) in a VGPR
-    asm volatile("" : "+v"(c_one2));
+    uint32_t c_one2 = 0x3C003C00u, c_int1 = 0x00010001u;   // fp16x2 (1.0, 1.0) and u16x2 (1, 1) in VGPRs
+    asm volatile("" : "+v"(c_one2), "+v"(c_int1));
     // salient mask {0, 1.0} from the tile fragment itself
     auto mfrag = [&](const u32x4 s) -> v8h {
         u32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if constexpr (SF) {   // any bit below the sign: nonzero fp16 (no coded salient is zero, PBL_FLAG_SLABS)
-                const uint32_t t = (s[q] & 0x7FFF7FFFu) + 0x7FFF7FFFu;          // bit 15 of each half = nonzero
-                o[q] = ((t >> 15) & 0x00010001u) * 0x3C00u;
+            if constexpr (SF) {   // any bit set (a zero VALUE is stored as -0): min(half, 1) * 0x3C00, two packed u16 ops
+                uint32_t t;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(s[q]), "v"(c_int1));
+                asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(o[q]) : "v"(t), "v"(c_one2));
             } else {              // stored halves are 0 or >= 0x6400: unsigned min with fp16 1.0.  Inline asm: hipcc 7.2
                                   // folds __builtin_elementwise_min over the four dwords of a vector into the FIRST one
                 asm("v_pk_min_u16 %0, %1, %2" : "=v"(o[q]) : "v"(s[q]), "v"(c_one2));
@@ -234,14 +249,18 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         reinterpret_cast<float4*>(smem_g + size_t(2) * XT * SSTR * 2 + size_t(tid >> 4) * MFMA_WAVE_BYTES + size_t(16) * SSTR * 2 + 1024)[tid & 15] = wp[tid & 15];
     }
     u32x4 t_cur = {0, 0, 0, 0}, t_next = {0, 0, 0, 0};
-    ChunkRegs cur, nxt;
-    cur.col0 = nxt.col0 = PBL_NO_CHUNK; cur.d4 = cur.q4 = nxt.d4 = nxt.q4 = u32x4{0, 0, 0, 0};
-    int fb = 0, fn = 0, tb = 0, tn = 0;
+    ChunkRegs cA, cB, nA, nB;                          // passes 0 and 1 of the current / next slab
+    cA.col0 = cB.col0 = nA.col0 = nB.col0 = PBL_NO_CHUNK;
+    cA.d4 = cA.q4 = cB.d4 = cB.q4 = nA.d4 = nA.q4 = nB.d4 = nB.q4 = u32x4{0, 0, 0, 0};
+    uint32_t eP = 0, e0 = 0, e1 = 0, e2 = 0;           // slab-index entries of slabs s-1, s, s+1, s+2
+    Seq sq = {0, 0, 0, 0};
     if (s0 < s1) {
         t_cur = __builtin_nontemporal_load(tiles + (s0 >> 1) * 64);
         load_x(s0);
-        slab_seq(s0, fb, fn, tb, tn);
-        cur = load_chunk(slot, fb, fn, tb, tn);
+        eP = tab(s0 - 1); e0 = tab(s0); e1 = tab(s0 + 1); e2 = tab(s0 + 2);
+        sq = seq_of(eP, e0);
+        cA = load_chunk(slot, sq);
+        cB = load_chunk(slot + 4, sq);
     }
     for (int i = lane; i < int(size_t(16) * SSTR * 2 / 16); i += GW) reinterpret_cast<u32x4*>(St)[i] = u32x4{0, 0, 0, 0};
     if (s0 < s1) store_x(0);
@@ -249,45 +268,67 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     for (int s = s0; s < s1; ++s) {
         const int buf = (s - s0) & 1, half = s & 1, cb = s * SLAB;
         const bool more = s + 1 < s1;
-        if (more) load_x(s + 1);                          // in flight across the whole slab
-        if (half && more) t_next = __builtin_nontemporal_load(tiles + ((s + 1) >> 1) * 64);
+        // x of THIS slab, loaded during the previous iteration, goes to its LDS tile first: the only wait on memory in
+        // the loop then is for loads that have had a whole iteration to land.  (Tile `buf` was last read two slabs ago
+        // and every wave has passed the previous slab's barrier since.)
+        if (s > s0) store_x(buf);
+        // everything slab s+1 needs from memory, issued now, consumed a slab later
+        const Seq sqn = seq_of(e0, e1);
+        uint32_t e3 = 0;
+        if (more) {
+            load_x(s + 1);
+            nA = load_chunk(slot, sqn);
+            nB = load_chunk(slot + 4, sqn);
+            e3 = tab(s + 3);
+            if (half) t_next = __builtin_nontemporal_load(tiles + ((s + 1) >> 1) * 64);
+        }
         {   // this slab's two sign-plane dwords -> Wp[sub-block][lane], as is and << 8
             const uint32_t w0 = half ? t_cur[2] : t_cur[0], w1 = half ? t_cur[3] : t_cur[1];
             Wp[lane] = w0; Wp[64 + lane] = w1; Wp8[lane] = w0 << 8; Wp8[64 + lane] = w1 << 8;
         }
-        // salient entries of the slab -> St: pass 0 was loaded one slab ahead
-        scatter(cur, cb);
+        // salient entries of the slab -> St: passes 0 and 1 were loaded one slab ahead; rows with more than 8 chunks
+        // in a slab (density above ~45 %, or many short chunks) fetch the rest on demand
+        scatter(cA, cb);
+        scatter(cB, cb);
         {
-            const int n = fn + tn;
-            for (int q = slot + 4; __any(q < n); q += 4) scatter(load_chunk(q, fb, fn, tb, tn), cb);
-        }
-        if (more) {
-            slab_seq(s + 1, fb, fn, tb, tn);
-            nxt = load_chunk(slot, fb, fn, tb, tn);
+            const int n = sq.fn + sq.tn;
+            for (int q = slot + 8; __any(q < n); q += 4) scatter(load_chunk(q, sq), cb);
         }
         __syncthreads();   // x tile `buf` complete (written one slab ago); everybody is done reading tile buf ^ 1; St / Wp ordered
         const _Float16* xt = Xs + size_t(buf) * XT * SSTR;
         // all 8 k-steps, branch free: right of K the x tile holds zeros (and the plane / St nothing), so a ragged last
-        // slab just adds zeros
+        // slab just adds zeros.  The fragments of k-step k+1 are read from LDS before the MFMAs of k-step k are issued
+        // (two waves per SIMD do not hide an LDS round trip per k-step by themselves).
+        struct Frags { u32x4 sd, wd; v8h bx[NTB]; };
+        auto read_frags = [&](int k8) -> Frags {
+            Frags f;
+            f.sd = *reinterpret_cast<const u32x4*>(St + row_a * SSTR + k8 * 32 + kblk * 8);
+            f.wd = *reinterpret_cast<const u32x4*>(Wsel + (k8 >> 2) * 64 + (k8 & 3) * 16 + kblk * 4);
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) f.bx[t] = *reinterpret_cast<const v8h*>(xt + (t * 16 + row_a) * SSTR + k8 * 32 + kblk * 8);
+            return f;
+        };
+        Frags fcur = read_frags(0);
 #pragma unroll
         for (int k8 = 0; k8 < 8; ++k8) {
-            const u32x4 sd = *reinterpret_cast<const u32x4*>(St + row_a * SSTR + k8 * 32 + kblk * 8);
-            const v8h aW = frag(*reinterpret_cast<const u32x4*>(Wsel + (k8 >> 2) * 64 + (k8 & 3) * 16 + kblk * 4));
-            const v8h aS = __builtin_bit_cast(v8h, sd);
-            const v8h aM = mfrag(sd);
+            Frags fnext = fcur;
+            if (k8 + 1 < 8) fnext = read_frags(k8 + 1);
+            const v8h aW = frag(fcur.wd);
+            const v8h aS = __builtin_bit_cast(v8h, fcur.sd);
+            const v8h aM = mfrag(fcur.sd);
 #pragma unroll
             for (int t = 0; t < ((PBL_MFMA_ABLATE & 4) ? 0 : NTB); ++t) {
-                const v8h bx = *reinterpret_cast<const v8h*>(xt + (t * 16 + row_a) * SSTR + k8 * 32 + kblk * 8);
-                accW[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aW, bx, accW[t], 0, 0, 0);
-                accS[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS, bx, accS[t], 0, 0, 0);
-                accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aM, bx, accM[t], 0, 0, 0);
+                accW[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aW, fcur.bx[t], accW[t], 0, 0, 0);
+                accS[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS, fcur.bx[t], accS[t], 0, 0, 0);
+                accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aM, fcur.bx[t], accM[t], 0, 0, 0);
             }
+            fcur = fnext;
         }
-        if (more) store_x(buf ^ 1);                       // next slab's x: everybody passed this slab's barrier, so tile buf ^ 1 is free
         if (!(PBL_MFMA_ABLATE & 8)) {
             for (int i = lane; i < int(size_t(16) * SSTR * 2 / 16); i += GW) reinterpret_cast<u32x4*>(St)[i] = u32x4{0, 0, 0, 0};
         }
-        cur = nxt;
+        cA = nA; cB = nB; sq = sqn;
+        eP = e0; e0 = e1; e1 = e2; e2 = e3;
         if (half) t_cur = t_next;
         // the tile is written as halves / dwords and read as 16-byte vectors: keep the compiler from moving the next
         // slab's stores across this slab's (type-based alias analysis would allow it; the LDS itself is in order)
@@ -342,21 +383,39 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     }
 }
 
-// y = sum over the K splits, in split order (deterministic)
+// y = sum over the K splits, in split order (deterministic); 4 elements per thread (MN is a multiple of 4 whenever N is,
+// the scalar tail covers the rest)
 __global__ __launch_bounds__(256) void pbl_mfma_reduce(const float* __restrict__ part, void* __restrict__ y, int KS, size_t MN, int y_f32) {
-    const size_t i = size_t(blockIdx.x) * 256 + threadIdx.x;
+    const size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * 4;
     if (i >= MN) return;
-    float s = part[i];
-    for (int k = 1; k < KS; ++k) s += part[size_t(k) * MN + i];
-    if (y_f32) static_cast<float*>(y)[i] = s;
-    else static_cast<_Float16*>(y)[i] = _Float16(s);
+    if (i + 4 <= MN && !(MN & 3)) {
+        float4 s = *reinterpret_cast<const float4*>(part + i);
+        for (int k = 1; k < KS; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(part + size_t(k) * MN + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (y_f32) *reinterpret_cast<float4*>(static_cast<float*>(y) + i) = s;
+        else {
+            _Float16* o = static_cast<_Float16*>(y) + i;
+            o[0] = _Float16(s.x); o[1] = _Float16(s.y); o[2] = _Float16(s.z); o[3] = _Float16(s.w);
+        }
+        return;
+    }
+    for (size_t j = i; j < MN && j < i + 4; ++j) {
+        float s = part[j];
+        for (int k = 1; k < KS; ++k) s += part[size_t(k) * MN + j];
+        if (y_f32) static_cast<float*>(y)[j] = s;
+        else static_cast<_Float16*>(y)[j] = _Float16(s);
+    }
 }
 
-// K splits so that a launch fields about two waves per SIMD (256 CUs x 4 SIMDs); at least 2 slabs per split
+// K splits so that ONE round of workgroups fills the chip: 256 CUs x 2 resident workgroups (LDS bound).  A second,
+// partly filled round costs a whole workgroup time, and every workgroup pays a prologue of ~3 dependent memory
+// latencies, so fewer, longer workgroups win; at least 2 slabs per split.
 void pick_split(const pbl_layer* L, int& KS, int& sps) {
     const int NS = int((L->K + SLAB - 1) / SLAB);
-    const int waves = int((L->NRB + WPG - 1) / WPG) * WPG;
-    int ks = (2048 + waves - 1) / waves;
+    const int groups = int((L->NRB + WPG - 1) / WPG);
+    int ks = 512 / groups;
     if (ks > NS / 2) ks = NS / 2;
     if (ks < 1) ks = 1;
     sps = (NS + ks - 1) / ks;
@@ -406,7 +465,7 @@ extern "C" int pbl_gemm_mfma_f16_ws(const pbl_layer* layer, const void* x, void*
         size_t MN = size_t(M) * layer->N;
         int KS = a.KS;
         void* rv[] = {&part, &y, &KS, &MN, &y_f32};
-        if (hipLaunchKernel(reinterpret_cast<const void*>(pbl_mfma_reduce), dim3(uint32_t((MN + 255) / 256)), dim3(256), rv, 0, st) != hipSuccess)
+        if (hipLaunchKernel(reinterpret_cast<const void*>(pbl_mfma_reduce), dim3(uint32_t((MN + 1023) / 1024)), dim3(256), rv, 0, st) != hipSuccess)
             return PBL_ERR_LAUNCH;
     }
     return PBL_OK;

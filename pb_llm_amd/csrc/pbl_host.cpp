@@ -136,9 +136,6 @@ void build_record(const PackArgs& a, uint32_t b, RecImage& out) {
                     for (int dq = 0; dq <= 2 && !coded; ++dq) {
                         int q = int(qf) + (dq == 0 ? 0 : (dq == 1 ? 1 : -1));
                         if (q >= 0 && q <= 255 && (a.sal16 ? dequant_f16(ss, sz, q) : dequant(ss, sz, q)) == v) {
-                            // PBL_FLAG_SLABS promise: in an fp16-checkpoint layer no CODED salient is zero (the
-                            // matrix-core kernels read "value != 0" as "salient"); a zero goes to the exception list
-                            if (a.sal16 && v == 0.f) break;
                             ents.push_back({uint16_t(c), uint8_t(q)});
                             coded = true;
                         }

@@ -267,7 +267,7 @@ class PBLinear(nn.Module, BinaryInterface):
 
     def forward(self, x):
         if torch.compiler.is_compiling():
-            m = self.packed
+            m = self._meta          # (the tracer cannot read tensor version counters; the header fields are constants of the module)
             return torch.ops.pbllm.linear(self.pbl_blob, self.pbl_bias, x,
                                           [m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch, m.max_nexc, m.nnz, m.nexc],
                                           self.weight_dtype == torch.float16, False)

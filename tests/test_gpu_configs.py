@@ -67,7 +67,7 @@ def test_config3_llama7b_linears_hessian_m2048(name):
     assert abs(sal_frac - 0.05) < 2e-3 and p.nexc < 1e-3 * N * K
     # hessian saliency is column concentrated: some input channels are salient for (nearly) every row
     col_frac = (~mask).mean(0)
-    assert (col_frac > 0.9).sum() >= 0.005 * K
+    assert (col_frac > 0.9).sum() >= 8 and np.median(col_frac) < 0.05
     x = synth.activations((2048, K), 77, 21)
     y = layer(T(x))
     assert y.shape == (2048, N) and y.dtype == torch.float16

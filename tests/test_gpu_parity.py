@@ -176,7 +176,7 @@ def test_g6_llama7b_qproj_gemv(llama7b_qproj):
     assert torch.equal(y, layer(T(x)))
     # traffic accounting
     assert p.algorithmic_bytes(1) == 4096 * 4096 // 8 + 2 * p.nnz + 4 * 4096 + 8 * 4096 + 4 * 4097 + 4 * 4096
-    assert p.nbytes < 1.12 * p.algorithmic_bytes(1)
+    assert p.nbytes < 1.13 * p.algorithmic_bytes(1)       # 7.3 % list format + alignment, 4.4 % slab index (matrix-core kernels only)
 
 
 # ---------------------------------------------------------------- shapes, batches, edge cases

@@ -26,9 +26,9 @@ out = {}
 for shp, _ in SHAPES:
     N, K = map(int, shp.split("x"))
     pk = PackedWeight.from_blob(blobs[shp])
-    ncopy = max(2, int(0.6e9 / (N * K * 0.3)))
+    ncopy = max(2, int(float(os.environ.get("PBL_BENCH_BYTES", "0.6e9")) / (N * K * 0.3)))
     layers = [pk.to("cuda:0") for _ in range(ncopy)]
-    for M in (16, 32):
+    for M in tuple(int(m) for m in os.environ.get("PBL_BENCH_M", "16,32").split(",")):
         x = torch.from_numpy(synth.activations((M, K), 3, 21)).cuda()
         def run():
             for l in layers: Q.mfma_forward(l, None, x)

@@ -58,10 +58,17 @@ def main():
             print(json.dumps(s))
     for sub in sorted(os.listdir(root)):
         p = os.path.join(root, sub)
-        if sub.startswith("pmc") and os.path.isdir(p):
-            st = pmc_stats(p)
+        if not os.path.isdir(p):
+            continue
+        if sub.endswith("_trace"):
+            print(f"\n## {sub}: kernel trace, un-instrumented timing (durations in us)")
+            for s in kernel_stats(p)[:6]:
+                print(json.dumps(s))
+        want = "pbl_mfma_kernel" if sub.startswith("mfma") else ("pbl_gemm" if sub.startswith("gemm") else "pbl_gemv")
+        if "pmc" in sub or "fetch" in sub or "write" in sub:
+            st = pmc_stats(p, want)
             if st:
-                print(f"\n## {sub}: per-dispatch averages for pbl_gemv_kernel")
+                print(f"\n## {sub}: per-dispatch averages for {want}")
                 print(json.dumps(st))
     cal = os.path.join(root, "calib")
     if os.path.isdir(cal):
