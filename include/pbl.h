@@ -261,6 +261,24 @@ int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, 
                          int L, int M, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch,
                          uint32_t max_nexc, int group_flags, int y_f32, void* stream);
 
+/* GEMM regime (M > 32 tokens: prefill, large batches) straight from the packed format: y[M,N] (fp16) = x[M,K] (fp16) @
+ * W^T + bias with fp32 accumulation, for layers whose every weight is an fp16 number (PBL_FLAG_SAL_F16: packed from an
+ * fp16 checkpoint; G == 1, K % 8 == 0, x and y 16-B aligned; else PBL_ERR_UNSUPPORTED and the caller falls back to
+ * pbl_unpack_dev + a library GEMM).  A workgroup rebuilds the exact fp16 weight tile of 8 records x 128 columns in LDS
+ * (sign plane through v_perm_b32, salients through the slab index) while the previous tile is multiplied with
+ * v_mfma_f32_16x16x32_f16 against 256 tokens of x staged in LDS (csrc/pbl_gemm_big.hip); the dense weight never exists
+ * in HBM.  Replaces nn.Linear over the dense fake-quant checkpoint at seq 2048 (gptq_pb/eval_ppl_utils.py:55-64). */
+int pbl_gemm_f16(const pbl_layer* layer, const void* x, void* y, int M, void* stream);
+
+/* Decode-time FUSED projections (q/k/v, gate/up: layers that read the same activation): L layers, ONE x [M, K] (fp16,
+ * 16-B aligned rows are not required), ONE output matrix y [M, ldy] in which layer l owns the columns
+ * [y_off[l], y_off[l] + N_l).  Unlike pbl_gemv_f16_grouped no pointer table refers to x or y, so the caller may pass
+ * freshly allocated tensors on every call and capture the launch in a hipGraph.  M <= 4; biases through the pbl_layer
+ * entries as usual.  The callers this replaces: three / two separate nn.Linear calls per decoder layer
+ * (gptq_pb/eval_ppl_utils.py:55-64 via the HF attention / MLP modules). */
+int pbl_gemv_f16_fused(const pbl_layer* layers_dev, const uint64_t* y_off_dev, const void* x, void* y, int L, int M,
+                       uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, void* stream);
+
 /* ---------------- QAT step, weight side ------------------------------------------ */
 /* The elementwise work of one training step of BinaryXnorExceptOutliersLinear
  * (quant/outlier_quantizer.py:83-99; straight-through estimator quant/quantizer.py:18-25), fused into

@@ -184,6 +184,12 @@ struct GemvArgs {
     int M;                // tokens in this pass (== MB)
     int y_f32;
     int grouped;
+    // fused launch (pbl_gemv_f16_fused): every layer reads the SAME x and writes its column range of ONE output
+    // matrix y[M, ldy]; x_shared / y_shared override xs[] / ys[] when set
+    const _Float16* x_shared;
+    void* y_shared;
+    const uint64_t* y_off;   // device: element offset of layer l's columns in a row of y
+    uint32_t ldy;            // row stride of y in elements (0: the layer's own N)
 };
 
 // Gather 8 fp16 values from LDS byte addresses a[0..7] into 4 packed half2 registers
@@ -276,11 +282,12 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     void* yg;
     if (args.grouped) {
         L = args.layers[blockIdx.y];
-        xg = static_cast<const _Float16*>(args.xs[blockIdx.y]);
-        yg = args.ys[blockIdx.y];
+        xg = args.x_shared ? args.x_shared : static_cast<const _Float16*>(args.xs[blockIdx.y]);
+        yg = args.y_shared ? static_cast<char*>(args.y_shared) + args.y_off[blockIdx.y] * (args.y_f32 ? 4 : 2) : args.ys[blockIdx.y];
     } else {
         L = args.layer; xg = args.x; yg = args.y;
     }
+    const size_t ldy = args.ldy ? size_t(args.ldy) : size_t(L.N);
     // XCD-aware record mapping (speed only, never correctness): the dispatcher places
     // workgroup b on XCD b % 8, so give each XCD a CONTIGUOUS range of a layer's records and
     // the 128-byte lines shared by neighbouring records stay within one L2.  Measured neutral
@@ -512,8 +519,8 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
         if (L.bias && row < L.N) yv += L.bias[row];
         if (PBL_ABLATE == 1 && abl == 0x9E3779B9u) yv += 1.f;
         if (sub == 0 && row < L.N) {
-            if (args.y_f32) static_cast<float*>(yg)[size_t(m) * L.N + row] = yv;
-            else static_cast<_Float16*>(yg)[size_t(m) * L.N + row] = _Float16(yv);
+            if (args.y_f32) static_cast<float*>(yg)[size_t(m) * ldy + row] = yv;
+            else static_cast<_Float16*>(yg)[size_t(m) * ldy + row] = _Float16(yv);
         }
     }
 }
@@ -558,11 +565,12 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
     void* yg;
     if (args.grouped) {
         L = args.layers[blockIdx.y];
-        xg = static_cast<const _Float16*>(args.xs[blockIdx.y]);
-        yg = args.ys[blockIdx.y];
+        xg = args.x_shared ? args.x_shared : static_cast<const _Float16*>(args.xs[blockIdx.y]);
+        yg = args.y_shared ? static_cast<char*>(args.y_shared) + args.y_off[blockIdx.y] * (args.y_f32 ? 4 : 2) : args.ys[blockIdx.y];
     } else {
         L = args.layer; xg = args.x; yg = args.y;
     }
+    const size_t ldy = args.ldy ? size_t(args.ldy) : size_t(L.N);
     const uint32_t rb0 = blockIdx.x * WPB;
     if (rb0 >= L.NRB) return;
     const int K = int(L.K), P = int(L.P), G = int(L.G);
@@ -732,8 +740,8 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
         float yv = T[m] + (Q - H) + e;
         if (L.bias && row < L.N) yv += L.bias[row];
         if (sub == 0 && row < L.N) {
-            if (args.y_f32) static_cast<float*>(yg)[size_t(m) * L.N + row] = yv;
-            else static_cast<_Float16*>(yg)[size_t(m) * L.N + row] = _Float16(yv);
+            if (args.y_f32) static_cast<float*>(yg)[size_t(m) * ldy + row] = yv;
+            else static_cast<_Float16*>(yg)[size_t(m) * ldy + row] = _Float16(yv);
         }
     }
 }
@@ -1025,6 +1033,32 @@ int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, 
     const bool sf = (any_groups & 2) != 0;   // bit 1: the group may contain PBL_FLAG_SAL_F16 layers
     hipStream_t st = static_cast<hipStream_t>(stream);
     // few records in total (fused q/k/v, gate+up at decode time): latency mode, S waves per record
+    const int split = uint64_t(max_NRB) * uint64_t(Lc) >= PBL_SPLIT_TARGET_WAVES ? 1 : pick_split(max_NRB * uint32_t(Lc), P);
+    if (split > 1) {
+        const dim3 grid(max_NRB, Lc, 1);
+        const size_t lds = lds_bytes(P, max_nch, M, split, split);
+        switch (split) {
+            case 8: return launch_split<8>(M, sf, a, grid, lds, st);
+            case 4: return launch_split<4>(M, sf, a, grid, lds, st);
+            default: return launch_split<2>(M, sf, a, grid, lds, st);
+        }
+    }
+    const int wpb = PBL_GROUPED_WPB;
+    const dim3 grid((max_NRB + wpb - 1) / wpb, Lc, 1);
+    return launch_mb<PBL_GROUPED_WPB>(M, sf, a, grid, lds_bytes(P, max_nch, M, wpb), st);
+}
+
+int pbl_gemv_f16_fused(const pbl_layer* layers_dev, const uint64_t* y_off_dev, const void* x, void* y, int Lc, int M,
+                       uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, void* stream) {
+    if (!layers_dev || !y_off_dev || !x || !y || Lc < 1 || M < 1 || M > PBL_MAX_TOKENS_PER_LAUNCH || !ldy)
+        return PBL_ERR_INVALID_ARG;
+    if ((group_flags & 1) || Lc > 65535) return PBL_ERR_UNSUPPORTED;
+    GemvArgs a{};
+    a.layers = layers_dev; a.M = M; a.y_f32 = y_f32; a.grouped = 1;
+    a.x_shared = static_cast<const _Float16*>(x); a.y_shared = y; a.y_off = y_off_dev; a.ldy = ldy;
+    const uint32_t P = (K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS;
+    const bool sf = (group_flags & 2) != 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     const int split = uint64_t(max_NRB) * uint64_t(Lc) >= PBL_SPLIT_TARGET_WAVES ? 1 : pick_split(max_NRB * uint32_t(Lc), P);
     if (split > 1) {
         const dim3 grid(max_NRB, Lc, 1);

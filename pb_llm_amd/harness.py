@@ -131,6 +131,95 @@ def quant_sequential_(model: nn.Module, calib_ids, low_frac: float, salient_metr
     return errors
 
 
+class _FusedMember(nn.Module):
+    """Stands where q_proj / k_proj / v_proj (or gate_proj / up_proj) stood.  The first member called with an activation
+    launches the whole group once (runtime.FusedGemv) and the others pick their slice up, as long as they are called
+    with the same tensor (HF attention / MLP modules call the projections back to back on one hidden_states).  More than
+    4 rows, or a non-fp16 activation: each member runs its own PBLinear (matrix-core / GEMM regime), bit-identical to the
+    unfused model."""
+
+    def __init__(self, group: "_FusedGroup", index: int, own: PBLinear):
+        super().__init__()
+        self.own = own                      # registered: state_dict / .to() keep working
+        self._group, self._index = [group], index          # (list: keep the group out of the module tree)
+        self.in_features, self.out_features = own.in_features, own.out_features
+        self.global_name = own.global_name
+
+    def forward(self, x):
+        g = self._group[0]
+        rows = x.numel() // x.shape[-1]
+        if x.dtype != torch.float16 or rows > 4 or not x.is_cuda or (torch.is_grad_enabled() and x.requires_grad):
+            return self.own(x)
+        key = (x.data_ptr(), x._version, tuple(x.shape))
+        if self._index == 0:
+            # the leader always launches: the allocator hands the next token's activation the same address, so a key
+            # match alone does not prove the cached outputs belong to this tensor
+            g.outs = g.fused(x.reshape(rows, x.shape[-1]).contiguous())
+            g.key, g.pending = key, set(range(1, len(g.outs)))
+            return g.outs[0].reshape(*x.shape[:-1], self.out_features)
+        if g.key == key and self._index in g.pending:      # each launch serves each follower once
+            g.pending.discard(self._index)
+            return g.outs[self._index].reshape(*x.shape[:-1], self.out_features)
+        return self.own(x)
+
+
+class _FusedGroup:
+    def __init__(self, mods: list[PBLinear]):
+        from .runtime import FusedGemv
+        dev = mods[0].pbl_blob.device
+        self.fused = FusedGemv([m.packed for m in mods], [m.pbl_bias for m in mods], dev)
+        self.key, self.outs, self.pending = None, None, set()
+
+
+FUSE_SETS = (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))     # LLaMA naming (HF)
+
+
+def fuse_decode_(model: nn.Module, sets=FUSE_SETS) -> int:
+    """Decode-time fusion: in every module that holds all the projections of a set as PBLinears with one
+    in_features (HF LlamaAttention: q/k/v_proj; LlamaMLP: gate/up_proj), replace them by members of one fused launch.
+    7 launches per decoder layer become 4.  Returns the number of groups created.  The caller this serves is the token
+    loop of gptq_pb/eval_ppl_utils.py:55-64 / qat/eval_after_qat.py:11-33 at batch 1."""
+    n = 0
+    for mod in list(model.modules()):
+        for names in sets:
+            subs = [getattr(mod, nm, None) for nm in names]
+            if not all(isinstance(m_, PBLinear) for m_ in subs):
+                continue
+            if len({m_.in_features for m_ in subs}) != 1 or any(m_.packed.G > 1 for m_ in subs) or not subs[0].pbl_blob.is_cuda:
+                continue
+            grp = _FusedGroup(subs)
+            for i, (nm, m_) in enumerate(zip(names, subs)):
+                setattr(mod, nm, _FusedMember(grp, i, m_))
+            n += 1
+    return n
+
+
+class GraphedForward:
+    """One forward of `model` on a fixed input shape captured in a hipGraph (the C ABI launches are asynchronous and
+    allocation free; torch's caching allocator serves the temporaries from the graph's private pool).  replay(ids) copies
+    the new token ids into the static input and replays: per-token host cost is one graph launch instead of hundreds of
+    Python-side kernel launches."""
+
+    def __init__(self, model: nn.Module, example_ids: torch.Tensor, warmup: int = 2):
+        self.model = model
+        self.static_ids = example_ids.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(warmup):
+                model(self.static_ids, use_cache=False)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.static_logits = model(self.static_ids, use_cache=False).logits
+
+    def replay(self, ids: torch.Tensor) -> torch.Tensor:
+        self.static_ids.copy_(ids)
+        self.graph.replay()
+        return self.static_logits
+
+
 @torch.no_grad()
 def perplexity(model: nn.Module, input_ids: torch.Tensor, seqlen: int) -> float:
     """The loop of gptq_pb/eval_ppl_utils.py:55-86 / evaluate.py:126-156 on pre-tokenised ids

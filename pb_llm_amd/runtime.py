@@ -67,3 +67,46 @@ class GroupedGemv:
             self.M, self.max_NRB, self.max_K, self.max_nch, self.max_nexc, self.any_groups, int(self.out_f32), st),
             "grouped gemv")
         return self.y
+
+
+class FusedGemv:
+    """Decode-time fusion of projections that read the same activation (q/k/v; gate/up): ONE launch, one output tensor.
+    __call__(x [M <= 4, K] fp16) -> list of [M, N_l] views of a fresh [M, sum N_l] tensor.  No pointer table refers to x
+    or y (pbl_gemv_f16_fused), so every call may use new tensors and the launch can be captured in a hipGraph."""
+
+    def __init__(self, packed: list[PackedWeight], biases: list[torch.Tensor | None] | None = None, device="cuda"):
+        if not packed:
+            raise ValueError("empty group")
+        if len({p.K for p in packed}) != 1:
+            raise ValueError("fused projections share their input: equal in_features")
+        if any(p.G > 1 for p in packed):
+            raise ValueError("column-group layers are not supported in a fused launch")
+        self.device = torch.device(device)
+        self.packed = [p if p.blob.device == self.device else p.to(self.device) for p in packed]
+        biases = biases or [None] * len(packed)
+        self.biases = [b.detach().float().to(self.device) if b is not None else None for b in biases]
+        self.K = self.packed[0].K
+        self.Ns = [p.N for p in self.packed]
+        self.offs = np.cumsum([0] + self.Ns)
+        structs = (_lib.PblLayer * len(self.packed))(*[p.layer_struct(b) for p, b in zip(self.packed, self.biases)])
+        self._layers_dev = torch.from_numpy(np.frombuffer(bytes(structs), dtype=np.uint8).copy()).to(self.device)
+        self._yoff_dev = torch.tensor(self.offs[:-1].tolist(), dtype=torch.int64, device=self.device)
+        self.max_NRB = max(p.NRB for p in self.packed)
+        self.max_nch = max(p.max_nch for p in self.packed)
+        self.flags = 2 * int(any(p.flags & _lib.PBL_FLAG_SAL_F16 for p in self.packed))
+
+    def __call__(self, x2: torch.Tensor, out_f32: bool = False) -> list[torch.Tensor]:
+        M = x2.shape[0]
+        if x2.dtype != torch.float16 or not x2.is_contiguous() or x2.shape[1] != self.K or not 1 <= M <= _lib.PBL_MAX_TOKENS_PER_LAUNCH:
+            raise _lib.PblError("FusedGemv: x must be a contiguous fp16 [M <= 4, K] tensor")
+        total = int(self.offs[-1])
+        y = torch.empty(M, total, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
+        st = torch.cuda.current_stream(x2.device).cuda_stream
+        _lib.check(_lib.lib().pbl_gemv_f16_fused(self._layers_dev.data_ptr(), self._yoff_dev.data_ptr(), x2.data_ptr(), y.data_ptr(),
+                                                 len(self.packed), M, total, self.max_NRB, self.K, self.max_nch, self.flags,
+                                                 int(out_f32), st), "fused gemv")
+        return [y[:, int(self.offs[i]):int(self.offs[i + 1])] for i in range(len(self.packed))]
+
+    def algorithmic_bytes(self, M: int = 1) -> int:
+        # x is read once for the group, not once per layer
+        return sum(p.algorithmic_bytes(M, b is not None) for p, b in zip(self.packed, self.biases)) - 2 * M * self.K * (len(self.packed) - 1)

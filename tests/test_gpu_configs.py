@@ -46,10 +46,11 @@ def cfg3_layer(name):
     """packed llama-7b linear `name` at low_frac 0.95 with hessian salients (fp16 checkpoint, as gptq_pb writes it)"""
     if name not in _cache:
         N, K = LLAMA7B[name]
-        W, mask, r = hessian_layer(N, K, 0.95, seed=300 + len(_cache))
+        W, mask, r = hessian_layer(N, K, 0.95, seed=300 + len(_cache) // 2)
         W16 = torch.from_numpy(r["W_fq"]).half()
         layer = Q.PBLinear.from_dense(W16, None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
         _cache[name] = (layer, W16, mask)
+        _cache[name + "_rtn"] = r
     return _cache[name]
 
 
@@ -89,14 +90,18 @@ def test_config5_ksplit_shards_on_one_gpu(world):
     N, K = LLAMA7B["down_proj"]
     pts = PP.split_points(K, world, PP.COL_ALIGN)
     assert pts[-1] == K and all(p % 128 == 0 for p in pts[:-1]) and len(set(np.diff(pts))) <= 2
+    rh = _cache["down_proj_rtn"]
+    mods = []
+    for rank in range(world):                                       # the P shards, built once (quantizer state handed through)
+        shard, (c0, c1) = PP.shard_linear(W16, None, torch.from_numpy(mask), "k", rank, world, high_scale=rh["hscale"],
+                                          high_zero=rh["hzero"])
+        assert (c0, c1) == (pts[rank], pts[rank + 1])
+        mods.append((PP.PBLinearKSplit(shard.to(DEV), (c0, c1)), c0, c1))
     for M in (1, 8):
         x = synth.activations((M, K), 5 + world, 21)
         xt = T(x)
         total = torch.zeros(M, N, dtype=torch.float32, device=DEV)
-        for rank in range(world):
-            shard, (c0, c1) = PP.shard_linear(W16, None, torch.from_numpy(mask), "k", rank, world)
-            assert (c0, c1) == (pts[rank], pts[rank + 1])
-            mod = PP.PBLinearKSplit(shard.to(DEV), (c0, c1))
+        for mod, c0, c1 in mods:
             part = mod.local_forward(xt[:, c0:c1].contiguous())
             assert part.dtype == torch.float32 and part.shape == (M, N)
             total += part
@@ -115,7 +120,9 @@ def test_config5_nsplit_shards_on_one_gpu(world):
     full = layer(x)
     parts = []
     for rank in range(world):
-        shard, (r0, r1) = PP.shard_linear(W16, None, torch.from_numpy(mask), "n", rank, world)
+        rh = _cache["gate_proj_rtn"]
+        shard, (r0, r1) = PP.shard_linear(W16, None, torch.from_numpy(mask), "n", rank, world, high_scale=rh["hscale"],
+                                          high_zero=rh["hzero"])
         assert r0 % 16 == 0
         parts.append(PP.PBLinearNSplit(shard.to(DEV), (r0, r1), N, gather_output=False)(x))
     assert torch.equal(torch.cat(parts, -1), full)
@@ -329,3 +336,93 @@ def test_mfma_k_split_equals_unsplit():
         assert_parity(ys, ref, 2e-4)
         assert_parity(yu, ref, 2e-4)
         assert torch.equal(ys, Q.mfma_forward(p, b, T(x), out_f32=True, split=True))    # deterministic
+
+
+# ------------------------------------------------------------------------------------------- (f4) decode path of the harness
+def test_fused_decode_and_graph_replay_bit_for_bit():
+    """harness.fuse_decode_: q/k/v and gate/up of every decoder layer become ONE launch each (7 -> 4 per layer); the logits
+    of a token-by-token forward equal the unfused model's BIT FOR BIT, also for consecutive tokens whose activations
+    reuse the same device address; longer prompts fall through to the members' own kernels; GraphedForward replays the
+    captured forward with new token ids and reproduces the eager logits exactly."""
+    import copy
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from pb_llm_amd import harness as H
+    from pb_llm_amd.runtime import FusedGemv
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8,
+                      num_key_value_heads=8, vocab_size=1000, max_position_embeddings=256)
+    model = LlamaForCausalLM(cfg).half().eval()
+
+    def producer(name, W):
+        Wn = W.float().numpy()
+        mask = O.ptq_low_mask(Wn, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(Wn, mask, 8, -1)
+        return dict(W_fq=torch.from_numpy(r["W_fq"]), low_mask=torch.from_numpy(mask), hscale=r["hscale"], hzero=r["hzero"])
+
+    side = H.quantize_dense_(model, producer)
+    plain = H.to_pb_(model, side).to(DEV)
+    fused = copy.deepcopy(plain)
+    assert H.fuse_decode_(fused) == 4                       # 2 layers x (qkv, gate/up)
+    ids = torch.from_numpy((synth.uniform01(64, 7, 1) * 1000).astype(np.int64)).view(1, -1).to(DEV)
+    with torch.no_grad():
+        for t in range(6):                                  # single tokens, one after the other (M = 1)
+            tok = ids[:, t:t + 1]
+            assert torch.equal(fused(tok, use_cache=False).logits, plain(tok, use_cache=False).logits), t
+        for T_ in (3, 4, 5, 40):                            # <= 4 rows fused, above: the members' own kernels
+            assert torch.equal(fused(ids[:, :T_], use_cache=False).logits, plain(ids[:, :T_], use_cache=False).logits), T_
+    # the fused launch itself against the oracle, with biases and unequal N
+    W1, W2 = synth.llm_weight(96, 512, seed=3), synth.llm_weight(160, 512, seed=4)
+    ps, refs, bs = [], [], []
+    x = synth.activations((3, 512), 5, 21)
+    for i, W in enumerate((W1, W2)):
+        mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        b = synth.normal((W.shape[0],), 6 + i, 3, 0.1)
+        ps.append(pack_dense(r["W_fq"], r["scale"][0] + r["mean"][0], -r["scale"][0] + r["mean"][0], r["hscale"], r["hzero"],
+                             (~mask).astype(np.uint8)))
+        bs.append(T(b)); refs.append(O.dense_linear(x, r["W_fq"], b))
+    outs = FusedGemv(ps, bs, DEV)(T(x))
+    assert outs[0].shape == (3, 96) and outs[1].shape == (3, 160) and outs[0].data_ptr() + 96 * 2 == outs[1].data_ptr()
+    for o, ref in zip(outs, refs):
+        assert_parity(o, ref)
+    # hipGraph: capture one single-token forward, replay with other tokens
+    g = H.GraphedForward(fused, ids[:, :1])
+    with torch.no_grad():
+        for t in (9, 10, 11):
+            tok = ids[:, t:t + 1]
+            assert torch.equal(g.replay(tok), plain(tok, use_cache=False).logits), t
+
+
+# ------------------------------------------------------------------------------------------- GEMM regime, fused kernel
+@pytest.mark.parametrize("N,K,M,lf,bias", [(256, 512, 33, 0.9, True), (130, 1288, 300, 0.8, False), (4096, 4096, 2048, 0.95, False),
+                                           (1000, 11008, 257, 0.95, True)])
+def test_fused_gemm_kernel(N, K, M, lf, bias):
+    """pbl_gemm_f16: exact fp16 weight tiles rebuilt in LDS from the packed records, v_mfma_f32_16x16x32_f16 against
+    x staged in LDS -- against the float64 oracle (sampled rows at the large shape) and against the library GEMM on the
+    unpacked layer (same operands, different summation order).  Ragged N / K / M, exceptions, bias."""
+    W = synth.llm_weight(N, K, seed=N + K, heavy_tail=True)
+    mask = O.ptq_low_mask(W, lf, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    W16 = torch.from_numpy(r["W_fq"]).half()
+    W16[min(5, N - 1), K // 2 + 1] = 0.4321                       # an exception
+    W16[N - 1, K - 1] = -0.0625
+    b = synth.normal((N,), 2, 3, 0.1) if bias else None
+    layer = Q.PBLinear.from_dense(W16, T(b).cpu() if bias else None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+    assert layer.packed.flags & _lib.PBL_FLAG_SAL_F16 and layer.packed.nexc >= 1
+    x = synth.activations((M, K), N, 21)
+    xt = T(x)
+    y = Q.fused_gemm_forward(layer.packed, layer.pbl_bias, xt)
+    assert y.shape == (M, N) and y.dtype == torch.float16
+    rows = np.arange(N) if N * K * M < 4e9 else np.unique(np.concatenate([np.arange(0, N, N // 160), [N - 1, N - 17, 127, 128]]))
+    ref = O.dense_linear(x, W16.numpy()[rows], None if b is None else b[rows])
+    assert_parity(y[:, torch.from_numpy(rows).to(DEV)], ref)
+    old = Q.GEMM_BACKEND
+    try:
+        Q.GEMM_BACKEND = "library"
+        y_lib = layer(xt)
+        Q.GEMM_BACKEND = "fused"
+        assert torch.equal(layer(xt), y)                            # the module routes the GEMM regime to the fused kernel
+    finally:
+        Q.GEMM_BACKEND = old
+    assert_parity(y, y_lib.float().cpu().numpy().astype(np.float64), 2e-3)
+    assert torch.equal(y, Q.fused_gemm_forward(layer.packed, layer.pbl_bias, xt))      # deterministic

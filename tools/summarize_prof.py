@@ -64,8 +64,8 @@ def main():
             print(f"\n## {sub}: kernel trace, un-instrumented timing (durations in us)")
             for s in kernel_stats(p)[:6]:
                 print(json.dumps(s))
-        want = "pbl_mfma_kernel" if sub.startswith("mfma") else ("pbl_gemm" if sub.startswith("gemm") else "pbl_gemv")
-        if "pmc" in sub or "fetch" in sub or "write" in sub:
+        want = "pbl_mfma_kernel" if sub.startswith("mfma") else ("pbl_gemm_kernel" if sub.startswith("gemm") else "pbl_gemv")
+        if "pmc" in sub or "fetch" in sub or "write" in sub or "tcc" in sub:
             st = pmc_stats(p, want)
             if st:
                 print(f"\n## {sub}: per-dispatch averages for {want}")
