@@ -164,7 +164,7 @@ def main():
 
     if a.gpus > 1 and "RANK" not in os.environ:
         # started directly: become the launcher of N ranks, one per GPU (RCCL over xGMI)
-        if torch.cuda.device_count() < a.gpus:
+        if torch.cuda.device_count() < a.gpus and os.environ.get("PBL_BENCH_BACKEND", "nccl") == "nccl":
             sys.exit(f"bench.py --gpus {a.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
         port = os.environ.get("MASTER_PORT", "29511")
         os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
@@ -179,13 +179,20 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
                  f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback for the product path)"
-    dev = torch.device(f"cuda:{local}")
+    # PBL_BENCH_BACKEND=gloo: plumbing test of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
+    # control tensors travel over gloo, --collective p2p does the data-path sum); never a measurement.
+    backend = os.environ.get("PBL_BENCH_BACKEND", "nccl")
+    dev = torch.device(f"cuda:{local % torch.cuda.device_count() if backend != 'nccl' else local}")
     torch.cuda.set_device(dev)
+    ctl = dev if backend == "nccl" else torch.device("cpu")
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         assert dist.get_world_size() == a.gpus
 
     import __graft_entry__ as ge
@@ -278,7 +285,7 @@ def main():
         torch.cuda.synchronize()
         done = time.perf_counter() - t_pre >= a.preheat_s
         if use_dist:   # every rank must leave the loop after the same number of collectives
-            flag = torch.tensor([int(done)], device=dev)
+            flag = torch.tensor([int(done)], device=ctl)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             done = bool(flag.item())
         if done:
@@ -309,7 +316,7 @@ def main():
     dev_s = e0.elapsed_time(e1) * 1e-3
     kern_s = sum(s.elapsed_time(e) for s, e in kev) * 1e-3 if kev else dev_s
     if use_dist:
-        tt = torch.tensor([wall, dev_s, kern_s], device=dev, dtype=torch.float64)
+        tt = torch.tensor([wall, dev_s, kern_s], device=ctl, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_s, kern_s = tt.tolist()
 
