@@ -135,6 +135,83 @@ def cpu_baseline(dense_layers, K, M, budget_s=8.0):
     return out
 
 
+def run_side_workload(a):
+    """--workload cfg3 | cfg4: the other single-GPU configurations of BASELINE.json as bench lines of their own (the driver
+    runs the default workload; these feed profiles/).  One step = one pass over the configuration's linears.
+      cfg3  configs[2]: the seven linears of a llama-7b decoder layer, low_frac 0.95 HESSIAN salients, M = 2048 (prefill);
+            bound: fp16 MFMA (2.5 PFLOP/s dense).  value = tokens/s of the 32-layer stack's linears = M / (32 t_layer).
+      cfg4  configs[3]: llama-13b FFN 13824x5120 and 5120x13824, low_frac 0.8, M = 32; bound: HBM."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from cfg_shapes import LLAMA7B, hessian_layer
+    from oracle import pb_oracle as O
+    from pb_llm_amd import synth
+    import pb_llm_amd.quant as Q
+    import __graft_entry__ as ge
+    ge.build()
+    dev = torch.device("cuda:0")
+    layers, flops, alg = [], 0.0, 0
+    if a.workload == "cfg3":
+        M = 2048
+        built = {}
+        for name, (N, K) in LLAMA7B.items():
+            key = (N, K)
+            if key not in built:
+                W, mask, r = hessian_layer(N, K, 0.95, seed=300 + len(built))
+                built[key] = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1,
+                                                   r["hscale"], r["hzero"])
+            layers.append(Q.PBLinear(built[key].packed.to(dev), None))           # own device copy per linear
+            flops += 2.0 * M * N * K
+    else:
+        M = 32
+        for N, K in ((13824, 5120), (5120, 13824)):
+            W = synth.llm_weight(N, K, seed=N % 97)
+            mask = O.ptq_low_mask(W, 0.8, "magnitude", None, -1)
+            r = O.ptq_rtn(W, mask, 8, -1)
+            base = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
+            for _ in range(6):                                                    # 6 device copies each: beyond the Infinity Cache
+                layers.append(Q.PBLinear(base.packed.to(dev), None))
+    Q.GEMM_BACKEND = a.gemm_backend
+    xs = {K: torch.from_numpy(synth.activations((M, K), 3, 21)).to(dev) for K in {l.in_features for l in layers}}
+    alg = sum(l.packed.algorithmic_bytes(M) for l in layers)
+
+    def run():
+        for l in layers:
+            l(xs[l.in_features])
+
+    with torch.no_grad():
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < a.preheat_s:
+            run(); torch.cuda.synchronize()
+        for _ in range(a.warmup):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(a.steps):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    dev_s = e0.elapsed_time(e1) * 1e-3 / a.steps
+    if a.workload == "cfg3":
+        roof = {"bound": "mfma", "achieved": flops / dev_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "traffic": None,
+                "kernel": "pbl_gemm_kernel" if a.gemm_backend == "fused" else "pbl_unpack_kernel + library GEMM",
+                "us_per_step": 1e6 * dev_s}
+        value, unit = M / (32 * wall / a.steps), "tokens/s (linears of a 32-layer stack)"
+        work = "llama-7b decoder-layer linears (q,k,v,o 4096x4096; gate,up 11008x4096; down 4096x11008), low_frac 0.95 hessian, M=2048"
+    else:
+        roof = {"bound": "hbm", "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+                "kernel": "pbl_mfma_kernel", "us_per_step": 1e6 * dev_s, "us_per_layer": 1e6 * dev_s / len(layers)}
+        value, unit = len(layers) * M / (wall / a.steps), "layer-tokens/s"
+        work = "llama-13b FFN 13824x5120 + 5120x13824 (6 device copies each), low_frac 0.8, M=32"
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    print(json.dumps({"metric": f"PB-linear side workload {a.workload}", "value": value, "unit": unit, "n_gpus": 1,
+                      "steps": a.steps, "warmup": a.warmup, "preheat_s": a.preheat_s, "ms_per_step": 1e3 * wall / a.steps,
+                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 in/out, f32 accumulate",
+                      "data": "synthetic", "config": {"workload": work, "gemm_backend": a.gemm_backend}, "roofline": roof}), flush=True)
+
+
 # role of layer i in a llama decoder layer (SURVEY 8(e) "LLaMA layer mapping"): True = K-split (+ all-reduce)
 TP_KSPLIT_ROLE = (False, False, False, True, False, False, True)   # q k v o gate up down
 
@@ -160,7 +237,14 @@ def main():
                          "layer streams per rank (weak scaling, no collective)")
     ap.add_argument("--collective", choices=["rccl", "p2p"], default="rccl",
                     help="tp all-reduce: RCCL (torch.distributed) or libpbl's one-shot peer-to-peer all-reduce")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
+                    help="cfg2 = BASELINE configs[1], the headline GEMV stream (default, what the driver runs); cfg3 / cfg4: "
+                         "configs[2] / configs[3] as side lines (see run_side_workload)")
+    ap.add_argument("--gemm-backend", choices=["library", "fused"], default="library")
     a = ap.parse_args()
+    if a.workload != "cfg2":
+        assert a.gpus == 1, "side workloads are single-GPU lines"
+        return run_side_workload(a)
 
     if a.gpus > 1 and "RANK" not in os.environ:
         # started directly: become the launcher of N ranks, one per GPU (RCCL over xGMI)

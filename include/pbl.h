@@ -197,6 +197,23 @@ int pbl_pack_dense_f32(const float* W, uint32_t N, uint32_t K, uint32_t G,
                        const uint8_t* sal_mask, uint32_t flags /* PBL_FLAG_SAL_F16 or 0 */,
                        void* out, size_t out_capacity, size_t* out_bytes);
 
+/* Device-side packer: the same blob, BYTE FOR BYTE, from device tensors (csrc/pbl_pack.hip; one wavefront per record).
+ * Two steps because the blob's size depends on the data:
+ *   1. pbl_pack_dev_count -> counts_out [NRB][PBL_PACK_COUNT_WORDS] u32 (device): word 0 record bytes, 1 nfull, 2 ntail,
+ *      3 nexc, 4 coded entries, 5 status (non-zero: the layer exceeds the format's limits), 8.. per-row counts;
+ *   2. the caller prefix-sums word 0 into rec_off [NRB+1] (u64, device; rec_off[0] = PBL_ALIGN128(80 + 16 (NRB+1)), the
+ *      last entry = blob size), reduces max(nfull+ntail), max(nexc), sum(word 4), sum(nexc), allocates the blob and calls
+ *      pbl_pack_dev_write, which writes header, rb_info and every record (padding zeroed).
+ * All pointers are device pointers (W fp32 [N,K]; hi, lo [N,G]; sscale, szero [N] or NULL; sal_mask u8 [N,K] or NULL). */
+#define PBL_PACK_COUNT_WORDS 56
+int pbl_pack_dev_count(const float* W, uint32_t N, uint32_t K, uint32_t G, const float* hi, const float* lo,
+                       const float* sscale, const float* szero, const uint8_t* sal_mask, uint32_t flags,
+                       uint32_t* counts_out, void* stream);
+int pbl_pack_dev_write(const float* W, uint32_t N, uint32_t K, uint32_t G, const float* hi, const float* lo,
+                       const float* sscale, const float* szero, const uint8_t* sal_mask, uint32_t flags,
+                       const uint32_t* counts, const uint64_t* rec_off, uint64_t blob_bytes, uint32_t max_nch, uint32_t max_nexc,
+                       uint64_t nnz, uint64_t nexc, void* blob_out, void* stream);
+
 /* Validate a host blob and fill a pbl_layer (blob/bias pointers are left NULL).  The WHOLE structure is checked, not
  * only the header: record offsets monotone, 128-byte aligned and inside the blob; every record's header equal to its
  * rb_info entry and its size equal to the layout macros; rowinfo ranges consistent with the chunk counts; every chunk's

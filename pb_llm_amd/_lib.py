@@ -18,6 +18,7 @@ PBL_FLAG_HAS_GROUPS = 0x1
 PBL_FLAG_SAL_F16 = 0x2
 PBL_FLAG_TAIL_REPEAT = 0x4
 PBL_FLAG_SLABS = 0x8
+PBL_PACK_COUNT_WORDS = 56
 PBL_DTYPE_F32, PBL_DTYPE_F16, PBL_DTYPE_BF16 = 0, 1, 2
 (PBL_OK, PBL_ERR_INVALID_ARG, PBL_ERR_BAD_BLOB, PBL_ERR_UNSUPPORTED, PBL_ERR_MISALIGNED, PBL_ERR_CAPACITY, PBL_ERR_LAUNCH,
  PBL_ERR_NOT_REPRESENTABLE) = (0, -1, -2, -3, -4, -5, -6, -7)
@@ -45,7 +46,7 @@ class PblError(RuntimeError):
 
 _lib = None
 
-EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_blob_describe",
+EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_pack_dev_count", "pbl_pack_dev_write", "pbl_blob_describe",
            "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_linear_f16_ws", "pbl_gemm_mfma_f16",
            "pbl_gemm_mfma_f16_ws", "pbl_mfma_workspace_bytes", "pbl_gemv_f16_grouped", "pbl_gemv_f16_fused", "pbl_gemm_f16",
            "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad",
@@ -71,6 +72,10 @@ def lib() -> C.CDLL:
     L.pbl_version.restype = C.c_int
     L.pbl_pack_dense_f32.restype = C.c_int
     L.pbl_pack_dense_f32.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp, sz, C.POINTER(sz)]
+    L.pbl_pack_dev_count.restype = C.c_int
+    L.pbl_pack_dev_count.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp, vp]
+    L.pbl_pack_dev_write.restype = C.c_int
+    L.pbl_pack_dev_write.argtypes = [vp, u32, u32, u32, vp, vp, vp, vp, vp, u32, vp, vp, C.c_uint64, u32, u32, C.c_uint64, C.c_uint64, vp, vp]
     L.pbl_blob_describe.restype = C.c_int
     L.pbl_blob_describe.argtypes = [vp, sz, C.POINTER(PblLayer)]
     L.pbl_unpack_dense_f32.restype = C.c_int

@@ -15,8 +15,8 @@
 //     as b128 (4 dwords = 8 columns x 16 rows, broadcast over the 16 row-lanes); ONE v_and_or per dword turns them
 //     into a CLASS-CODED fp16 A fragment -- the GEMV's (w & M_c) | C_c trick indexed by the lane's own row;
 //   * finds its record's salient chunks of the slab through the packer's slab index (include/pbl.h: no sort, no
-//     search): lane (row = lane / 4, slot = lane % 4) takes the row's chunks slot, slot + 4, ... and writes all 16
-//     entries of each into the fp16 tile St[16][256] -- the code as 1024 + q (0x6400 | q: one OR, exact), or for
+//     search): the 4 lanes of a row (row = lane / 4) take the row's chunks one after the other, each lane a quarter
+//     (4 entries: short dependent chains, no idle lanes at low density), and write them into the fp16 tile St[16][256] -- the code as 1024 + q (0x6400 | q: one OR, exact), or for
 //     fp16 checkpoints the double-rounded fp16 weight; entries left or right of the slab are clamped into pad columns;
 //   * derives the salient MASK fragment from the tile it has just read: v_pk_min_u16(s, 0x3C00) for codes (every
 //     stored half is >= 0x6400), min(s, 1) * 0x3C00 for fp16 values (a salient of value 0 is stored as -0, so every
@@ -65,7 +65,13 @@ __device__ __forceinline__ void class_consts_g(int ci, float& A, float& B, uint3
     Cc = (ci < 2 || ci == 7) ? 0x3C003C00u : 0u;   // classes whose two values are 1.0 + {0, d}
 }
 
-// one salient chunk held in registers: its 16 byte-steps, 16 codes, first column
+// One salient chunk in registers: its 16 byte steps, 16 codes, first column.  Two lane mappings (template parameter Q4):
+//   Q4 = false  lane (row, slot) owns whole chunks slot, slot + 4, ... of its row: 16 entries per lane and pass.  Best when a
+//               row has several chunks per slab (config 4 at 20 % salients: ~4): every lane is busy, 8 chunks per row are
+//               prefetched a slab ahead.
+//   Q4 = true   the 4 lanes of a row share ONE chunk, a quarter (4 entries) each: short dependent chains and no idle lanes
+//               when a row has only 1-2 chunks per slab (<= ~12 % salients); measured -5 % at 4096^2 / 10 %, but +16 % on
+//               config 4, where the round count is the MAXIMUM chunk count over the 16 rows.
 struct ChunkRegs {
     u32x4 d4, q4;
     int col0;               // PBL_NO_CHUNK: nothing to do
@@ -84,7 +90,7 @@ __host__ __device__ constexpr size_t mfma_lds_bytes(int ntb) {
     return size_t(2) * 16 * ntb * SSTR * 2 + WPG * MFMA_WAVE_BYTES + 128;
 }
 
-template <int NTB, bool SF>
+template <int NTB, bool SF, bool Q4>
 __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     constexpr int XT = 16 * NTB;                   // token rows of the x tile
@@ -173,29 +179,32 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         q.tb = int(PBL_SLAB_TE(pe)) - int(PBL_SLAB_TBACK(e)); q.tn = int(PBL_SLAB_TE(e)) - q.tb;
         return q;
     };
-    // q-th chunk of the row's sequence for the slab (its full chunks, then its tail chunks)
-    auto load_chunk = [&](int q, const Seq& sq) -> ChunkRegs {
+    // j-th chunk of the row's sequence for the slab (its full chunks, then its tail chunks): the same chunk for the row's 4 lanes
+    // round `rnd` of the lane's work on the slab: chunk rnd of the row (Q4: shared by the row's 4 lanes) or chunk slot + 4 rnd
+    auto load_chunk = [&](int rnd, const Seq& sq) -> ChunkRegs {
         ChunkRegs r;
         r.col0 = PBL_NO_CHUNK; r.d4 = u32x4{0, 0, 0, 0}; r.q4 = u32x4{0, 0, 0, 0};
+        const int j = Q4 ? rnd : slot + 4 * rnd;
         int c = -1;
-        if (q < sq.fn) c = int(ri.start) + sq.fb + q;
-        else if (q - sq.fn < sq.tn) c = nfull + int(ri.tailidx) + sq.tb + (q - sq.fn);
+        if (j < sq.fn) c = int(ri.start) + sq.fb + j;
+        else if (j - sq.fn < sq.tn) c = nfull + int(ri.tailidx) + sq.tb + (j - sq.fn);
         if (c >= 0) { r.d4 = deltap[c]; r.q4 = codep[c]; r.col0 = int(col0p[c]); }
         return r;
     };
+    // rounds the slowest row of the slab needs
+    auto rounds_left = [&](int rnd, const Seq& sq) -> bool { return __any((Q4 ? rnd : slot + 4 * rnd) < sq.fn + sq.tn); };
     const float4 prs = reinterpret_cast<const float4*>(params)[rho_s];        // the scatter lane's row params (SF)
-    uint16_t* strow = reinterpret_cast<uint16_t*>(St) + rho_s * SSTR;
-    const uint32_t padcol = uint32_t(SLAB + (lane & 7));   // 8 pad columns per row: clamped writes do not pile up on one address
-    // all 16 entries of one chunk -> St of the slab starting at column cb (tail padding repeats the last entry:
-    // PBL_FLAG_TAIL_REPEAT, so a writer needs no count)
+    char* strow_b = reinterpret_cast<char*>(St + rho_s * SSTR);
+    const uint32_t pad_b = uint32_t(2 * (SLAB + (lane & 7)));   // 8 pad columns per row: clamped writes do not pile up on one address
+    // One chunk (Q4: the lane's quarter of it) -> St of the slab starting at column cb.  Tail padding repeats the last entry
+    // (PBL_FLAG_TAIL_REPEAT), so a writer needs no count.  Deltas are stored doubled = byte steps in an fp16 row; a quarter's
+    // first offset is the chunk's plus the byte sum (v_sad_u8) of the deltas before it.
     auto scatter = [&](const ChunkRegs& r, int cb) {
         if ((PBL_MFMA_ABLATE & 2) || r.col0 == PBL_NO_CHUNK) return;
-        int col = r.col0 - cb;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            col += int(((r.d4[e >> 2] >> (8 * (e & 3))) & 0xFFu) >> 1);
-            const uint32_t cc = min(uint32_t(col), padcol);
-            const uint32_t q = (r.q4[e >> 2] >> (8 * (e & 3))) & 0xFFu;
+        uint32_t off = uint32_t(2 * (r.col0 - cb));            // wraps for entries left of the slab: clamped into the pad below
+        auto put = [&](uint32_t dbyte, uint32_t q) {
+            off += dbyte;
+            const uint32_t o = min(off, pad_b);
             uint16_t bits;
             if constexpr (SF) {
                 bits = __builtin_bit_cast(uint16_t, round_f16_twice(prs.z * (float(q) - prs.w)));
@@ -203,7 +212,21 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
             } else {
                 bits = uint16_t(0x6400u | q);                  // fp16 1024 + q, exact
             }
-            strow[cc] = bits;
+            *reinterpret_cast<uint16_t*>(strow_b + o) = bits;
+        };
+        if constexpr (Q4) {
+            uint32_t pre = 0;
+            pre = slot > 0 ? __builtin_amdgcn_sad_u8(r.d4[0], 0u, pre) : pre;
+            pre = slot > 1 ? __builtin_amdgcn_sad_u8(r.d4[1], 0u, pre) : pre;
+            pre = slot > 2 ? __builtin_amdgcn_sad_u8(r.d4[2], 0u, pre) : pre;
+            const uint32_t dd = slot == 0 ? r.d4[0] : (slot == 1 ? r.d4[1] : (slot == 2 ? r.d4[2] : r.d4[3]));
+            const uint32_t qq = slot == 0 ? r.q4[0] : (slot == 1 ? r.q4[1] : (slot == 2 ? r.q4[2] : r.q4[3]));
+            off += pre;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) put((dd >> (8 * e)) & 0xFFu, (qq >> (8 * e)) & 0xFFu);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) put((r.d4[e >> 2] >> (8 * (e & 3))) & 0xFFu, (r.q4[e >> 2] >> (8 * (e & 3))) & 0xFFu);
         }
     };
 
@@ -249,9 +272,10 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         reinterpret_cast<float4*>(smem_g + size_t(2) * XT * SSTR * 2 + size_t(tid >> 4) * MFMA_WAVE_BYTES + size_t(16) * SSTR * 2 + 1024)[tid & 15] = wp[tid & 15];
     }
     u32x4 t_cur = {0, 0, 0, 0}, t_next = {0, 0, 0, 0};
-    ChunkRegs cA, cB, nA, nB;                          // passes 0 and 1 of the current / next slab
-    cA.col0 = cB.col0 = nA.col0 = nB.col0 = PBL_NO_CHUNK;
-    cA.d4 = cA.q4 = cB.d4 = cB.q4 = nA.d4 = nA.q4 = nB.d4 = nB.q4 = u32x4{0, 0, 0, 0};
+    ChunkRegs cA, cB, cC, nA, nB, nC;                  // rounds 0, 1, 2 of the current / next slab
+    cA.col0 = cB.col0 = cC.col0 = nA.col0 = nB.col0 = nC.col0 = PBL_NO_CHUNK;
+    cA.d4 = cB.d4 = cC.d4 = nA.d4 = nB.d4 = nC.d4 = u32x4{0, 0, 0, 0};
+    cA.q4 = cB.q4 = cC.q4 = nA.q4 = nB.q4 = nC.q4 = u32x4{0, 0, 0, 0};
     uint32_t eP = 0, e0 = 0, e1 = 0, e2 = 0;           // slab-index entries of slabs s-1, s, s+1, s+2
     Seq sq = {0, 0, 0, 0};
     if (s0 < s1) {
@@ -259,8 +283,9 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         load_x(s0);
         eP = tab(s0 - 1); e0 = tab(s0); e1 = tab(s0 + 1); e2 = tab(s0 + 2);
         sq = seq_of(eP, e0);
-        cA = load_chunk(slot, sq);
-        cB = load_chunk(slot + 4, sq);
+        cA = load_chunk(0, sq);
+        cB = load_chunk(1, sq);
+        if (Q4) cC = load_chunk(2, sq);
     }
     for (int i = lane; i < int(size_t(16) * SSTR * 2 / 16); i += GW) reinterpret_cast<u32x4*>(St)[i] = u32x4{0, 0, 0, 0};
     if (s0 < s1) store_x(0);
@@ -277,8 +302,9 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         uint32_t e3 = 0;
         if (more) {
             load_x(s + 1);
-            nA = load_chunk(slot, sqn);
-            nB = load_chunk(slot + 4, sqn);
+            nA = load_chunk(0, sqn);
+            nB = load_chunk(1, sqn);
+            if (Q4) nC = load_chunk(2, sqn);
             e3 = tab(s + 3);
             if (half) t_next = __builtin_nontemporal_load(tiles + ((s + 1) >> 1) * 64);
         }
@@ -286,14 +312,12 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
             const uint32_t w0 = half ? t_cur[2] : t_cur[0], w1 = half ? t_cur[3] : t_cur[1];
             Wp[lane] = w0; Wp[64 + lane] = w1; Wp8[lane] = w0 << 8; Wp8[64 + lane] = w1 << 8;
         }
-        // salient entries of the slab -> St: passes 0 and 1 were loaded one slab ahead; rows with more than 8 chunks
-        // in a slab (density above ~45 %, or many short chunks) fetch the rest on demand
+        // salient entries of the slab -> St: the first rounds (Q4: 3 chunks per row, else 8) were loaded one slab ahead; rows
+        // with more chunks in a slab fetch the rest on demand
         scatter(cA, cb);
         scatter(cB, cb);
-        {
-            const int n = sq.fn + sq.tn;
-            for (int q = slot + 8; __any(q < n); q += 4) scatter(load_chunk(q, sq), cb);
-        }
+        if (Q4) scatter(cC, cb);
+        for (int rnd = Q4 ? 3 : 2; rounds_left(rnd, sq); ++rnd) scatter(load_chunk(rnd, sq), cb);
         __syncthreads();   // x tile `buf` complete (written one slab ago); everybody is done reading tile buf ^ 1; St / Wp ordered
         const _Float16* xt = Xs + size_t(buf) * XT * SSTR;
         // all 8 k-steps, branch free: right of K the x tile holds zeros (and the plane / St nothing), so a ragged last
@@ -327,7 +351,7 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         if (!(PBL_MFMA_ABLATE & 8)) {
             for (int i = lane; i < int(size_t(16) * SSTR * 2 / 16); i += GW) reinterpret_cast<u32x4*>(St)[i] = u32x4{0, 0, 0, 0};
         }
-        cA = nA; cB = nB; sq = sqn;
+        cA = nA; cB = nB; cC = nC; sq = sqn;
         eP = e0; e0 = e1; e1 = e2; e2 = e3;
         if (half) t_cur = t_next;
         // the tile is written as halves / dwords and read as 16-byte vectors: keep the compiler from moving the next
@@ -453,8 +477,12 @@ extern "C" int pbl_gemm_mfma_f16_ws(const pbl_layer* layer, const void* x, void*
     a.part = a.KS > 1 ? static_cast<float*>(workspace) : nullptr;
     const bool sf = layer->flags & PBL_FLAG_SAL_F16;
     const int ntb = M <= 16 ? 1 : 2;
-    const void* k = ntb == 1 ? (sf ? reinterpret_cast<const void*>(pbl_mfma_kernel<1, true>) : reinterpret_cast<const void*>(pbl_mfma_kernel<1, false>))
-                             : (sf ? reinterpret_cast<const void*>(pbl_mfma_kernel<2, true>) : reinterpret_cast<const void*>(pbl_mfma_kernel<2, false>));
+    // lane mapping of the salient scatter (see ChunkRegs): four lanes per chunk when a row has at most ~2 chunks per slab
+    const uint32_t NSl = (layer->K + SLAB - 1) / SLAB;
+    const bool q4 = layer->max_nch <= 35u * NSl;                          // 16 rows x 2.2 chunks per row and slab
+#define PBL_PICK(NTB_, SF_) (q4 ? reinterpret_cast<const void*>(pbl_mfma_kernel<NTB_, SF_, true>) : reinterpret_cast<const void*>(pbl_mfma_kernel<NTB_, SF_, false>))
+    const void* k = ntb == 1 ? (sf ? PBL_PICK(1, true) : PBL_PICK(1, false)) : (sf ? PBL_PICK(2, true) : PBL_PICK(2, false));
+#undef PBL_PICK
     const size_t lds = mfma_lds_bytes(ntb);
     if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
         return PBL_ERR_LAUNCH;

@@ -108,6 +108,48 @@ def pack_dense(W, hi, lo, sscale=None, szero=None, sal_mask=None, sal_f16: bool 
     return PackedWeight.from_blob(blob)
 
 
+def pack_dense_dev(W: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor, sscale: torch.Tensor | None = None,
+                   szero: torch.Tensor | None = None, sal_mask: torch.Tensor | None = None, sal_f16: bool = False) -> PackedWeight:
+    """pack_dense for tensors that already live on the GPU: the blob is built there (csrc/pbl_pack.hip, one wavefront per
+    record) and is byte-identical to the host packer's.  No host round trip of the weights; one small device -> host copy
+    (the blob's size and header totals)."""
+    if not W.is_cuda:
+        raise _lib.PblError("pack_dense_dev needs GPU tensors (use pack_dense on the host)")
+    dev = W.device
+    W = W.detach().to(torch.float32).contiguous()
+    N, K = W.shape
+    f32 = lambda t: None if t is None else torch.as_tensor(t, device=dev).detach().to(torch.float32).contiguous()   # noqa: E731
+    hi, lo = f32(hi).reshape(N, -1), f32(lo).reshape(N, -1)
+    G = hi.shape[1]
+    if lo.shape != hi.shape:
+        raise ValueError("hi / lo shape mismatch")
+    ss, sz = f32(sscale), f32(szero)
+    sm = None if sal_mask is None else torch.as_tensor(sal_mask, device=dev).reshape(N, K).to(torch.uint8).contiguous()
+    L = _lib.lib()
+    NRB, CW = (N + 15) // 16, _lib.PBL_PACK_COUNT_WORDS
+    counts = torch.empty(NRB, CW, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    ptr = lambda t: None if t is None else t.data_ptr()      # noqa: E731
+    flags = _lib.PBL_FLAG_SAL_F16 if sal_f16 else 0
+    _lib.check(L.pbl_pack_dev_count(W.data_ptr(), N, K, G, hi.data_ptr(), lo.data_ptr(), ptr(ss), ptr(sz), ptr(sm), flags,
+                                    counts.data_ptr(), st), "pack_dev_count")
+    c = counts.to(torch.int64)
+    rec0 = (80 + 16 * (NRB + 1) + 127) & ~127
+    rec_off = torch.empty(NRB + 1, dtype=torch.int64, device=dev)
+    rec_off[0] = rec0
+    rec_off[1:] = rec0 + torch.cumsum(c[:, 0], 0)
+    tot = torch.stack([rec_off[-1], (c[:, 1] + c[:, 2]).max(), c[:, 3].max(), c[:, 4].sum(), c[:, 3].sum(), c[:, 5].max()]).tolist()
+    total, max_nch, max_nexc, nnz, nexc, bad = (int(v) for v in tot)
+    if bad:
+        raise _lib.PblError("layer exceeds the packed format's limits (chunks per record / tail chunks per row)")
+    blob = torch.empty(total, dtype=torch.uint8, device=dev)
+    _lib.check(L.pbl_pack_dev_write(W.data_ptr(), N, K, G, hi.data_ptr(), lo.data_ptr(), ptr(ss), ptr(sz), ptr(sm), flags,
+                                    counts.data_ptr(), rec_off.data_ptr(), total, max_nch, max_nexc, nnz, nexc, blob.data_ptr(), st),
+               "pack_dev_write")
+    fl = (_lib.PBL_FLAG_HAS_GROUPS if G > 1 else 0) | flags | _lib.PBL_FLAG_TAIL_REPEAT | _lib.PBL_FLAG_SLABS
+    return PackedWeight(blob, N, K, (K + 511) // 512, G, NRB, fl, max_nch, max_nexc, nnz, nexc)
+
+
 def infer_levels(W: np.ndarray, groupsize: int = -1, low_mask: np.ndarray | None = None):
     """Per (row, column group): the two most frequent values among the binarized
     positions -> (hi, lo) with hi >= lo.  This is how PB structure is re-discovered

@@ -138,10 +138,17 @@ class LowHighGPTQ:
     def to_pb(self):
         """Pack the quantised layer (after fasterquant) into a PBLinear without going through a dense checkpoint."""
         from .quant import PBLinear
-        gs = -1 if self.n_groups == 1 else self.groupsize
+        from .packing import pack_dense_dev
         W = self.layer.weight.data
-        return PBLinear.from_dense(W.cpu(), None if self.layer.bias is None else self.layer.bias.data.cpu(), self.mask.cpu(), gs,
-                                   self.hscale.cpu().numpy(), self.hzero.cpu().numpy())
+        N = W.shape[0]
+        # levels from the low quantizer's state, rounded like the written-back weight (gptq.py:182 `.to(dtype)`); the matrix,
+        # the mask and the quantizer state are all on the GPU, so the blob is built there (csrc/pbl_pack.hip)
+        hi = (self.scale + self.mean).reshape(self.n_groups, N).t().to(W.dtype).float().contiguous()
+        lo = (-self.scale + self.mean).reshape(self.n_groups, N).t().to(W.dtype).float().contiguous()
+        packed = pack_dense_dev(W.float(), hi, lo, self.hscale.reshape(-1), self.hzero.reshape(-1), ~self.mask,
+                                sal_f16=W.dtype == torch.float16)
+        bias = None if self.layer.bias is None else self.layer.bias.data
+        return PBLinear(packed, bias, W.dtype)
 
     def free(self):
         self.H = None

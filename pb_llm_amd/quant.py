@@ -24,7 +24,7 @@ import torch.nn as nn
 
 from . import _lib
 from .qat import STEBinary, qat_linear
-from .packing import PackedWeight, infer_code_grid, infer_levels, pack_dense
+from .packing import PackedWeight, infer_code_grid, infer_levels, pack_dense, pack_dense_dev
 
 
 class BinaryInterface:
@@ -308,8 +308,11 @@ class PBLinear(nn.Module, BinaryInterface):
 
 def _pack_sign_like(w_sim: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor) -> PackedWeight:
     """Fully binarized variants: anything that is neither level (sign(0) == 0) is a
-    code entry with value 0 (sscale=1, szero=0, q=0)."""
+    code entry with value 0 (sscale=1, szero=0, q=0).  GPU tensors are packed on the GPU (byte-identical blob)."""
     N = w_sim.shape[0]
+    if w_sim.is_cuda:
+        one = torch.ones(N, device=w_sim.device)
+        return pack_dense_dev(w_sim, hi.to(w_sim.device).reshape(N, 1), lo.to(w_sim.device).reshape(N, 1), one, torch.zeros_like(one))
     return pack_dense(w_sim, hi.reshape(N, 1), lo.reshape(N, 1), np.ones(N, np.float32), np.zeros(N, np.float32))
 
 
@@ -384,7 +387,7 @@ class BinaryLinear(_DenseBacked):
         return STEBinary.apply(self.weight)                       # quant/quantizer.py:84-85
 
     def _pack(self):
-        w = self.quant_weight().cpu()
+        w = self.quant_weight()
         one = torch.ones(w.shape[0])
         return _pack_sign_like(w, one, -one)
 
@@ -411,7 +414,7 @@ class XnorBinaryLinear(_DenseBacked):
         return STEBinary.apply(w) * w.abs().mean(-1).view(-1, 1).detach()
 
     def _pack(self):
-        w = self.weight.detach().cpu()
+        w = self.weight.detach()
         wc = w - w.mean(-1).view(-1, 1)
         alpha = wc.abs().mean(-1)
         return _pack_sign_like(wc.sign() * alpha.view(-1, 1), alpha, -alpha)
@@ -524,14 +527,21 @@ class BinaryXnorExceptOutliersLinear(_DenseBacked):
             self.invalidate()
 
     def _pack(self):
-        w_sim = self.binarize_except_outliers().float().cpu()
-        N = w_sim.shape[0]
-        a = self.binary_scale.float().cpu().reshape(1).expand(N)
-        # salient value = outlier_scale * (code*(range/255) + zp) = sscale*(q - szero)
+        w_dev = self.binarize_except_outliers().float()
+        N = w_dev.shape[0]
+        # salient value = outlier_scale * (code*(range/255) + zp) = sscale*(q - szero); the per-row grid is computed on the host
+        # (N numbers; correctly rounded division) whichever packer runs
         ss = (self._code_scale.float().cpu() * float(self.outlier_scale)).numpy()
         with np.errstate(divide="ignore", invalid="ignore"):
             sz = np.where(self._code_scale.cpu().numpy() != 0,
                           -self._code_zp.cpu().numpy() / self._code_scale.cpu().numpy(), 0.0).astype(np.float32)
+        if w_dev.is_cuda:
+            # weights, mask and levels are on the GPU: pack there (csrc/pbl_pack.hip), no host round trip of the matrix
+            a_dev = self.binary_scale.float().reshape(1).expand(N).to(w_dev.device)
+            return pack_dense_dev(w_dev, a_dev.reshape(N, 1), (-a_dev).reshape(N, 1), torch.from_numpy(ss).to(w_dev.device),
+                                  torch.from_numpy(sz).to(w_dev.device), self.outlier_mask, sal_f16=self.weight.dtype == torch.float16)
+        w_sim = w_dev
+        a = self.binary_scale.float().cpu().reshape(1).expand(N)
         # an fp16 module holds fl16(code*scale + zp) at the salient positions: pack it like an fp16 checkpoint
         return pack_dense(w_sim, a.reshape(N, 1), (-a).reshape(N, 1), ss, sz,
                           self.outlier_mask.cpu().numpy().astype(np.uint8), sal_f16=self.weight.dtype == torch.float16)
