@@ -271,8 +271,8 @@ int pbl_linear_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int
  * stream benchmark of SURVEY.md 8(d)).  layers_dev: DEVICE array of L pbl_layer;
  * x_dev / y_dev: DEVICE arrays of L pointers (fp16 [M,K_l] / fp16 [M,N_l]);
  * max_NRB, max_K, max_nch, max_nexc: maxima over the group (the host knows them).  M <= 4.
- * group_flags: bit 0 = some layer has column groups (unsupported here), bit 1 = some layer
- * has PBL_FLAG_SAL_F16.
+ * group_flags: bit 0 = some layer has column groups (the launch then runs the column-group kernel: every group size a power
+ * of two, every K a multiple of 128; group-free layers may ride along), bit 1 = some layer has PBL_FLAG_SAL_F16.
  * y_f32 != 0: every y_l is fp32 (tensor-parallel partial sums). */
 int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, void* const* y_dev,
                          int L, int M, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch,

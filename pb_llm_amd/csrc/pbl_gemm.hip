@@ -83,14 +83,18 @@ struct MfmaArgs {
     void* y;                // [M, N] fp16 / fp32 (KS == 1)
     float* part;            // [KS][M][N] fp32 (KS > 1)
     int M, y_f32, KS, sps;  // sps: slabs per K split
+    int gshift;             // log2(columns per group) (GRP kernels)
 };
 
 constexpr size_t MFMA_WAVE_BYTES = size_t(16) * SSTR * 2 + 2 * 512 + 256;   // St + Wp + Wp << 8 + row params
 __host__ __device__ constexpr size_t mfma_lds_bytes(int ntb) {
-    return size_t(2) * 16 * ntb * SSTR * 2 + WPG * MFMA_WAVE_BYTES + 128;
+    return size_t(2) * 16 * ntb * SSTR * 2 + WPG * MFMA_WAVE_BYTES + 128 + 512;   // + Xsum[32] + Xh[2][2][32]
 }
 
-template <int NTB, bool SF, bool Q4>
+// GRP: the layer has column groups (G > 1, a power-of-two number of columns >= 128 each): the binarized part and the salient
+// mask are folded into per-row totals at every group boundary with that group's (hi, lo), exactly as the column-group GEMV does
+// (pbl_kernels.hip); X is then needed per 128-column half slab and goes through LDS (Xh).
+template <int NTB, bool SF, bool Q4, bool GRP>
 __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     constexpr int XT = 16 * NTB;                   // token rows of the x tile
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     const int nfull = __builtin_amdgcn_readfirstlane(info.y), ntail = __builtin_amdgcn_readfirstlane(info.z);
     const int nexc = __builtin_amdgcn_readfirstlane(info.w), nch = nfull + ntail;
     const uint32_t nchu = uint32_t(nch);
-    const uint32_t tiles_off = PBL_TILES_OFF(1u);
+    const uint32_t tiles_off = GRP ? PBL_TILES_OFF(L.G) : PBL_TILES_OFF(1u);
     const uint8_t* sal = rec + tiles_off + uint32_t(P) * 1024u;
     const pbl_rowparams* params = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
     const pbl_rowinfo* rinfo = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF);
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
     const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + PBL_SAL_DELTA_OFF(nchu));
     const u32x4* codep = reinterpret_cast<const u32x4*>(sal + PBL_SAL_CODE_OFF(nchu));
-    constexpr bool has_crow = SF;                  // G == 1 here, so per-chunk row ids exist exactly for fp16 checkpoints
+    constexpr bool has_crow = SF || GRP;           // per-chunk row ids exist for fp16 checkpoints and for column groups
     const uint2* exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), has_crow));
     const uint32_t* slabtab = reinterpret_cast<const uint32_t*>(sal + PBL_SAL_SLAB_OFF(nchu, uint32_t(ntail), uint32_t(nexc), has_crow));
 
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     uint32_t* Wp8 = Wp + 128;
     float4* prm = reinterpret_cast<float4*>(Wp8 + 128);                        // [16] {hi, lo, sscale, szero}
     float* Xsum = reinterpret_cast<float*>(smem_g + size_t(2) * XT * SSTR * 2 + WPG * MFMA_WAVE_BYTES);
+    float* Xh = Xsum + 32;                          // [buf][half slab][token] (GRP)
 
     const int row_a = lane & 15, kblk = lane >> 4;   // fragment coordinates: A row / B token, 8-column block
     const int rho_s = lane >> 2, slot = lane & 3;    // scatter coordinates: the lane's row and its chunk slot
@@ -155,12 +160,20 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         for (int j = 0; j < 2 * NTB; ++j) {
             const int idx = tid + j * (WPG * GW), tok = idx >> 5;
             *reinterpret_cast<u32x4*>(Xs + (size_t(buf) * XT + tok) * SSTR + (idx & 31) * 8) = xr[j];
+            float h = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // (through a scalar: hipcc 7.2 miscompiles __builtin_bit_cast applied directly to a vector ELEMENT -- it
                 // reads element 0 whatever the subscript)
                 const uint32_t w = xr[j][q];
-                xsum[j] = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2v, w), h2v{_Float16(1.f), _Float16(1.f)}, xsum[j], false);
+                h = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2v, w), h2v{_Float16(1.f), _Float16(1.f)}, h, false);
+            }
+            if constexpr (GRP) {   // 16 consecutive lanes staged one token's 128-column half slab
+#pragma unroll
+                for (int d = 8; d >= 1; d >>= 1) h += __shfl_xor(h, d, GW);
+                if ((tid & 15) == 0) Xh[(buf * 2 + ((tid >> 4) & 1)) * 32 + tok] = h;
+            } else {
+                xsum[j] += h;
             }
         }
     };
@@ -233,6 +246,45 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     v4f accW[NTB], accS[NTB], accM[NTB];
 #pragma unroll
     for (int t = 0; t < NTB; ++t) { accW[t] = accS[t] = accM[t] = v4f{0.f, 0.f, 0.f, 0.f}; }
+    // GRP: per-row totals over the finished groups, the salient mask sum over all groups, X of the open group; class constants
+    // of the lane's four OUTPUT rows; (hi, lo) of the groups the current slab's two halves lie in, fetched a slab ahead
+    v4f tot[NTB], Stot[NTB];
+    float Xg[NTB], Ar[4], Br[4];
+    float2 hlc[2][4], hln[2][4];
+#pragma unroll
+    for (int t = 0; t < NTB; ++t) { tot[t] = Stot[t] = v4f{0.f, 0.f, 0.f, 0.f}; Xg[t] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        uint32_t cu;
+        class_consts_g((4 * (lane >> 4) + r) & 7, Ar[r], Br[r], cu);
+        hlc[0][r] = hlc[1][r] = hln[0][r] = hln[1][r] = make_float2(0.f, 0.f);
+    }
+    const float2* ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
+    const int Gm1 = int(L.G) - 1;
+    auto load_hl = [&](int s, float2 (&dst)[2][4]) {
+        if constexpr (GRP) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int g = min((s * SLAB + hf * 128) >> a.gshift, Gm1);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[hf][r] = ghl[(4 * (lane >> 4) + r) * int(L.G) + g];
+            }
+        }
+    };
+    auto fold = [&](const float2 (&hl)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float alpha = 0.5f * (hl[r].x - hl[r].y), mu = 0.5f * (hl[r].x + hl[r].y);
+#pragma unroll
+            for (int t = 0; t < NTB; ++t) {
+                const float D = fmaf(Ar[r], accW[t][r], -(Br[r] * Xg[t]));
+                tot[t][r] += fmaf(alpha, D, fmaf(mu, Xg[t], -(hl[r].x * accM[t][r])));
+                Stot[t][r] += accM[t][r];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTB; ++t) { accW[t] = accM[t] = v4f{0.f, 0.f, 0.f, 0.f}; Xg[t] = 0.f; }
+    };
     // the lane's row decides its bit (rows >= 8 read the pre-shifted copy, then bit 8 + class in each half-word) and class
     float Acl, Bcl;
     uint32_t Ccl;
@@ -286,6 +338,7 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         cA = load_chunk(0, sq);
         cB = load_chunk(1, sq);
         if (Q4) cC = load_chunk(2, sq);
+        load_hl(s0, hlc);
     }
     for (int i = lane; i < int(size_t(16) * SSTR * 2 / 16); i += GW) reinterpret_cast<u32x4*>(St)[i] = u32x4{0, 0, 0, 0};
     if (s0 < s1) store_x(0);
@@ -306,6 +359,7 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
             nB = load_chunk(1, sqn);
             if (Q4) nC = load_chunk(2, sqn);
             e3 = tab(s + 3);
+            load_hl(s + 1, hln);
             if (half) t_next = __builtin_nontemporal_load(tiles + ((s + 1) >> 1) * 64);
         }
         {   // this slab's two sign-plane dwords -> Wp[sub-block][lane], as is and << 8
@@ -347,6 +401,21 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
                 accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aM, fcur.bx[t], accM[t], 0, 0, 0);
             }
             fcur = fnext;
+            if constexpr (GRP) {
+                if ((k8 & 3) == 3) {   // a 128-column half slab is done: its X, and the fold if its group ends here
+                    const int hf = k8 >> 2;
+#pragma unroll
+                    for (int t = 0; t < NTB; ++t) Xg[t] += Xh[(buf * 2 + hf) * 32 + t * 16 + row_a];
+                    const int cend = cb + 128 * (hf + 1);
+                    if (!(cend & ((1 << a.gshift) - 1)) || (hf == 1 && !more)) fold(hlc[hf]);
+                }
+            }
+        }
+        if constexpr (GRP) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hlc[hf][r] = hln[hf][r];
         }
         if (!(PBL_MFMA_ABLATE & 8)) {
             for (int i = lane; i < int(size_t(16) * SSTR * 2 / 16); i += GW) reinterpret_cast<u32x4*>(St)[i] = u32x4{0, 0, 0, 0};
@@ -385,21 +454,31 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         for (int t = 0; t < NTB; ++t) {
             const int tok = t * 16 + row_a;
             if (tok >= M) continue;
-            const float X = Xsum[t * 16 + row_a];
-            const float Wv = accW[t][r], Sv = accS[t][r], S = accM[t][r];
-            const float D = fmaf(A, Wv, -(B * X));
-            float salv;
-            if constexpr (SF) salv = fmaf(-pr.x, S, Sv);
-            else salv = fmaf(pr.z, fmaf(-pr.w, S, fmaf(-1024.f, S, Sv)), -(pr.x * S));
             float e = 0.f;
             if (ks == 0) {
                 for (int k = 0; k < nexc; ++k) {
                     const uint2 ex = exc[k];
-                    if (int(ex.x >> 16) == rho)
-                        e += (__builtin_bit_cast(float, ex.y) - pr.x) * float(a.x[size_t(tok) * K + (ex.x & 0xFFFFu)]);
+                    if (int(ex.x >> 16) == rho) {
+                        const uint32_t col = ex.x & 0xFFFFu;
+                        const float hv = GRP ? ghl[rho * int(L.G) + int(col >> a.gshift)].x : pr.x;
+                        e += (__builtin_bit_cast(float, ex.y) - hv) * float(a.x[size_t(tok) * K + col]);
+                    }
                 }
             }
-            const float out = fmaf(alpha, D, fmaf(mu, X, salv)) + e + bias;
+            float out;
+            if constexpr (GRP) {     // the groups are folded already; what is left is the salient weights themselves
+                const float Sv = accS[t][r], S = Stot[t][r];
+                const float salv = SF ? Sv : pr.z * fmaf(-pr.w, S, fmaf(-1024.f, S, Sv));
+                out = tot[t][r] + salv + e + bias;
+            } else {
+                const float X = Xsum[t * 16 + row_a];
+                const float Wv = accW[t][r], Sv = accS[t][r], S = accM[t][r];
+                const float D = fmaf(A, Wv, -(B * X));
+                float salv;
+                if constexpr (SF) salv = fmaf(-pr.x, S, Sv);
+                else salv = fmaf(pr.z, fmaf(-pr.w, S, fmaf(-1024.f, S, Sv)), -(pr.x * S));
+                out = fmaf(alpha, D, fmaf(mu, X, salv)) + e + bias;
+            }
             if (a.KS > 1) a.part[(size_t(ks) * M + tok) * L.N + row] = out;
             else if (a.y_f32) static_cast<float*>(a.y)[size_t(tok) * L.N + row] = out;
             else static_cast<_Float16*>(a.y)[size_t(tok) * L.N + row] = _Float16(out);
@@ -447,7 +526,11 @@ void pick_split(const pbl_layer* L, int& KS, int& sps) {
 }
 
 bool mfma_supported(const pbl_layer* layer, const void* x) {
-    return layer->G == 1 && !(layer->K & 7) && !(reinterpret_cast<uintptr_t>(x) & 15) &&
+    if (layer->G > 1) {   // column groups: a power-of-two number of columns, at least a half slab
+        const uint32_t gs = layer->K / layer->G;
+        if (gs * layer->G != layer->K || (gs & (gs - 1)) || gs < 128) return false;
+    }
+    return !(layer->K & 7) && !(reinterpret_cast<uintptr_t>(x) & 15) &&
            (layer->flags & PBL_FLAG_TAIL_REPEAT) && (layer->flags & PBL_FLAG_SLABS);
 }
 
@@ -480,9 +563,13 @@ extern "C" int pbl_gemm_mfma_f16_ws(const pbl_layer* layer, const void* x, void*
     // lane mapping of the salient scatter (see ChunkRegs): four lanes per chunk when a row has at most ~2 chunks per slab
     const uint32_t NSl = (layer->K + SLAB - 1) / SLAB;
     const bool q4 = layer->max_nch <= 35u * NSl;                          // 16 rows x 2.2 chunks per row and slab
-#define PBL_PICK(NTB_, SF_) (q4 ? reinterpret_cast<const void*>(pbl_mfma_kernel<NTB_, SF_, true>) : reinterpret_cast<const void*>(pbl_mfma_kernel<NTB_, SF_, false>))
+    const bool grp = layer->G > 1;
+    a.gshift = grp ? 31 - __builtin_clz(layer->K / layer->G) : 31;
+#define PBL_PICK2(NTB_, SF_, Q4_) (grp ? reinterpret_cast<const void*>(pbl_mfma_kernel<NTB_, SF_, Q4_, true>) : reinterpret_cast<const void*>(pbl_mfma_kernel<NTB_, SF_, Q4_, false>))
+#define PBL_PICK(NTB_, SF_) (q4 ? PBL_PICK2(NTB_, SF_, true) : PBL_PICK2(NTB_, SF_, false))
     const void* k = ntb == 1 ? (sf ? PBL_PICK(1, true) : PBL_PICK(1, false)) : (sf ? PBL_PICK(2, true) : PBL_PICK(2, false));
 #undef PBL_PICK
+#undef PBL_PICK2
     const size_t lds = mfma_lds_bytes(ntb);
     if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
         return PBL_ERR_LAUNCH;

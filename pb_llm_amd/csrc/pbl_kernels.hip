@@ -190,6 +190,8 @@ struct GemvArgs {
     void* y_shared;
     const uint64_t* y_off;   // device: element offset of layer l's columns in a row of y
     uint32_t ldy;            // row stride of y in elements (0: the layer's own N)
+    int Lc;                  // layers of a grouped launch (host side only)
+    int tok0;                // column-group kernel in a grouped launch: first token of this pass (it takes 2 tokens per pass)
 };
 
 // Gather 8 fp16 values from LDS byte addresses a[0..7] into 4 packed half2 registers
@@ -571,11 +573,14 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
         L = args.layer; xg = args.x; yg = args.y;
     }
     const size_t ldy = args.ldy ? size_t(args.ldy) : size_t(L.N);
+    xg += size_t(args.tok0) * L.K;
+    yg = static_cast<char*>(yg) + size_t(args.tok0) * ldy * (args.y_f32 ? 4 : 2);
     const uint32_t rb0 = blockIdx.x * WPB;
     if (rb0 >= L.NRB) return;
     const int K = int(L.K), P = int(L.P), G = int(L.G);
     const int Kp = P * PBL_PANEL_COLS, xstride = Kp + 8;
     const int gw = (K / G) / 128;  // dwords of a lane per column group
+    if (gshift < 0) gshift = G > 1 ? 31 - __builtin_clz(uint32_t(K / G)) : 31;   // grouped launch: every layer has its own group size (G == 1: one group)
     _Float16* xs = reinterpret_cast<_Float16*>(smem);
     char* after_x = smem + ((size_t(MB) * xstride * 2 + 15) & ~size_t(15));
     float2* cacb = reinterpret_cast<float2*>(after_x) + size_t(wave) * G * 16;          // [g][rho]
@@ -604,9 +609,11 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
         }
         if (active) {
             const float2* ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
+            const pbl_rowparams* rp = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
             for (int idx = lane; idx < 16 * G; idx += PBL_WAVE) {
                 const int rho = idx & 15, g = idx >> 4;
-                const float2 hl = ghl[rho * G + g];
+                // a group-free layer riding along in a grouped launch has no ghl table: its one "group" is the row's own levels
+                const float2 hl = G > 1 ? ghl[rho * G + g] : make_float2(rp[rho].hi, rp[rho].lo);
                 float A, B;
                 class_consts(rho & 7, A, B);
                 const float al = 0.5f * (hl.x - hl.y), mu = 0.5f * (hl.x + hl.y);
@@ -671,12 +678,23 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
     const u32x4* codep = reinterpret_cast<const u32x4*>(sal + PBL_SAL_CODE_OFF(nchu));
     const uint8_t* tailcnt = sal + PBL_SAL_TAILCNT_OFF(nchu);
     const uint8_t* crow = sal + PBL_SAL_CROW_OFF(nchu, uint32_t(ntail));
+    const bool has_crow = (L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16)) != 0;
+    const pbl_rowinfo* rinfo = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF);
     for (int base = 0; base < nch; base += PBL_WAVE) {
         const int c = base + lane;
         if (c < nch) {
             const u32x4 d4 = deltap[c], q4 = codep[c];
             const int cnt = c >= nfull ? int(tailcnt[c - nfull]) : 16;
-            const int row = crow[c];
+            int row = 0;
+            if (has_crow) row = crow[c];
+            else {            // (group-free member without per-chunk row ids: the row whose chunk range holds c)
+                for (int r = 0; r < 16; ++r) {
+                    const pbl_rowinfo q = rinfo[r];
+                    const bool in = c < nfull ? (c >= int(q.start) && c < int(q.start) + int(q.nfull))
+                                              : (c - nfull >= int(q.tailidx) && c - nfull < int(q.tailidx) + int(q.ntail));
+                    row = in ? r : row;
+                }
+            }
             const pbl_rowparams cp = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF)[row];
             const bool sf16 = L.flags & PBL_FLAG_SAL_F16;
             uint32_t col2 = 2u * col0p[c];
@@ -714,7 +732,8 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_groups_kernel(GemvArg
     const int sub = lane & 3;
     const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF)[rho];
     const uint32_t row = rb * 16 + rho;
-    const uint2* exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), true));
+    const uint2* exc = reinterpret_cast<const uint2*>(sal + (has_crow ? PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), true)
+                                                                       : PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), false)));
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
         float Q = 0.f, S = 0.f, H = 0.f;
@@ -894,6 +913,24 @@ int linear_groups(const pbl_layer* layer, const void* x, void* y, int M, int y_f
     return PBL_OK;
 }
 
+// Grouped / fused launch of layers that carry column groups (groupsize 128 / 256 / ...: gptq_pb/run_all.sh): the column-group
+// kernel, one wave per record, grid (records, layers); every layer's group size must be a power of two (each layer decodes
+// its own from K / G) and every K a multiple of 128.  Group-free layers may ride along (they are one group).
+int grouped_groups(const GemvArgs& a, int M, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch, hipStream_t st) {
+    if (max_K & 127) return PBL_ERR_UNSUPPORTED;
+    const uint32_t P = (max_K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS, Gmax = max_K / 128;
+    const dim3 grid(max_NRB, a.Lc, 1);
+    for (int m0 = 0; m0 < M; m0 += 2) {                       // two tokens per weight pass (the 2 x 16 accumulators stay in registers)
+        const int mb = M - m0 < 2 ? M - m0 : 2;
+        GemvArgs b = a;
+        b.M = mb; b.tok0 = m0;
+        const size_t lds = lds_bytes_groups(P, Gmax, max_nch, mb, 1);
+        const int rc = mb == 1 ? launch_groups<1>(b, -1, grid, lds, st) : launch_groups<2>(b, -1, grid, lds, st);
+        if (rc != PBL_OK) return rc;
+    }
+    return PBL_OK;
+}
+
 template <int WPB, bool SF>
 int launch_mb2(int mb, const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     switch (mb) {
@@ -957,8 +994,21 @@ int pbl_linear_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int
     if (!layer || !layer->blob || !x || !y || M < 1) return PBL_ERR_INVALID_ARG;
     if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (layer->G != 1) return linear_groups(layer, x, y, M, y_f32, st);
     const size_t esz = y_f32 ? 4 : 2;
+    if (layer->G != 1) {
+        // column groups: the GEMV variant serves 2 tokens per pass over the weights; beyond that the matrix-core kernel
+        // (32 tokens per pass) when the group size is a power of two
+        if (M > 2 && (M > 8 || layer->NRB >= 128)) {
+            int rc = PBL_OK;
+            for (int m0 = 0; m0 < M && rc == PBL_OK; m0 += 32) {
+                const int mb = M - m0 < 32 ? M - m0 : 32;
+                rc = pbl_gemm_mfma_f16_ws(layer, static_cast<const _Float16*>(x) + size_t(m0) * layer->K,
+                                          static_cast<char*>(y) + size_t(m0) * layer->N * esz, mb, y_f32, workspace, workspace_bytes, stream);
+            }
+            if (rc != PBL_ERR_UNSUPPORTED) return rc;
+        }
+        return linear_groups(layer, x, y, M, y_f32, st);
+    }
     const bool sf = layer->flags & PBL_FLAG_SAL_F16;
     // throughput mode (a wave per record, 4 per workgroup) when there are enough records to fill the
     // chip; otherwise latency mode: S waves share a record
@@ -1023,9 +1073,10 @@ int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, 
     (void)max_nexc;
     if (!layers_dev || !x_dev || !y_dev || Lc < 1 || M < 1 || M > PBL_MAX_TOKENS_PER_LAUNCH)
         return PBL_ERR_INVALID_ARG;
-    if ((any_groups & 1) || Lc > 65535) return PBL_ERR_UNSUPPORTED;
+    if (Lc > 65535) return PBL_ERR_UNSUPPORTED;
     GemvArgs a{};
-    a.layers = layers_dev; a.xs = x_dev; a.ys = y_dev; a.M = M; a.y_f32 = y_f32; a.grouped = 1;
+    a.layers = layers_dev; a.xs = x_dev; a.ys = y_dev; a.M = M; a.y_f32 = y_f32; a.grouped = 1; a.Lc = Lc;
+    if (any_groups & 1) return grouped_groups(a, M, max_NRB, max_K, max_nch, static_cast<hipStream_t>(stream));
 #ifndef PBL_GROUPED_WPB
 #define PBL_GROUPED_WPB 4
 #endif
@@ -1052,10 +1103,11 @@ int pbl_gemv_f16_fused(const pbl_layer* layers_dev, const uint64_t* y_off_dev, c
                        uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, void* stream) {
     if (!layers_dev || !y_off_dev || !x || !y || Lc < 1 || M < 1 || M > PBL_MAX_TOKENS_PER_LAUNCH || !ldy)
         return PBL_ERR_INVALID_ARG;
-    if ((group_flags & 1) || Lc > 65535) return PBL_ERR_UNSUPPORTED;
+    if (Lc > 65535) return PBL_ERR_UNSUPPORTED;
     GemvArgs a{};
     a.layers = layers_dev; a.M = M; a.y_f32 = y_f32; a.grouped = 1;
     a.x_shared = static_cast<const _Float16*>(x); a.y_shared = y; a.y_off = y_off_dev; a.ldy = ldy;
+    if (group_flags & 1) { a.Lc = Lc; return grouped_groups(a, M, max_NRB, K, max_nch, static_cast<hipStream_t>(stream)); }
     const uint32_t P = (K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS;
     const bool sf = (group_flags & 2) != 0;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -185,7 +185,7 @@ def fuse_decode_(model: nn.Module, sets=FUSE_SETS) -> int:
             subs = [getattr(mod, nm, None) for nm in names]
             if not all(isinstance(m_, PBLinear) for m_ in subs):
                 continue
-            if len({m_.in_features for m_ in subs}) != 1 or any(m_.packed.G > 1 for m_ in subs) or not subs[0].pbl_blob.is_cuda:
+            if len({m_.in_features for m_ in subs}) != 1 or not subs[0].pbl_blob.is_cuda:
                 continue
             grp = _FusedGroup(subs)
             for i, (nm, m_) in enumerate(zip(names, subs)):

@@ -137,7 +137,9 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
     L = _lib.lib()
     if M == 0:
         return x.new_zeros(*lead, packed.N)
-    mfma_ok = packed.G == 1 and packed.K % 8 == 0 and bool(packed.flags & _lib.PBL_FLAG_SLABS)
+    gs = packed.K // packed.G      # column groups: the matrix-core kernel wants a power-of-two group of >= 128 columns
+    mfma_ok = ((packed.G == 1 or (gs >= 128 and gs & (gs - 1) == 0 and gs * packed.G == packed.K))
+               and packed.K % 8 == 0 and bool(packed.flags & _lib.PBL_FLAG_SLABS))
 
     def run(layer_s, xin, yout, rows, f32):
         ws, nb = _mfma_workspace(layer_s, rows, x.device) if (rows > _lib.PBL_MAX_TOKENS_PER_LAUNCH and mfma_ok) else (None, 0)

@@ -51,7 +51,7 @@ class GroupedGemv:
         self.max_K = Kmax
         self.max_nch = max(p.max_nch for p in self.packed)
         self.max_nexc = max(p.max_nexc for p in self.packed)
-        # bit 0: column groups present (unsupported in a grouped launch), bit 1: fp16-checkpoint layers present
+        # bit 0: column-group layers present (the launch then runs the column-group kernel), bit 1: fp16-checkpoint layers present
         self.any_groups = int(any(p.G > 1 for p in self.packed)) | (2 * int(any(p.flags & _lib.PBL_FLAG_SAL_F16 for p in self.packed)))
 
     def algorithmic_bytes(self) -> int:
@@ -79,8 +79,6 @@ class FusedGemv:
             raise ValueError("empty group")
         if len({p.K for p in packed}) != 1:
             raise ValueError("fused projections share their input: equal in_features")
-        if any(p.G > 1 for p in packed):
-            raise ValueError("column-group layers are not supported in a fused launch")
         self.device = torch.device(device)
         self.packed = [p if p.blob.device == self.device else p.to(self.device) for p in packed]
         biases = biases or [None] * len(packed)
@@ -93,7 +91,8 @@ class FusedGemv:
         self._yoff_dev = torch.tensor(self.offs[:-1].tolist(), dtype=torch.int64, device=self.device)
         self.max_NRB = max(p.NRB for p in self.packed)
         self.max_nch = max(p.max_nch for p in self.packed)
-        self.flags = 2 * int(any(p.flags & _lib.PBL_FLAG_SAL_F16 for p in self.packed))
+        # bit 0: column-group layers present (the launch then runs the column-group kernel), bit 1: fp16-checkpoint layers present
+        self.flags = int(any(p.G > 1 for p in self.packed)) | 2 * int(any(p.flags & _lib.PBL_FLAG_SAL_F16 for p in self.packed))
 
     def __call__(self, x2: torch.Tensor, out_f32: bool = False) -> list[torch.Tensor]:
         M = x2.shape[0]
