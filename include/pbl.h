@@ -262,6 +262,10 @@ int pbl_gemm_mfma_f16(const pbl_layer* layer, const void* x, void* y, int M, int
  * (deterministic, no atomics).  pbl_mfma_workspace_bytes() is what this layer needs for M tokens (0: no split is used);
  * workspace == NULL or too small: runs unsplit.  pbl_linear_f16_ws is pbl_linear_f16 with that workspace handed through. */
 size_t pbl_mfma_workspace_bytes(const pbl_layer* layer, int M);
+/* What pbl_linear_f16_ws wants as workspace for M tokens of this layer: pbl_mfma_workspace_bytes() when it will route the
+ * call to the matrix-core kernel (more tokens than one GEMV pass takes at two workgroups per CU), 0 when the GEMV serves it.
+ * Without the workspace a call of up to 8 tokens falls back to GEMV passes; larger ones run the matrix-core kernel unsplit. */
+size_t pbl_linear_workspace_bytes(const pbl_layer* layer, int M);
 int pbl_gemm_mfma_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32,
                          void* workspace, size_t workspace_bytes, void* stream);
 int pbl_linear_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32,

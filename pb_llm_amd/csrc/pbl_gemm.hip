@@ -86,7 +86,7 @@ struct MfmaArgs {
     int gshift;             // log2(columns per group) (GRP kernels)
 };
 
-constexpr size_t MFMA_WAVE_BYTES = size_t(16) * SSTR * 2 + 2 * 512 + 256;   // St + Wp + Wp << 8 + row params
+constexpr size_t MFMA_WAVE_BYTES = 16 + size_t(16) * SSTR * 2 + 2 * 512 + 256;   // dump slot + St + Wp + Wp << 8 + row params
 __host__ __device__ constexpr size_t mfma_lds_bytes(int ntb) {
     return size_t(2) * 16 * ntb * SSTR * 2 + WPG * MFMA_WAVE_BYTES + 128 + 512;   // + Xsum[32] + Xh[2][2][32]
 }
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     // plane, [128-column sub-block][lane], as is and << 8), the record's row params; Xsum[32] (shared, at the end)
     _Float16* Xs = reinterpret_cast<_Float16*>(smem_g);
     char* wbase = smem_g + size_t(2) * XT * SSTR * 2 + size_t(wave) * MFMA_WAVE_BYTES;
-    _Float16* St = reinterpret_cast<_Float16*>(wbase);
-    uint32_t* Wp = reinterpret_cast<uint32_t*>(wbase + size_t(16) * SSTR * 2);
+    _Float16* St = reinterpret_cast<_Float16*>(wbase + 16);   // 16 bytes in front: where row 0's out-of-slab entries are dumped
+    uint32_t* Wp = reinterpret_cast<uint32_t*>(wbase + 16 + size_t(16) * SSTR * 2);
     uint32_t* Wp8 = Wp + 128;
     float4* prm = reinterpret_cast<float4*>(Wp8 + 128);                        // [16] {hi, lo, sscale, szero}
     float* Xsum = reinterpret_cast<float*>(smem_g + size_t(2) * XT * SSTR * 2 + WPG * MFMA_WAVE_BYTES);
@@ -201,32 +201,57 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         int c = -1;
         if (j < sq.fn) c = int(ri.start) + sq.fb + j;
         else if (j - sq.fn < sq.tn) c = nfull + int(ri.tailidx) + sq.tb + (j - sq.fn);
-        if (c >= 0) { r.d4 = deltap[c]; r.q4 = codep[c]; r.col0 = int(col0p[c]); }
+        if (c >= 0) {
+            if (PBL_MFMA_ABLATE & 64) { r.d4 = u32x4{0x08060402u, 0x0a0c0e04u, 0x02040608u, 0x10020406u}; r.q4 = u32x4{uint32_t(c), 77u, 99u, 3u}; r.col0 = (c * 37) & 0xFFF; }   // no memory traffic
+            else { r.d4 = deltap[c]; r.q4 = codep[c]; r.col0 = int(col0p[c]); }
+        }
         return r;
     };
     // rounds the slowest row of the slab needs
     auto rounds_left = [&](int rnd, const Seq& sq) -> bool { return __any((Q4 ? rnd : slot + 4 * rnd) < sq.fn + sq.tn); };
     const float4 prs = reinterpret_cast<const float4*>(params)[rho_s];        // the scatter lane's row params (SF)
-    char* strow_b = reinterpret_cast<char*>(St + rho_s * SSTR);
-    const uint32_t pad_b = uint32_t(2 * (SLAB + (lane & 7)));   // 8 pad columns per row: clamped writes do not pile up on one address
     // One chunk (Q4: the lane's quarter of it) -> St of the slab starting at column cb.  Tail padding repeats the last entry
-    // (PBL_FLAG_TAIL_REPEAT), so a writer needs no count.  Deltas are stored doubled = byte steps in an fp16 row; a quarter's
-    // first offset is the chunk's plus the byte sum (v_sad_u8) of the deltas before it.
+    // (PBL_FLAG_TAIL_REPEAT), so a writer needs no count.  Deltas are stored doubled = byte steps in an fp16 row, so one
+    // SDWA add per entry advances the running LDS byte address; ONE v_med3_i32 sends entries outside the slab to a dump
+    // slot: left of the slab into the 8 pad columns of the previous tile row (row 0: the 16 bytes in front of the tile),
+    // right of it into the row's own pad columns -- eight different ones per side, chosen by the lane, so that clamped
+    // writes do not pile up on one address.
+    // SF: the tile holds MINUS the weight, u = fl16(fl32((-ss) * (q - sz))): the rounding is symmetric, so u = -w exactly,
+    // and a weight of value zero ((q - sz) = +0 times a negative factor) comes out as -0 = 0x8000 -- every stored half has a
+    // bit set and the mask is "any bit set", without a compare per entry.  The epilogue negates the accumulated sum.  (The
+    // packers never emit an entry whose u would be +0: zero scale, or a product that underflows from the positive side.)
+    const int st_row = int(uint32_t(reinterpret_cast<uintptr_t>(St))) + rho_s * (SSTR * 2);   // LDS byte address of the lane's tile row
+    const int clamp_lo = st_row - 2 * (1 + (lane & 7)), clamp_hi = st_row + 2 * (SLAB + (lane & 7));
+    const float nss = -prs.z;
+    uint32_t abl_acc = 0;   // ablation builds only
+    auto store_half = [&](int addr, uint32_t v, bool hi) {
+        if (PBL_MFMA_ABLATE & 32) { abl_acc ^= uint32_t(addr) ^ v; return; }     // everything but the LDS write
+        if (hi) asm volatile("ds_write_b16_d16_hi %0, %1" :: "v"(addr), "v"(v) : "memory");
+        else asm volatile("ds_write_b16 %0, %1" :: "v"(addr), "v"(v) : "memory");
+    };
     auto scatter = [&](const ChunkRegs& r, int cb) {
         if ((PBL_MFMA_ABLATE & 2) || r.col0 == PBL_NO_CHUNK) return;
-        uint32_t off = uint32_t(2 * (r.col0 - cb));            // wraps for entries left of the slab: clamped into the pad below
-        auto put = [&](uint32_t dbyte, uint32_t q) {
-            off += dbyte;
-            const uint32_t o = min(off, pad_b);
-            uint16_t bits;
+        int run = st_row + 2 * (r.col0 - cb);
+        // entries e0, e0 + 1 of the lane's part: byte steps d0, d1, codes q0, q1
+        auto put2 = [&](uint32_t d0, uint32_t d1, uint32_t q0, uint32_t q1) {
+            int a0, a1;
+            run += int(d0);
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(a0) : "v"(run), "v"(clamp_lo), "v"(clamp_hi));
+            run += int(d1);
+            asm("v_med3_i32 %0, %1, %2, %3" : "=v"(a1) : "v"(run), "v"(clamp_lo), "v"(clamp_hi));
+            uint32_t pair;
             if constexpr (SF) {
-                bits = __builtin_bit_cast(uint16_t, round_f16_twice(prs.z * (float(q) - prs.w)));
-                if (!(bits & 0x7FFFu)) bits = 0x8000u;         // a salient of value 0 is stored as -0: "any bit set" = salient
+                h2v w;
+                w.x = round_f16_twice(nss * (float(q0) - prs.w));
+                w.y = round_f16_twice(nss * (float(q1) - prs.w));
+                pair = __builtin_bit_cast(uint32_t, w);
             } else {
-                bits = uint16_t(0x6400u | q);                  // fp16 1024 + q, exact
+                pair = 0x64006400u | q0 | (q1 << 16);            // fp16 1024 + q, exact
             }
-            *reinterpret_cast<uint16_t*>(strow_b + o) = bits;
+            store_half(a0, pair, false);
+            store_half(a1, pair, true);
         };
+        auto byte_of = [](uint32_t w, int k) -> uint32_t { return (w >> (8 * k)) & 0xFFu; };
         if constexpr (Q4) {
             uint32_t pre = 0;
             pre = slot > 0 ? __builtin_amdgcn_sad_u8(r.d4[0], 0u, pre) : pre;
@@ -234,12 +259,16 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
             pre = slot > 2 ? __builtin_amdgcn_sad_u8(r.d4[2], 0u, pre) : pre;
             const uint32_t dd = slot == 0 ? r.d4[0] : (slot == 1 ? r.d4[1] : (slot == 2 ? r.d4[2] : r.d4[3]));
             const uint32_t qq = slot == 0 ? r.q4[0] : (slot == 1 ? r.q4[1] : (slot == 2 ? r.q4[2] : r.q4[3]));
-            off += pre;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) put((dd >> (8 * e)) & 0xFFu, (qq >> (8 * e)) & 0xFFu);
+            run += int(pre);
+            put2(byte_of(dd, 0), byte_of(dd, 1), byte_of(qq, 0), byte_of(qq, 1));
+            put2(byte_of(dd, 2), byte_of(dd, 3), byte_of(qq, 2), byte_of(qq, 3));
         } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) put((r.d4[e >> 2] >> (8 * (e & 3))) & 0xFFu, (r.q4[e >> 2] >> (8 * (e & 3))) & 0xFFu);
+            for (int e = 0; e < 16; e += 2) {
+                // (through scalars: hipcc 7.2 miscompiles some element-wise uses of a vector ELEMENT in place)
+                const uint32_t dw = r.d4[e >> 2], qw = r.q4[e >> 2];
+                put2(byte_of(dw, e & 3), byte_of(dw, (e & 3) + 1), byte_of(qw, e & 3), byte_of(qw, (e & 3) + 1));
+            }
         }
     };
 
@@ -321,7 +350,7 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         const uint32_t wr = min(blockIdx.x * WPG + uint32_t(tid >> 4), L.NRB - 1);
         const uint4 winfo = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[wr];
         const float4* wp = reinterpret_cast<const float4*>(blob + size_t(winfo.x) * 16 + PBL_REC_PARAMS_OFF);
-        reinterpret_cast<float4*>(smem_g + size_t(2) * XT * SSTR * 2 + size_t(tid >> 4) * MFMA_WAVE_BYTES + size_t(16) * SSTR * 2 + 1024)[tid & 15] = wp[tid & 15];
+        reinterpret_cast<float4*>(smem_g + size_t(2) * XT * SSTR * 2 + size_t(tid >> 4) * MFMA_WAVE_BYTES + 16 + size_t(16) * SSTR * 2 + 1024)[tid & 15] = wp[tid & 15];
     }
     u32x4 t_cur = {0, 0, 0, 0}, t_next = {0, 0, 0, 0};
     ChunkRegs cA, cB, cC, nA, nB, nC;                  // rounds 0, 1, 2 of the current / next slab
@@ -438,6 +467,7 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     }
     __syncthreads();
     if (!rec_ok) return;
+    if ((PBL_MFMA_ABLATE & 32) && abl_acc == 0x12345678u) a.part[0] = 1.f;
 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                    // lane holds token (lane & 15) of each token block, row 4*(lane >> 4) + r
@@ -468,14 +498,14 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
             float out;
             if constexpr (GRP) {     // the groups are folded already; what is left is the salient weights themselves
                 const float Sv = accS[t][r], S = Stot[t][r];
-                const float salv = SF ? Sv : pr.z * fmaf(-pr.w, S, fmaf(-1024.f, S, Sv));
+                const float salv = SF ? -Sv : pr.z * fmaf(-pr.w, S, fmaf(-1024.f, S, Sv));   // (SF: the tile holds minus the weight)
                 out = tot[t][r] + salv + e + bias;
             } else {
                 const float X = Xsum[t * 16 + row_a];
                 const float Wv = accW[t][r], Sv = accS[t][r], S = accM[t][r];
                 const float D = fmaf(A, Wv, -(B * X));
                 float salv;
-                if constexpr (SF) salv = fmaf(-pr.x, S, Sv);
+                if constexpr (SF) salv = fmaf(-pr.x, S, -Sv);      // the tile holds minus the weight
                 else salv = fmaf(pr.z, fmaf(-pr.w, S, fmaf(-1024.f, S, Sv)), -(pr.x * S));
                 out = fmaf(alpha, D, fmaf(mu, X, salv)) + e + bias;
             }

@@ -24,6 +24,15 @@ inline size_t align128(size_t x) { return (x + 127) & ~size_t(127); }
 inline float dequant(float sscale, float szero, int q) { return sscale * (float(q) - szero); }
 // the same value after the checkpoint's fp16 round trip (round-to-nearest-even)
 inline float dequant_f16(float sscale, float szero, int q) { return float(_Float16(dequant(sscale, szero, q))); }
+// fp16-checkpoint entries only: the matrix-core kernels keep MINUS the weight, fl16((-scale) * (q - zero)), in their fp16 tile
+// and recognise an entry by "any bit set" (a weight of value 0 is -0 there).  An entry whose negated product would be +0 --
+// zero or negative scale, or a product that underflows from the positive side -- is therefore not coded (it becomes an exception).
+inline bool sal16_storable(float sscale, float szero, int q) {
+    const _Float16 u = _Float16((-sscale) * (float(q) - szero));
+    uint16_t bits;
+    std::memcpy(&bits, &u, 2);
+    return bits != 0;
+}
 
 struct Entry { uint16_t col; uint8_t code; };
 
@@ -135,7 +144,7 @@ void build_record(const PackArgs& a, uint32_t b, RecImage& out) {
                     float qf = std::nearbyint(v / ss + sz);
                     for (int dq = 0; dq <= 2 && !coded; ++dq) {
                         int q = int(qf) + (dq == 0 ? 0 : (dq == 1 ? 1 : -1));
-                        if (q >= 0 && q <= 255 && (a.sal16 ? dequant_f16(ss, sz, q) : dequant(ss, sz, q)) == v) {
+                        if (q >= 0 && q <= 255 && (a.sal16 ? dequant_f16(ss, sz, q) == v && sal16_storable(ss, sz, q) : dequant(ss, sz, q) == v)) {
                             ents.push_back({uint16_t(c), uint8_t(q)});
                             coded = true;
                         }
@@ -365,6 +374,12 @@ int pbl_blob_describe(const void* host_blob, size_t bytes, pbl_layer* out) {
                 }
                 if (col >= h.K) return PBL_ERR_BAD_BLOB;
                 if (has_crow && crow[c] > 15) return PBL_ERR_BAD_BLOB;
+                if (h.flags & PBL_FLAG_SAL_F16) {      // every coded value must be recognisable in the kernels' fp16 tile (sal16_storable)
+                    const pbl_rowparams* prm = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
+                    const uint8_t* code = s + PBL_SAL_CODE_OFF(nch32);
+                    for (uint32_t k = 0; k < cnt; ++k)
+                        if (!sal16_storable(prm[crow[c]].sscale, prm[crow[c]].szero, code[size_t(c) * 16 + k])) return PBL_ERR_BAD_BLOB;
+                }
                 nnz += cnt;
             }
             const pbl_exception* exc = reinterpret_cast<const pbl_exception*>(s + PBL_SAL_EXC_OFF(nch32, ri.ntail, has_crow));

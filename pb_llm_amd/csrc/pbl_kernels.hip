@@ -989,47 +989,89 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
     return pbl_linear_f16_ws(layer, x, y, M, y_f32, nullptr, 0, stream);
 }
 
+// Routing of one layer's forward between the GEMV (weights streamed once per `mb` tokens) and the matrix-core kernel (once per
+// 32 tokens, but with a per-record expansion cost that only pays off from a handful of tokens on).  Measured on MI355X
+// (tools/bench_route.py): the GEMV wins while all tokens fit ONE pass whose LDS footprint (x tile + chunk partials) leaves at
+// least two workgroups per CU; a pass squeezed into a single workgroup per CU (K = 11008 with 3 tokens, 13824x5120 at 20 %
+// salients with 4) is 3-10x slower than the matrix-core kernel, and so is the matrix-core kernel without its K split.
+struct Route {
+    int split, wpb, mb_max;   // GEMV: waves per record, waves per workgroup, tokens per pass
+    bool mfma;                // more tokens than one GEMV pass takes and the matrix-core kernel applies
+};
+#ifndef PBL_GEMV_LDS_BUDGET
+#define PBL_GEMV_LDS_BUDGET (80 * 1024)   // two workgroups per CU
+#endif
+static Route route_of(const pbl_layer* layer, int M, bool x_aligned) {
+    Route r;
+    if (layer->G != 1) {
+        r.split = 1; r.wpb = 1; r.mb_max = 2;     // the column-group GEMV keeps 2 x 16 accumulators in registers
+        while (r.mb_max > 1 && lds_bytes_groups(layer->P, layer->G, layer->max_nch, r.mb_max, 1) > 96 * 1024) --r.mb_max;
+    } else {
+        // throughput mode (a wave per record, 4 per workgroup) when there are enough records to fill the
+        // chip; otherwise latency mode: S waves share a record
+        r.split = layer->NRB >= PBL_SPLIT_TARGET_WAVES ? 1 : pick_split(layer->NRB, layer->P);
+        r.wpb = r.split > 1 ? r.split : (layer->NRB >= 1024 ? 4 : 1);
+        r.mb_max = PBL_MAX_TOKENS_PER_LAUNCH;
+        while (r.mb_max > 1 && lds_bytes(layer->P, layer->max_nch, r.mb_max, r.wpb, r.split) > PBL_GEMV_LDS_BUDGET) --r.mb_max;
+    }
+    // (tiny layers at M <= 8 stay on the GEMV: both are launch-latency bound and the GEMV starts faster)
+    r.mfma = M > r.mb_max && (M > 8 || layer->NRB >= 128) && !(layer->K & 7) && x_aligned &&
+             (layer->flags & PBL_FLAG_TAIL_REPEAT) && (layer->flags & PBL_FLAG_SLABS);
+    if (r.mfma && M <= 8 && layer->G == 1) {
+        // a few tokens more than one pass holds: several GEMV passes can still beat the matrix-core kernel.  Estimates in us,
+        // fitted to tools/bench_route.py on MI355X (4096^2, 11008x4096, 4096x11008, 13824x5120 at 5-20 % salients; within 30 %):
+        //   GEMV pass of mb tokens   4.5 + packed bytes / 4 TB/s + 0.09 * (N K / 1e6) * mb
+        //   matrix-core kernel       9 + 0.43 * (N K / 1e6)          (flat in M up to 32 tokens)
+        const double wm = double(layer->N) * layer->K * 1e-6;
+        const double bytes = double(layer->N) * layer->K / 8 + double(layer->max_nch) * layer->NRB * 34.0;
+        const double pass0 = 4.5 + bytes / 4e6;
+        double gemv = 0;
+        for (int m0 = 0; m0 < M; m0 += r.mb_max) gemv += pass0 + 0.09 * wm * (M - m0 < r.mb_max ? M - m0 : r.mb_max);
+        r.mfma = 9.0 + 0.43 * wm < gemv;
+    }
+    if (r.mfma && layer->G != 1) {
+        const uint32_t gs = layer->K / layer->G;
+        r.mfma = gs * layer->G == layer->K && !(gs & (gs - 1)) && gs >= 128;
+    }
+    return r;
+}
+
+size_t pbl_linear_workspace_bytes(const pbl_layer* layer, int M) {
+    if (!layer || M < 1) return 0;
+    return route_of(layer, M, true).mfma ? pbl_mfma_workspace_bytes(layer, M < 32 ? M : 32) : 0;
+}
+
+static int mfma_passes(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* workspace, size_t workspace_bytes, void* stream) {
+    const size_t esz = y_f32 ? 4 : 2;
+    int rc = PBL_OK;
+    for (int m0 = 0; m0 < M && rc == PBL_OK; m0 += 32) {
+        const int mb = M - m0 < 32 ? M - m0 : 32;
+        rc = pbl_gemm_mfma_f16_ws(layer, static_cast<const _Float16*>(x) + size_t(m0) * layer->K,
+                                  static_cast<char*>(y) + size_t(m0) * layer->N * esz, mb, y_f32, workspace, workspace_bytes, stream);
+    }
+    return rc;
+}
+
 int pbl_linear_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* workspace, size_t workspace_bytes,
                       void* stream) {
     if (!layer || !layer->blob || !x || !y || M < 1) return PBL_ERR_INVALID_ARG;
     if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t esz = y_f32 ? 4 : 2;
-    if (layer->G != 1) {
-        // column groups: the GEMV variant serves 2 tokens per pass over the weights; beyond that the matrix-core kernel
-        // (32 tokens per pass) when the group size is a power of two
-        if (M > 2 && (M > 8 || layer->NRB >= 128)) {
-            int rc = PBL_OK;
-            for (int m0 = 0; m0 < M && rc == PBL_OK; m0 += 32) {
-                const int mb = M - m0 < 32 ? M - m0 : 32;
-                rc = pbl_gemm_mfma_f16_ws(layer, static_cast<const _Float16*>(x) + size_t(m0) * layer->K,
-                                          static_cast<char*>(y) + size_t(m0) * layer->N * esz, mb, y_f32, workspace, workspace_bytes, stream);
-            }
-            if (rc != PBL_ERR_UNSUPPORTED) return rc;
+    const Route r = route_of(layer, M, !(reinterpret_cast<uintptr_t>(x) & 15));
+    if (r.mfma) {
+        // Without the K-split workspace the matrix-core kernel leaves most of the chip idle on all but the largest layers:
+        // a few tokens are then better served by GEMV passes.
+        const size_t need = pbl_mfma_workspace_bytes(layer, M < 32 ? M : 32);
+        const bool ws_ok = !need || (workspace && workspace_bytes >= need);
+        if (ws_ok || M > 8) {
+            const int rc = mfma_passes(layer, x, y, M, y_f32, workspace, workspace_bytes, stream);
+            if (rc != PBL_ERR_UNSUPPORTED) return rc;   // unsupported (LDS budget): every pass failed the same way, fall through
         }
-        return linear_groups(layer, x, y, M, y_f32, st);
     }
+    if (layer->G != 1) return linear_groups(layer, x, y, M, y_f32, st);
     const bool sf = layer->flags & PBL_FLAG_SAL_F16;
-    // throughput mode (a wave per record, 4 per workgroup) when there are enough records to fill the
-    // chip; otherwise latency mode: S waves share a record
-    const int split = layer->NRB >= PBL_SPLIT_TARGET_WAVES ? 1 : pick_split(layer->NRB, layer->P);
-    const int wpb = split > 1 ? split : (layer->NRB >= 1024 ? 4 : 1);
-    // tokens per weight pass: as many as fit a 96 KiB LDS budget (x tile + chunk partials),
-    // so that K = 13824 layers still run several workgroups per CU
-    int mb_max = PBL_MAX_TOKENS_PER_LAUNCH;
-    while (mb_max > 1 && lds_bytes(layer->P, layer->max_nch, mb_max, wpb, split) > 96 * 1024) --mb_max;
-    // more than one GEMV pass: the matrix-core kernel streams the weights once per 32 tokens instead of once
-    // per 4 (tiny layers at M <= 8 stay on the GEMV: both are launch-latency bound and the GEMV starts faster)
-    if (M > mb_max && (M > 8 || layer->NRB >= 128) && !(layer->K & 7) &&
-        (layer->flags & PBL_FLAG_TAIL_REPEAT) && (layer->flags & PBL_FLAG_SLABS) && !(reinterpret_cast<uintptr_t>(x) & 15)) {
-        int m0 = 0, rc = PBL_OK;
-        for (; m0 < M && rc == PBL_OK; m0 += 32) {
-            const int mb = M - m0 < 32 ? M - m0 : 32;
-            rc = pbl_gemm_mfma_f16_ws(layer, static_cast<const _Float16*>(x) + size_t(m0) * layer->K,
-                                      static_cast<char*>(y) + size_t(m0) * layer->N * esz, mb, y_f32, workspace, workspace_bytes, stream);
-        }
-        if (rc != PBL_ERR_UNSUPPORTED) return rc;   // unsupported (LDS budget): every slab failed the same way, fall through
-    }
+    const int split = r.split, wpb = r.wpb, mb_max = r.mb_max;
     for (int m0 = 0; m0 < M; m0 += mb_max) {
         const int mb = M - m0 < mb_max ? M - m0 : mb_max;
         GemvArgs a{};

@@ -35,6 +35,13 @@ __device__ __forceinline__ float dequant_dev(float ss, float sz, int q, bool f16
     return f16 ? float(_Float16(p)) : p;
 }
 
+// the host packer's sal16_storable (pbl_host.cpp): fl16((-ss) * (q - sz)) must have a bit set
+__device__ __forceinline__ bool sal16_storable_dev(float ss, float sz, int q) {
+    float p = __fmul_rn(-ss, __fsub_rn(float(q), sz));
+    asm volatile("" : "+v"(p));
+    return __builtin_bit_cast(uint16_t, _Float16(p)) != 0;
+}
+
 template <bool WRITE>
 __global__ __launch_bounds__(64) void pack_dev_kernel(PackDevArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(64) void pack_dev_kernel(PackDevArgs a) {
 #pragma unroll
                     for (int dq = 0; dq <= 2 && code < 0; ++dq) {
                         const int q = q0 + (dq == 0 ? 0 : (dq == 1 ? 1 : -1));
-                        if (q >= 0 && q <= 255 && dequant_dev(ss, sz, q, sal16) == v) code = q;
+                        if (q >= 0 && q <= 255 && dequant_dev(ss, sz, q, sal16) == v && (!sal16 || sal16_storable_dev(ss, sz, q))) code = q;
                     }
                 }
                 if (code >= 0) {

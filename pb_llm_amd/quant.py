@@ -142,7 +142,9 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
                and packed.K % 8 == 0 and bool(packed.flags & _lib.PBL_FLAG_SLABS))
 
     def run(layer_s, xin, yout, rows, f32):
-        ws, nb = _mfma_workspace(layer_s, rows, x.device) if (rows > _lib.PBL_MAX_TOKENS_PER_LAUNCH and mfma_ok) else (None, 0)
+        # the K-split scratch of the matrix-core kernel, when pbl_linear_f16_ws is going to route this call there
+        nb = L.pbl_linear_workspace_bytes(C.byref(layer_s), rows)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
         _lib.check(L.pbl_linear_f16_ws(C.byref(layer_s), xin.data_ptr(), yout.data_ptr(), rows, int(f32),
                                        ws.data_ptr() if ws is not None else None, nb, stream), "linear")
 

@@ -3,6 +3,7 @@ row-sharded over 2/4/8 ranks) through the HIP path, plus the rows round 1 left a
 (utils.py:65-124), the Hessian-mask module (a8, quant/outlier_quantizer.py:126-143), the input gradient
 of the packed forward and the staleness of the packed cache.
 """
+import ctypes as C
 import os
 import socket
 
@@ -426,3 +427,69 @@ def test_fused_gemm_kernel(N, K, M, lf, bias):
         Q.GEMM_BACKEND = old
     assert_parity(y, y_lib.float().cpu().numpy().astype(np.float64), 2e-3)
     assert torch.equal(y, Q.fused_gemm_forward(layer.packed, layer.pbl_bias, xt))      # deterministic
+
+
+# ------------------------------------------------------------------------------------------- fp16-checkpoint zeros in the matrix-core tile
+def test_mfma_fp16_checkpoint_zero_valued_salients():
+    """The matrix-core kernel keeps MINUS the salient weight in its fp16 tile and tells entries from empty positions by "any
+    bit set": a salient of value 0 must come out as -0.  Rows with many exact zeros (q == zero point), a row with a non-integer
+    zero point and a scale so small that every product underflows to 0 in fp16, and a row of scale 0: the packers code only
+    entries whose negated product has a bit set (the rest become exceptions), the blob validates, unpacks bit-exactly and
+    every forward path agrees with the oracle."""
+    N, K = 32, 1024
+    rng = np.random.default_rng(5)
+    W = np.where(rng.random((N, K)) < 0.5, 0.25, -0.125).astype(np.float32)
+    ss = np.full(N, 0.01, np.float32); sz = np.full(N, 100.0, np.float32)
+    sal = rng.random((N, K)) < 0.15
+    q = rng.integers(0, 256, (N, K))
+    q[:, ::7] = 100                                           # plenty of exact zeros
+    ss[3] = 1e-9; sz[3] = 5.3                                 # every product underflows: the weight is +-0
+    ss[4] = 0.0                                               # degenerate quantizer
+    vals = (ss[:, None] * (q.astype(np.float32) - sz[:, None])).astype(np.float32).astype(np.float16).astype(np.float32)
+    W[sal] = vals[sal]
+    hi = np.full((N, 1), 0.25, np.float32); lo = np.full((N, 1), -0.125, np.float32)
+    p = pack_dense(W, hi, lo, ss, sz, sal.astype(np.uint8), sal_f16=True)
+    np.testing.assert_array_equal(p.unpack().numpy(), W)
+    assert p.nexc > 0                                          # the entries the tile could not represent
+    assert int((W[sal] == 0).sum()) > 300
+    pd = p.to(DEV)
+    for M in (1, 3, 16, 32):
+        x = synth.activations((M, K), 3 + M, 21)
+        ref = O.dense_linear(x, W)
+        assert_parity(Q.mfma_forward(pd, None, T(x), out_f32=True), ref, 2e-4)
+        assert_parity(Q.PBLinear(pd, None)(T(x)), ref)
+    # the device packer applies the same rule: byte-identical blob
+    pdv = pack_dense_dev_like(W, hi, lo, ss, sz, sal)
+    assert torch.equal(pdv.blob.cpu(), p.blob.cpu())
+
+
+def pack_dense_dev_like(W, hi, lo, ss, sz, sal):
+    from pb_llm_amd.packing import pack_dense_dev
+    return pack_dense_dev(T(W), T(hi), T(lo), T(ss), T(sz), T(sal.astype(np.uint8)), sal_f16=True)
+
+
+def test_routing_of_few_tokens_on_wide_layers():
+    """pbl_linear_f16_ws routing (tools/bench_route.py): a GEMV pass that would leave one workgroup per CU (K = 11008 with 3-4
+    tokens) goes to the matrix-core kernel, which then NEEDS its K-split workspace -- pbl_linear_workspace_bytes tells the
+    caller how much; without one, up to 8 tokens fall back to GEMV passes.  All routes agree with the oracle, and the module
+    (which asks for the workspace) takes well under the unsplit kernel's time."""
+    N, K = 2048, 11008
+    W = synth.llm_weight(N, K, seed=9)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    W16 = torch.from_numpy(r["W_fq"]).half()
+    layer = Q.PBLinear.from_dense(W16, None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+    ls = layer.packed.layer_struct(None)
+    L = _lib.lib()
+    assert L.pbl_linear_workspace_bytes(C.byref(ls), 1) == 0 and L.pbl_linear_workspace_bytes(C.byref(ls), 2) == 0
+    need = L.pbl_linear_workspace_bytes(C.byref(ls), 9)
+    assert need == L.pbl_mfma_workspace_bytes(C.byref(ls), 9) > 0
+    st = torch.cuda.current_stream().cuda_stream
+    for M in (3, 4, 7, 9):
+        x = synth.activations((M, K), 40 + M, 21)
+        ref = O.dense_linear(x, W16.float().numpy())
+        assert_parity(layer(T(x)), ref)                                           # module: workspace provided
+        y = torch.empty(M, N, dtype=torch.float16, device=DEV)
+        _lib.check(L.pbl_linear_f16(C.byref(ls), T(x).data_ptr(), y.data_ptr(), M, 0, st), "linear")   # no workspace
+        assert_parity(y, ref)
+
