@@ -6,13 +6,13 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from pb_llm_amd import quant as Q
 from pb_llm_amd.packing import PackedWeight
 sys.argv = [sys.argv[0]]
-CACHE = "/tmp/pbl_mfma_cache.pt"
+CACHE = os.environ.get("PBL_BENCH_CACHE", "/tmp/pbl_mfma_cache.pt")
 if not os.path.exists(CACHE):
     import runpy; runpy.run_path(os.path.join(REPO, "tools", "bench_mfma.py"))
 blobs = torch.load(CACHE)
 out = {}
 for shp, blob in blobs.items():
-    N, K = map(int, shp.split("x"))
+    N, K = map(int, shp.split(":")[0].split("x"))
     pk = PackedWeight.from_blob(blob).to("cuda:0")
     for dt in (torch.float16, torch.float32):
         Q.unpack_on_device(pk, dt); torch.cuda.synchronize()

@@ -62,7 +62,7 @@ def main():
             continue
         if sub.endswith("_trace"):
             print(f"\n## {sub}: kernel trace, un-instrumented timing (durations in us)")
-            for s in kernel_stats(p)[:6]:
+            for s in kernel_stats(p)[:10]:
                 print(json.dumps(s))
         want = "pbl_mfma_kernel" if sub.startswith("mfma") else ("pbl_gemm_kernel" if sub.startswith("gemm") else "pbl_gemv")
         if "pmc" in sub or "fetch" in sub or "write" in sub or "tcc" in sub:
