@@ -145,6 +145,14 @@ typedef enum {
 #define PBL_FLAG_SLABS 0x8u       /* the records carry the column-slab index (format version 2) */
 #define PBL_FLAG_KNOWN 0xFu
 
+/* Limits (every entry point answers PBL_ERR_UNSUPPORTED / PBL_ERR_BAD_BLOB beyond them; pb_llm_amd/packing.py names the limit):
+ *   in_features  K <= 32767          16-bit column indices with pre-doubled byte steps; shard wider layers along K
+ *   out_features N <= 2^24
+ *   column groups: K % G == 0 and K / G a multiple of 128; the kernels additionally want K / G a power of two
+ *   tokens per GEMV pass <= PBL_MAX_TOKENS_PER_LAUNCH (pbl_linear_f16 loops / routes to the matrix-core kernel beyond)
+ *   matrix-core kernels: K % 8 == 0, x 16-byte aligned, <= 32 tokens per pass; GEMM-regime kernel: fp16-checkpoint layers, G == 1
+ *   pbl_quant8_rows: K <= 16384 (prep.py falls back to the torch path above)
+ */
 typedef struct {
     uint32_t magic, version;
     uint32_t N, K;          /* out_features, in_features */

@@ -548,8 +548,14 @@ __global__ __launch_bounds__(256) void pbl_mfma_reduce(const float* __restrict__
 void pick_split(const pbl_layer* L, int& KS, int& sps) {
     const int NS = int((L->K + SLAB - 1) / SLAB);
     const int groups = int((L->NRB + WPG - 1) / WPG);
-    int ks = 512 / groups;
-    if (ks > NS / 2) ks = NS / 2;
+#ifndef PBL_MFMA_SLOTS
+#define PBL_MFMA_SLOTS 512
+#endif
+#ifndef PBL_MFMA_MIN_SLABS
+#define PBL_MFMA_MIN_SLABS 2
+#endif
+    int ks = PBL_MFMA_SLOTS / groups;
+    if (ks > NS / PBL_MFMA_MIN_SLABS) ks = NS / PBL_MFMA_MIN_SLABS;
     if (ks < 1) ks = 1;
     sps = (NS + ks - 1) / ks;
     KS = (NS + sps - 1) / sps;

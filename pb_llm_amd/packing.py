@@ -76,6 +76,22 @@ class PackedWeight:
         return PackedWeight(blob, h.N, h.K, h.P, h.G, h.NRB, h.flags, h.max_nch, h.max_nexc, h.nnz, h.nexc)
 
 
+MAX_IN_FEATURES = 32767          # 16-bit column indices in the salient list (include/pbl.h, "Limits")
+MAX_OUT_FEATURES = 1 << 24
+
+
+def _check_limits(N: int, K: int, G: int) -> None:
+    """The format's limits, spelled out before libpbl answers with a bare PBL_ERR_UNSUPPORTED."""
+    if K > MAX_IN_FEATURES:
+        raise _lib.PblError(f"in_features = {K}: the PBL1 format indexes columns with 16 bits (at most {MAX_IN_FEATURES}); "
+                            "shard the layer along K (parallel.shard_linear(..., mode='k')) and sum the partial outputs")
+    if N > MAX_OUT_FEATURES:
+        raise _lib.PblError(f"out_features = {N}: at most {MAX_OUT_FEATURES} rows per packed layer")
+    if G > 1 and (K % G or (K // G) % 128):
+        raise _lib.PblError(f"groupsize {K / G:g}: column groups must divide in_features and be multiples of 128 "
+                            "(power-of-two sizes for the kernels: 128, 256, 512, ...)")
+
+
 def pack_dense(W, hi, lo, sscale=None, szero=None, sal_mask=None, sal_f16: bool = False) -> PackedWeight:
     """Pack a dense simulated weight.  W [N,K]; hi, lo [N,G] (the two values the
     binarized weights of each row/group take); sscale, szero [N] (salient value =
@@ -90,6 +106,7 @@ def pack_dense(W, hi, lo, sscale=None, szero=None, sal_mask=None, sal_f16: bool 
     G = hi.shape[1]
     if lo.shape != hi.shape:
         raise ValueError("hi / lo shape mismatch")
+    _check_limits(N, K, G)
     ss = _f32(sscale).reshape(N) if sscale is not None else None
     sz = _f32(szero).reshape(N) if szero is not None else None
     sm = None
@@ -121,6 +138,7 @@ def pack_dense_dev(W: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor, sscale: 
     f32 = lambda t: None if t is None else torch.as_tensor(t, device=dev).detach().to(torch.float32).contiguous()   # noqa: E731
     hi, lo = f32(hi).reshape(N, -1), f32(lo).reshape(N, -1)
     G = hi.shape[1]
+    _check_limits(N, K, G)
     if lo.shape != hi.shape:
         raise ValueError("hi / lo shape mismatch")
     ss, sz = f32(sscale), f32(szero)

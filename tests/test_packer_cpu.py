@@ -161,9 +161,9 @@ def test_bad_arguments_and_blobs():
     assert L.pbl_pack_dense_f32(None, 1, 1, 1, None, None, None, None, None, 0, None, 0, C.byref(sz)) == -1
     W = np.zeros((16, 512), np.float32)
     hi = np.ones((16, 3), np.float32)
-    with pytest.raises(_lib.PblError):       # K % G != 0 / groupsize not a multiple of 128
+    with pytest.raises(_lib.PblError, match="multiples of 128"):       # K % G != 0 / groupsize not a multiple of 128
         pack_dense(W, hi, -hi)
-    with pytest.raises(_lib.PblError):       # column indices are 16 bit with pre-doubled byte steps: K <= 32767
+    with pytest.raises(_lib.PblError, match="16 bits"):   # column indices are 16 bit with pre-doubled byte steps: K <= 32767
         pack_dense(np.zeros((1, 32768), np.float32), np.ones((1, 1), np.float32), -np.ones((1, 1), np.float32))
     junk = torch.zeros(256, dtype=torch.uint8)
     with pytest.raises(_lib.PblError):
