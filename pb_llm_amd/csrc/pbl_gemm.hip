@@ -87,8 +87,15 @@ struct MfmaArgs {
 };
 
 constexpr size_t MFMA_WAVE_BYTES = 16 + size_t(16) * SSTR * 2 + 2 * 512 + 256;   // dump slot + St + Wp + Wp << 8 + row params
+// One x tile instead of two for <= 16 tokens: 48 KB of LDS instead of 56, i.e. THREE workgroups per CU instead of two, for
+// one more barrier per slab; the K split then aims at 768 workgroup slots.  Measured (gpurun_out/s24, 8-16 tokens):
+// 11008x4096 29.2 -> 23.0 us, 13824x5120 40.6 -> 36.8, 4096x11008 29.0 -> 27.1, 4096^2 unchanged.
+#ifndef PBL_MFMA_X1
+#define PBL_MFMA_X1 1
+#endif
+__host__ __device__ constexpr int mfma_xbufs(int ntb) { return (PBL_MFMA_X1 && ntb == 1) ? 1 : 2; }
 __host__ __device__ constexpr size_t mfma_lds_bytes(int ntb) {
-    return size_t(2) * 16 * ntb * SSTR * 2 + WPG * MFMA_WAVE_BYTES + 128 + 512;   // + Xsum[32] + Xh[2][2][32]
+    return size_t(mfma_xbufs(ntb)) * 16 * ntb * SSTR * 2 + WPG * MFMA_WAVE_BYTES + 128 + 512;   // + Xsum[32] + Xh[2][2][32]
 }
 
 // GRP: the layer has column groups (G > 1, a power-of-two number of columns >= 128 each): the binarized part and the salient
@@ -98,6 +105,7 @@ template <int NTB, bool SF, bool Q4, bool GRP>
 __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     constexpr int XT = 16 * NTB;                   // token rows of the x tile
+    constexpr int XB = mfma_xbufs(NTB);            // x tiles in LDS
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const pbl_layer& L = a.L;
@@ -130,12 +138,12 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     // LDS: x tiles [2][XT][SSTR] fp16 (shared); per wave St[16][SSTR] fp16, Wp[2][64] / Wp8[2][64] dwords (the slab's sign
     // plane, [128-column sub-block][lane], as is and << 8), the record's row params; Xsum[32] (shared, at the end)
     _Float16* Xs = reinterpret_cast<_Float16*>(smem_g);
-    char* wbase = smem_g + size_t(2) * XT * SSTR * 2 + size_t(wave) * MFMA_WAVE_BYTES;
+    char* wbase = smem_g + size_t(XB) * XT * SSTR * 2 + size_t(wave) * MFMA_WAVE_BYTES;
     _Float16* St = reinterpret_cast<_Float16*>(wbase + 16);   // 16 bytes in front: where row 0's out-of-slab entries are dumped
     uint32_t* Wp = reinterpret_cast<uint32_t*>(wbase + 16 + size_t(16) * SSTR * 2);
     uint32_t* Wp8 = Wp + 128;
     float4* prm = reinterpret_cast<float4*>(Wp8 + 128);                        // [16] {hi, lo, sscale, szero}
-    float* Xsum = reinterpret_cast<float*>(smem_g + size_t(2) * XT * SSTR * 2 + WPG * MFMA_WAVE_BYTES);
+    float* Xsum = reinterpret_cast<float*>(smem_g + size_t(XB) * XT * SSTR * 2 + WPG * MFMA_WAVE_BYTES);
     float* Xh = Xsum + 32;                          // [buf][half slab][token] (GRP)
 
     const int row_a = lane & 15, kblk = lane >> 4;   // fragment coordinates: A row / B token, 8-column block
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
         const uint32_t wr = min(blockIdx.x * WPG + uint32_t(tid >> 4), L.NRB - 1);
         const uint4 winfo = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[wr];
         const float4* wp = reinterpret_cast<const float4*>(blob + size_t(winfo.x) * 16 + PBL_REC_PARAMS_OFF);
-        reinterpret_cast<float4*>(smem_g + size_t(2) * XT * SSTR * 2 + size_t(tid >> 4) * MFMA_WAVE_BYTES + 16 + size_t(16) * SSTR * 2 + 1024)[tid & 15] = wp[tid & 15];
+        reinterpret_cast<float4*>(smem_g + size_t(XB) * XT * SSTR * 2 + size_t(tid >> 4) * MFMA_WAVE_BYTES + 16 + size_t(16) * SSTR * 2 + 1024)[tid & 15] = wp[tid & 15];
     }
     u32x4 t_cur = {0, 0, 0, 0}, t_next = {0, 0, 0, 0};
     ChunkRegs cA, cB, cC, nA, nB, nC;                  // rounds 0, 1, 2 of the current / next slab
@@ -373,12 +381,15 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     if (s0 < s1) store_x(0);
 
     for (int s = s0; s < s1; ++s) {
-        const int buf = (s - s0) & 1, half = s & 1, cb = s * SLAB;
+        const int buf = XB == 2 ? (s - s0) & 1 : 0, half = s & 1, cb = s * SLAB;
         const bool more = s + 1 < s1;
         // x of THIS slab, loaded during the previous iteration, goes to its LDS tile first: the only wait on memory in
         // the loop then is for loads that have had a whole iteration to land.  (Tile `buf` was last read two slabs ago
         // and every wave has passed the previous slab's barrier since.)
-        if (s > s0) store_x(buf);
+        if (s > s0) {
+            if (XB == 1) __syncthreads();          // a single x tile: every wave must be done with the previous slab's fragments
+            store_x(buf);
+        }
         // everything slab s+1 needs from memory, issued now, consumed a slab later
         const Seq sqn = seq_of(e0, e1);
         uint32_t e3 = 0;
@@ -545,7 +556,7 @@ __global__ __launch_bounds__(256) void pbl_mfma_reduce(const float* __restrict__
 // K splits so that ONE round of workgroups fills the chip: 256 CUs x 2 resident workgroups (LDS bound).  A second,
 // partly filled round costs a whole workgroup time, and every workgroup pays a prologue of ~3 dependent memory
 // latencies, so fewer, longer workgroups win; at least 2 slabs per split.
-void pick_split(const pbl_layer* L, int& KS, int& sps) {
+void pick_split(const pbl_layer* L, int& KS, int& sps, int ntb = 2) {
     const int NS = int((L->K + SLAB - 1) / SLAB);
     const int groups = int((L->NRB + WPG - 1) / WPG);
 #ifndef PBL_MFMA_SLOTS
@@ -554,7 +565,7 @@ void pick_split(const pbl_layer* L, int& KS, int& sps) {
 #ifndef PBL_MFMA_MIN_SLABS
 #define PBL_MFMA_MIN_SLABS 2
 #endif
-    int ks = PBL_MFMA_SLOTS / groups;
+    int ks = (mfma_xbufs(ntb) == 1 ? (PBL_MFMA_SLOTS * 3) / 2 : PBL_MFMA_SLOTS) / groups;
     if (ks > NS / PBL_MFMA_MIN_SLABS) ks = NS / PBL_MFMA_MIN_SLABS;
     if (ks < 1) ks = 1;
     sps = (NS + ks - 1) / ks;
@@ -575,8 +586,8 @@ bool mfma_supported(const pbl_layer* layer, const void* x) {
 extern "C" size_t pbl_mfma_workspace_bytes(const pbl_layer* layer, int M) {
     if (!layer || M < 1) return 0;
     int KS, sps;
-    pick_split(layer, KS, sps);
     const int mb = M < 32 ? M : 32;
+    pick_split(layer, KS, sps, mb <= 16 ? 1 : 2);
     return KS > 1 ? size_t(KS) * mb * layer->N * sizeof(float) : 0;
 }
 
@@ -588,7 +599,7 @@ extern "C" int pbl_gemm_mfma_f16_ws(const pbl_layer* layer, const void* x, void*
     hipStream_t st = static_cast<hipStream_t>(stream);
     MfmaArgs a;
     a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32;
-    pick_split(layer, a.KS, a.sps);
+    pick_split(layer, a.KS, a.sps, M <= 16 ? 1 : 2);
     const size_t need = size_t(a.KS) * M * layer->N * sizeof(float);
     if (a.KS > 1 && (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))) {
         a.KS = 1; a.sps = int((layer->K + SLAB - 1) / SLAB);              // no workspace: one split

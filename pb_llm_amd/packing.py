@@ -46,10 +46,17 @@ class PackedWeight:
                             self.max_nch, self.max_nexc, self.nnz, self.nexc)
 
     def layer_struct(self, bias: torch.Tensor | None = None) -> _lib.PblLayer:
-        if self.blob.data_ptr() % 16:
+        """The C descriptor of the layer (borrowed pointers).  Cached per (blob address, bias address): an eager decode calls
+        this 224 times per token, and building a ctypes structure costs as much as the launch it describes."""
+        bp, wp = (bias.data_ptr() if bias is not None else 0), self.blob.data_ptr()
+        hit = self.__dict__.get("_struct")
+        if hit is not None and hit[0] == wp and hit[1] == bp:
+            return hit[2]
+        if wp % 16:
             raise _lib.PblError("blob is not 16-byte aligned")
-        return _lib.PblLayer(self.blob.data_ptr(), bias.data_ptr() if bias is not None else None,
-                             self.N, self.K, self.P, self.G, self.NRB, self.flags, self.max_nch, self.max_nexc)
+        st = _lib.PblLayer(wp, bp or None, self.N, self.K, self.P, self.G, self.NRB, self.flags, self.max_nch, self.max_nexc)
+        self.__dict__["_struct"] = (wp, bp, st)
+        return st
 
     def unpack(self) -> torch.Tensor:
         """Dense simulated weight, fp32 [N, K] on the host (to_regular_linear,

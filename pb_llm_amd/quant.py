@@ -143,12 +143,12 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
 
     def run(layer_s, xin, yout, rows, f32):
         # the K-split scratch of the matrix-core kernel, when pbl_linear_f16_ws is going to route this call there
-        nb = L.pbl_linear_workspace_bytes(C.byref(layer_s), rows)
+        nb = L.pbl_linear_workspace_bytes(C.byref(layer_s), rows) if rows > 1 else 0      # one token is always one GEMV pass
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
         _lib.check(L.pbl_linear_f16_ws(C.byref(layer_s), xin.data_ptr(), yout.data_ptr(), rows, int(f32),
                                        ws.data_ptr() if ws is not None else None, nb, stream), "linear")
 
-    rows = M if x.dtype == torch.float16 else 2 * M     # fp32 / bf16 x runs as two fp16 terms
+    rows = 2 * M if x.dtype == torch.float32 else M     # fp32 x runs as two fp16 terms (bf16 converts exactly)
     if (rows > MFMA_MAX) if mfma_ok else (M >= GEMM_THRESHOLD):
         # GEMM regime: dense weight in the workspace + library GEMM, i.e. exactly what the
         # reference executes (F.linear over the dense fake-quant weight).  fp16 weights when
@@ -167,7 +167,15 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
         run(layer, xc, y, M, out_f32)
         return y.reshape(*lead, packed.N)
-    # fp32 / bf16 activations: x = x_hi + x_lo with both terms fp16; the kernel is
+    if x.dtype == torch.bfloat16:
+        # bf16 -> fp16 is exact (8 significand bits into 11) inside fp16's range: ONE pass, fp32 accumulation, bf16 result.
+        # Out-of-range values are saturated to +-65504 (the two-term split below cannot represent them either); magnitudes
+        # below 2^-24 round to fp16 subnormals (absolute error < 3e-8).
+        xc = x2.float().clamp_(-65504.0, 65504.0).half().contiguous()
+        y = torch.empty(M, packed.N, dtype=torch.float32, device=x.device)
+        run(layer, xc, y, M, True)
+        return (y if out_f32 else y.to(x.dtype)).reshape(*lead, packed.N)
+    # fp32 activations: x = x_hi + x_lo with both terms fp16; the kernel is
     # linear in x, so y = W x_hi + W x_lo accumulated in fp32 (bias added once).
     xf = x2.float()
     x_hi = xf.half()

@@ -493,3 +493,28 @@ def test_routing_of_few_tokens_on_wide_layers():
         _lib.check(L.pbl_linear_f16(C.byref(ls), T(x).data_ptr(), y.data_ptr(), M, 0, st), "linear")   # no workspace
         assert_parity(y, ref)
 
+
+
+def test_bf16_activations_single_pass():
+    """bf16 -> fp16 is exact inside fp16's range, so bf16 activations take ONE pass (round 1 ran two fp16 terms and spilled to
+    the dense path from 17 tokens on): every token count up to 32 stays on the packed kernels, the result equals the oracle on
+    the bf16 inputs to fp32-accumulation accuracy before the final bf16 rounding, and values beyond fp16's range saturate
+    instead of producing inf / nan."""
+    N, K = 512, 2048
+    W = synth.llm_weight(N, K, seed=31)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    W16 = torch.from_numpy(r["W_fq"]).half()
+    layer = Q.PBLinear.from_dense(W16, None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+    for M in (1, 4, 17, 32, 40):
+        xb = T(synth.activations((M, K), 70 + M, 21)).bfloat16()
+        ref = O.dense_linear(xb.float().cpu().numpy(), W16.float().numpy())
+        y32 = Q.pb_linear_forward(layer.packed, None, xb, out_f32=True)
+        assert y32.dtype == torch.float32
+        assert_parity(y32, ref, 2e-4 if M <= 32 else 2e-3)          # (40 rows: dense workspace + library GEMM in fp32)
+        y = layer(xb)
+        assert y.dtype == torch.bfloat16
+        np.testing.assert_allclose(y.float().cpu().numpy(), ref, rtol=1e-2, atol=2e-2)
+    xb = torch.zeros(2, K, dtype=torch.bfloat16, device=DEV)
+    xb[0, 5] = 1e6; xb[1, 7] = -3e38
+    assert torch.isfinite(layer(xb).float()).all()
