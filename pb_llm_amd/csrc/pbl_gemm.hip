@@ -557,6 +557,8 @@ __global__ __launch_bounds__(256) void pbl_mfma_reduce(const float* __restrict__
 // partly filled round costs a whole workgroup time, and every workgroup pays a prologue of ~3 dependent memory
 // latencies, so fewer, longer workgroups win; at least 2 slabs per split.
 void pick_split(const pbl_layer* L, int& KS, int& sps, int ntb = 2) {
+    // three resident workgroups per CU need <= 170 VGPRs per wave as well: the column-group kernels (182-234) stay at two
+    const bool three = mfma_xbufs(ntb) == 1 && L->G == 1;
     const int NS = int((L->K + SLAB - 1) / SLAB);
     const int groups = int((L->NRB + WPG - 1) / WPG);
 #ifndef PBL_MFMA_SLOTS
@@ -565,7 +567,7 @@ void pick_split(const pbl_layer* L, int& KS, int& sps, int ntb = 2) {
 #ifndef PBL_MFMA_MIN_SLABS
 #define PBL_MFMA_MIN_SLABS 2
 #endif
-    int ks = (mfma_xbufs(ntb) == 1 ? (PBL_MFMA_SLOTS * 3) / 2 : PBL_MFMA_SLOTS) / groups;
+    int ks = (three ? (PBL_MFMA_SLOTS * 3) / 2 : PBL_MFMA_SLOTS) / groups;
     if (ks > NS / PBL_MFMA_MIN_SLABS) ks = NS / PBL_MFMA_MIN_SLABS;
     if (ks < 1) ks = 1;
     sps = (NS + ks - 1) / ks;
