@@ -230,7 +230,10 @@ __global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     // packers never emit an entry whose u would be +0: zero scale, or a product that underflows from the positive side.)
     const int st_row = int(uint32_t(reinterpret_cast<uintptr_t>(St))) + rho_s * (SSTR * 2);   // LDS byte address of the lane's tile row
     const int clamp_lo = st_row - 2 * (1 + (lane & 7)), clamp_hi = st_row + 2 * (SLAB + (lane & 7));
-    const float nss = -prs.z;
+    float nss = -prs.z;
+    // (opaque to the optimiser: it must stay a multiplication by a NEGATIVE factor -- rewritten as ss * (sz - q) the product of a
+    // zero-valued salient would be +0, an empty tile position)
+    asm volatile("" : "+v"(nss));
     uint32_t abl_acc = 0;   // ablation builds only
     auto store_half = [&](int addr, uint32_t v, bool hi) {
         if (PBL_MFMA_ABLATE & 32) { abl_acc ^= uint32_t(addr) ^ v; return; }     // everything but the LDS write

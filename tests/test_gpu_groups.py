@@ -170,3 +170,27 @@ def test_fuse_decode_on_a_model_with_column_groups():
             # 3-4 rows: the fused launch runs the GEMV variant twice, the members alone the matrix-core kernel (small
             # layers: the GEMV too) -- equal to rounding
             torch.testing.assert_close(a.float(), b.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_zero_valued_fp16_salients_with_column_groups():
+    """fp16-checkpoint layers with groups and MANY salients of value exactly 0 (code == zero point): the matrix-core tile must
+    hold them as -0 (an all-zero half is an empty position whose binarized level is not cancelled)"""
+    N, K, gs = 48, 1024, 256
+    rng = np.random.default_rng(11)
+    G = K // gs
+    hi = (0.2 + 0.1 * rng.random((N, G))).astype(np.float16).astype(np.float32)
+    lo = (-0.15 - 0.1 * rng.random((N, G))).astype(np.float16).astype(np.float32)
+    W = np.where(rng.random((N, K)) < 0.5, np.repeat(hi, gs, 1), np.repeat(lo, gs, 1)).astype(np.float32)
+    ss = np.full(N, 0.01, np.float32); sz = np.full(N, 100.0, np.float32)
+    sal = rng.random((N, K)) < 0.15
+    q = rng.integers(0, 256, (N, K)); q[:, ::5] = 100
+    vals = (ss[:, None] * (q.astype(np.float32) - sz[:, None])).astype(np.float16).astype(np.float32)
+    W[sal] = vals[sal]
+    p = pack_dense(W, hi, lo, ss, sz, sal.astype(np.uint8), sal_f16=True)
+    assert p.G == G and p.nexc == 0 and int((W[sal] == 0).sum()) > 500
+    pd = p.to(DEV)
+    for M in (1, 2, 5, 11, 16, 17, 32):
+        x = synth.activations((M, K), 90 + M, 21)
+        ref = O.dense_linear(x, W)
+        assert_parity(Q.mfma_forward(pd, None, T(x), out_f32=True), ref, 2e-4)
+        assert_parity(Q.PBLinear(pd, None)(T(x)), ref)
