@@ -307,6 +307,12 @@ int pbl_gemm_f16(const pbl_layer* layer, const void* x, void* y, int M, void* st
  * (gptq_pb/eval_ppl_utils.py:55-64 via the HF attention / MLP modules). */
 int pbl_gemv_f16_fused(const pbl_layer* layers_dev, const uint64_t* y_off_dev, const void* x, void* y, int L, int M,
                        uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, void* stream);
+/* The same launch for at most PBL_FUSED_INLINE_MAX layers with HOST arrays: the descriptors and offsets are copied into the
+ * kernel arguments, so no device table is read (one dependent memory round trip less per workgroup; q/k/v and gate/up groups
+ * are 3 and 2 layers).  Graph-capturable like the device-table form: the arguments are captured by value. */
+#define PBL_FUSED_INLINE_MAX 4
+int pbl_gemv_f16_fused_host(const pbl_layer* layers_host, const uint64_t* y_off_host, const void* x, void* y, int L, int M,
+                            uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, void* stream);
 
 /* ---------------- QAT step, weight side ------------------------------------------ */
 /* The elementwise work of one training step of BinaryXnorExceptOutliersLinear

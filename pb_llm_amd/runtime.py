@@ -89,6 +89,10 @@ class FusedGemv:
         structs = (_lib.PblLayer * len(self.packed))(*[p.layer_struct(b) for p, b in zip(self.packed, self.biases)])
         self._layers_dev = torch.from_numpy(np.frombuffer(bytes(structs), dtype=np.uint8).copy()).to(self.device)
         self._yoff_dev = torch.tensor(self.offs[:-1].tolist(), dtype=torch.int64, device=self.device)
+        # up to PBL_FUSED_INLINE_MAX members: descriptors and offsets go into the kernel arguments (pbl_gemv_f16_fused_host)
+        self._inline = len(self.packed) <= _lib.PBL_FUSED_INLINE_MAX
+        self._structs_host = structs
+        self._yoff_host = (C.c_uint64 * len(self.packed))(*[int(o) for o in self.offs[:-1]])
         self.max_NRB = max(p.NRB for p in self.packed)
         self.max_nch = max(p.max_nch for p in self.packed)
         # bit 0: column-group layers present (the launch then runs the column-group kernel), bit 1: fp16-checkpoint layers present
@@ -101,9 +105,15 @@ class FusedGemv:
         total = int(self.offs[-1])
         y = torch.empty(M, total, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
         st = torch.cuda.current_stream(x2.device).cuda_stream
-        _lib.check(_lib.lib().pbl_gemv_f16_fused(self._layers_dev.data_ptr(), self._yoff_dev.data_ptr(), x2.data_ptr(), y.data_ptr(),
+        L = _lib.lib()
+        if self._inline:
+            _lib.check(L.pbl_gemv_f16_fused_host(C.addressof(self._structs_host), C.addressof(self._yoff_host), x2.data_ptr(), y.data_ptr(),
                                                  len(self.packed), M, total, self.max_NRB, self.K, self.max_nch, self.flags,
                                                  int(out_f32), st), "fused gemv")
+        else:
+            _lib.check(L.pbl_gemv_f16_fused(self._layers_dev.data_ptr(), self._yoff_dev.data_ptr(), x2.data_ptr(), y.data_ptr(),
+                                            len(self.packed), M, total, self.max_NRB, self.K, self.max_nch, self.flags,
+                                            int(out_f32), st), "fused gemv")
         return [y[:, int(self.offs[i]):int(self.offs[i + 1])] for i in range(len(self.packed))]
 
     def algorithmic_bytes(self, M: int = 1) -> int:

@@ -518,3 +518,24 @@ def test_bf16_activations_single_pass():
     xb = torch.zeros(2, K, dtype=torch.bfloat16, device=DEV)
     xb[0, 5] = 1e6; xb[1, 7] = -3e38
     assert torch.isfinite(layer(xb).float()).all()
+
+
+def test_fused_launch_inline_and_table_descriptors_agree():
+    """up to 4 fused members travel in the kernel arguments (pbl_gemv_f16_fused_host), more through the device table
+    (pbl_gemv_f16_fused): both equal the members' own launches bit for bit"""
+    from pb_llm_amd.runtime import FusedGemv
+    K = 1024
+    ps, xs = [], synth.activations((2, K), 12, 21)
+    for i, N in enumerate((64, 96, 48, 128, 80)):
+        W = synth.llm_weight(N, K, seed=40 + i)
+        mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        ps.append(pack_dense(r["W_fq"], r["scale"][0] + r["mean"][0], -r["scale"][0] + r["mean"][0], r["hscale"], r["hzero"],
+                             (~mask).astype(np.uint8)).to(DEV))
+    f5, f3 = FusedGemv(ps, None, DEV), FusedGemv(ps[:3], None, DEV)
+    assert not f5._inline and f3._inline
+    o5, o3 = f5(T(xs), out_f32=True), f3(T(xs), out_f32=True)
+    for a, b in zip(o3, o5[:3]):
+        assert torch.equal(a, b)
+    for p, o in zip(ps, o5):
+        assert_parity(o, O.dense_linear(xs, p.unpack().numpy()), 2e-4)
