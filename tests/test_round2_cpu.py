@@ -158,3 +158,33 @@ def test_bench_refuses_a_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_forward_routing_decisions_without_a_gpu():
+    """pbl_linear_workspace_bytes is pure host logic (the routing of pbl_linear_f16_ws): > 0 means "this call goes to the
+    matrix-core kernel, bring the K-split scratch".  Pins the decisions measured in tools/bench_route.py."""
+    L = _lib.lib()
+
+    def layer(N, K, sal_frac, G=1, flags=_lib.PBL_FLAG_SLABS | 0x4):          # 0x4 = PBL_FLAG_TAIL_REPEAT
+        nrb = (N + 15) // 16
+        max_nch = int(16 * K * sal_frac / 16) + 16
+        return _lib.PblLayer(0x1000, None, N, K, (K + 511) // 512, G, nrb, flags | (1 if G > 1 else 0), max_nch, 0)
+
+    def ws(l, M):
+        return L.pbl_linear_workspace_bytes(C.byref(l), M)
+
+    q = layer(4096, 4096, 0.1)
+    assert [ws(q, M) > 0 for M in (1, 2, 4, 9, 32)] == [False, False, False, True, True]      # <= 4 tokens: one GEMV pass
+    down = layer(4096, 11008, 0.1)
+    assert ws(down, 2) == 0                                   # two tokens still fit a pass with two workgroups per CU (72 KB)
+    assert ws(down, 9) > 0 and ws(down, 32) > 0
+    ffn = layer(13824, 5120, 0.2)
+    assert ws(ffn, 3) == 0 and ws(ffn, 4) > 0                 # 4 tokens would need 89 KB of LDS: matrix-core kernel
+    tiny = layer(768, 2048, 0.1)
+    assert ws(tiny, 8) == 0 and ws(tiny, 9) > 0               # few records: GEMV up to 8 tokens, both are latency bound
+    assert ws(layer(768, 768, 0.1), 9) == 0                   # three slabs only: the matrix-core kernel runs unsplit, no scratch
+    odd = layer(4096, 4100, 0.1)
+    assert ws(odd, 32) == 0                                   # K % 8 != 0: the matrix-core kernel does not apply
+    grp = layer(4096, 4096, 0.1, G=32)
+    assert ws(grp, 2) == 0 and ws(grp, 3) > 0                 # column groups: two tokens per GEMV pass
+    assert ws(layer(4096, 4096, 0.1, flags=0x4), 32) == 0     # a version-1 style blob without the slab index
