@@ -536,10 +536,18 @@ __global__ __launch_bounds__(256) void pbl_mfma_reduce(const float* __restrict__
     const size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * 4;
     if (i >= MN) return;
     if (i + 4 <= MN && !(MN & 3)) {
+        // the partial outputs of up to 8 splits are requested together (one memory latency, not one per split) and added in
+        // split order
         float4 s = *reinterpret_cast<const float4*>(part + i);
-        for (int k = 1; k < KS; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(part + size_t(k) * MN + i);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        for (int k0 = 1; k0 < KS; k0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = k0 + j < KS ? *reinterpret_cast<const float4*>(part + size_t(k0 + j) * MN + i) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (k0 + j < KS) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+            }
         }
         if (y_f32) *reinterpret_cast<float4*>(static_cast<float*>(y) + i) = s;
         else {
