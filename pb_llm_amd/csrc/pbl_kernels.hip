@@ -1032,15 +1032,16 @@ static Route route_of(const pbl_layer* layer, int M, bool x_aligned) {
              (layer->flags & PBL_FLAG_TAIL_REPEAT) && (layer->flags & PBL_FLAG_SLABS);
     if (r.mfma && M <= 8 && layer->G == 1) {
         // a few tokens more than one pass holds: several GEMV passes can still beat the matrix-core kernel.  Estimates in us,
-        // fitted to tools/bench_route.py on MI355X (4096^2, 11008x4096, 4096x11008, 13824x5120 at 5-20 % salients; within 30 %):
-        //   GEMV pass of mb tokens   4.5 + packed bytes / 4 TB/s + 0.09 * (N K / 1e6) * mb
-        //   matrix-core kernel       9 + 0.43 * (N K / 1e6)          (flat in M up to 32 tokens)
+        // fitted to tools/bench_route.py on MI355X (4096^2, 11008x4096, 4096x11008, 13824x5120 at 5-20 % salients; within 20 %):
+        //   GEMV pass of mb tokens   3.5 + packed bytes / 6.5 TB/s + (N K / 1e6) * (0.04 + 0.33 * salient density) * mb
+        //   matrix-core kernel       8.5 + (N K / 1e6) * (0.27 + 0.7 * salient density)      (flat in M up to 16 tokens)
         const double wm = double(layer->N) * layer->K * 1e-6;
-        const double bytes = double(layer->N) * layer->K / 8 + double(layer->max_nch) * layer->NRB * 34.0;
-        const double pass0 = 4.5 + bytes / 4e6;
+        const double nnz = double(layer->max_nch) * layer->NRB * 16.0;             // upper bound: every record as full as the fullest
+        const double bytes = double(layer->N) * layer->K / 8 + nnz * 2.125;
+        const double pass0 = 3.5 + bytes / 6.5e6, per_tok = wm * (0.04 + 0.33 * nnz / (wm * 1e6));
         double gemv = 0;
-        for (int m0 = 0; m0 < M; m0 += r.mb_max) gemv += pass0 + 0.09 * wm * (M - m0 < r.mb_max ? M - m0 : r.mb_max);
-        r.mfma = 9.0 + 0.43 * wm < gemv;
+        for (int m0 = 0; m0 < M; m0 += r.mb_max) gemv += pass0 + per_tok * (M - m0 < r.mb_max ? M - m0 : r.mb_max);
+        r.mfma = 8.5 + wm * (0.27 + 0.7 * nnz / (wm * 1e6)) < gemv;
     }
     if (r.mfma && layer->G != 1) {
         const uint32_t gs = layer->K / layer->G;
