@@ -255,13 +255,15 @@ int pbl_linear_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_
  * fp16-representable to be exact (true for layers packed from an fp16 checkpoint). */
 int pbl_unpack_dev(const pbl_layer* layer, void* W_out, int out_f32, void* stream);
 
-/* Matrix-core kernel for 1 <= M <= 32 tokens, any layer with G == 1, K % 8 == 0, PBL_FLAG_TAIL_REPEAT | PBL_FLAG_SLABS
- * and x 16-B aligned (else PBL_ERR_UNSUPPORTED): ONE pass over the packed weights for all tokens.  A workgroup of 4
+/* Matrix-core kernel for 1 <= M <= 32 tokens, any layer with K % 8 == 0, PBL_FLAG_TAIL_REPEAT | PBL_FLAG_SLABS, column
+ * groups (if any) of a power-of-two size >= 128, and x 16-B aligned (else PBL_ERR_UNSUPPORTED): ONE pass over the packed
+ * weights for all tokens.  A workgroup of 4
  * waves owns 4 records and walks the columns in 256-column slabs; the slab of x is staged in LDS once for the 4 waves;
  * per slab a wave builds class-coded sign-plane A fragments in registers, scatters its record's salient entries of the
  * slab (found through the slab index) into an fp16 tile, derives the salient mask from that tile, and contracts with
- * v_mfma_f32_16x16x32_f16; fp32 decode identical to the GEMV.  y fp16 (y_f32 == 0) or fp32.
- * pbl_linear_f16 routes M > 4 here by itself. */
+ * v_mfma_f32_16x16x32_f16; fp32 decode identical to the GEMV.  y fp16 (y_f32 == 0) or fp32.  Column-group layers fold the
+ * accumulators into per-row totals at every group boundary.  Up to 16 tokens a workgroup keeps one x tile (three workgroups
+ * per CU), above that two.  pbl_linear_f16_ws routes here by itself (see pbl_linear_workspace_bytes). */
 int pbl_gemm_mfma_f16(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream);
 
 /* The same kernel with a K split: a layer with few records (N = 4096: 256) cannot fill 1024 SIMDs with one wave per

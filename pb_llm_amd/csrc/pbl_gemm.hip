@@ -1,7 +1,7 @@
 // pbl_gemm.hip -- small-batch GEMM (1 <= M <= 32 tokens) straight from the PBL1 packed format, on the
 // matrix cores.  The GEMV streams the weights once per 4 tokens; this kernel streams them ONCE for up to
 // 32 tokens (batched decode, short prefill: BASELINE config 4).  Replaces F.linear(x, W_fq, b) of the
-// reference (quant/outlier_quantizer.py:105, gptq_pb/eval_ppl_utils.py:59-60).  Any layer with G == 1.
+// reference (quant/outlier_quantizer.py:105, gptq_pb/eval_ppl_utils.py:59-60).  Layers with or without column groups.
 //
 // Work decomposition (round 2; round 1 counting-sorted every record's chunks per launch and loaded x per wave):
 //   * a workgroup = 4 waves = 4 consecutive 16-row records; all four walk the SAME columns, slab by slab
