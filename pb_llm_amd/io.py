@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .packing import PackedWeight
-from .quant import BinaryInterface, PBLinear, _DenseBacked
+from .quant import BinaryInterface, PBLinear
 
 _DTYPES = {"float16": torch.float16, "float32": torch.float32, "bfloat16": torch.bfloat16}
 

@@ -10,7 +10,6 @@ synchronisation: binary_scale stays a device scalar.
 """
 from __future__ import annotations
 
-import ctypes as C
 
 import torch
 import torch.nn.functional as F

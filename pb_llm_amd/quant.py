@@ -35,10 +35,10 @@ class BinaryInterface:
 
 
 # Kernel choice by token count (rows of x after flattening):
-#   rows <= 4            bit-unpacking GEMV (pbl_linear_f16), weights streamed once
-#   rows <= MFMA_MAX     matrix-core kernel (pbl_linear_f16 routes to pbl_gemm_mfma_f16), weights streamed once
+#   rows <= MFMA_MAX     packed kernels: pbl_linear_f16_ws routes between GEMV passes (weights streamed once per <= 4 tokens)
+#                        and the matrix-core kernel (once per 32 tokens) by LDS footprint and a measured cost estimate
 #   above                unpack to a transient dense workspace + library GEMM (prefill / large batches)
-# Layers the matrix-core kernel cannot take (column groups, K % 8) switch to the dense path at GEMM_THRESHOLD.
+# Layers the matrix-core kernel cannot take (odd group sizes, K % 8) switch to the dense path at GEMM_THRESHOLD.
 MFMA_MAX = 32
 GEMM_THRESHOLD = 12
 # GEMM regime backend: "fused" = pbl_gemm_f16, the hand-written kernel that rebuilds exact fp16 weight tiles in LDS from the
