@@ -46,6 +46,25 @@ __global__ void one_mfma(const uint32_t* __restrict__ a, const uint32_t* __restr
     for (int r = 0; r < 4; ++r) d[l * 4 + r] = c[r];
 }
 
+// fragments from sign bits: one dword of row-major bits per lane -> four v_and_or -> the FP4 operand (as the prototype kernel does)
+__global__ void bits_mfma(const uint32_t* __restrict__ wbits, const uint32_t* __restrict__ b, float* __restrict__ d, const uint32_t* __restrict__ sc) {
+    const int l = threadIdx.x;
+    const uint32_t w = wbits[l];
+    uint32_t c22 = 0x22222222u, c00 = 0u;
+    asm volatile("" : "+v"(c22), "+v"(c00));
+    uint32_t f0, f1, f2, f3;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(f0) : "v"(w), "s"(0x11111111u), "v"(c22));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(f1) : "v"(w), "s"(0x22222222u), "v"(c00));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(f2) : "v"(w), "s"(0x44444444u), "v"(c00));
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(f3) : "v"(w), "s"(0x88888888u), "v"(c22));
+    const v8i A = {int(f0), int(f1), int(f2), int(f3), 0, 0, 0, 0};
+    v8i B;
+    for (int q = 0; q < 8; ++q) B[q] = int(b[l * 8 + q]);
+    v4f c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 4, 0, 0, 0x7f7f7f7f, 0, int(sc[l]));
+    for (int r = 0; r < 4; ++r) d[l * 4 + r] = c[r];
+}
+
 // probe: which fp4 element of the A operand meets column k0 of an fp8 B (layout validated by the fp8 x fp8 test)?
 // pattern 0: every fp4 element holds code (e % 8) -> values 0 .5 1 1.5 2 3 4 6; pattern 1: code (e / 8); pattern 2: code kb
 __global__ void probe(int pattern, float* __restrict__ out) {
@@ -191,6 +210,43 @@ int main() {
         printf("{\"part\": \"layout\", \"formats\": \"%s\", \"max_abs_err\": %.4g, \"max_abs_err_if_D_transposed\": %.4g}\n",
                combo == 0 ? "fp8 x fp8" : (combo == 1 ? "fp4 x fp4" : "fp4 x fp8"), maxerr, maxerr_t);
         (void)hipFree(da); (void)hipFree(db); (void)hipFree(dd);
+    }
+    {   // sign bits -> fragments -> MFMA against the host model of the prototype's layout
+        std::vector<uint32_t> wb(64), b(64 * 8, 0);
+        for (auto& v : wb) v = uint32_t(rand()) * 2654435761u + uint32_t(rand());
+        for (int l = 0; l < 64; ++l)
+            for (int e = 0; e < 32; ++e) b[l * 8 + e / 4] |= uint32_t(Bc[((l >> 4) * 32 + e) * 16 + (l & 15)]) << (8 * (e % 4));
+        for (int variant = 0; variant < 3; ++variant) {
+        // scale of B's lane (col, kb): variant 0 all 1.0; 1: per-lane exponents (byte replicated); 2: the same, byte 0 only
+        std::vector<uint32_t> sc(64);
+        std::vector<int> sexp(64, 0);
+        for (int l = 0; l < 64; ++l) { sexp[l] = variant ? (rand() % 7) - 3 : 0; const uint32_t by = uint32_t(127 + sexp[l]); sc[l] = variant == 2 ? by : by * 0x01010101u; }
+        uint32_t *dw, *db, *ds; float* dd;
+        CK(hipMalloc(&dw, 256)); CK(hipMalloc(&db, b.size() * 4)); CK(hipMalloc(&dd, 1024)); CK(hipMalloc(&ds, 256));
+        CK(hipMemcpy(dw, wb.data(), 256, hipMemcpyHostToDevice)); CK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(ds, sc.data(), 256, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(bits_mfma, dim3(1), dim3(64), 0, 0, dw, db, dd, ds);
+        std::vector<float> d(256);
+        CK(hipMemcpy(d.data(), dd, 1024, hipMemcpyDeviceToHost));
+        const float lo_v[4] = {1.f, 0.f, 0.f, 1.f}, hi_v[4] = {1.5f, 1.f, 2.f, -1.f};
+        double maxerr = 0;
+        for (int l = 0; l < 64; ++l)
+            for (int r = 0; r < 4; ++r) {
+                const int col = l & 15, row = 4 * (l >> 4) + r;
+                double ref = 0;
+                for (int kb = 0; kb < 4; ++kb)
+                    for (int bit = 0; bit < 32; ++bit) {
+                        const int n = bit / 4, c = bit % 4, e = 8 * c + n;
+                        const int k = 16 * (4 * (kb & 1) + 2 * (e / 16) + (kb >> 1)) + e % 16;
+                        const float v = ((wb[kb * 16 + row] >> bit) & 1) ? hi_v[c] : lo_v[c];
+                        // which lane's scale applies to B's column-k element: the K block in the 4-bit operand's order (= kb here)
+                        ref += double(v) * fp8_e4m3(Bc[k * 16 + col]) * std::ldexp(1.0, sexp[kb * 16 + col]);
+                    }
+                maxerr = std::fmax(maxerr, std::fabs(ref - d[l * 4 + r]));
+            }
+        printf("{\"part\": \"layout\", \"formats\": \"sign bits -> v_and_or fragments (fp4) x fp8, scale variant %d\", \"max_abs_err\": %.4g}\n", variant, maxerr);
+        (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dd); (void)hipFree(ds);
+        }
     }
     {   // fp4 (A) against fp8 (B): decode the element of A that column k0 of B meets
         float* po; CK(hipMalloc(&po, 3 * 128 * 16 * 4));
