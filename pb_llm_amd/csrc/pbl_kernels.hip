@@ -565,9 +565,12 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_rowmajor_kernel(Proto
     const _Float16* xg = static_cast<const _Float16*>(args.xs[blockIdx.y]);
     const uint8_t* xtg = args.xt[blockIdx.y];
     void* yg = args.ys[blockIdx.y];
-    const uint32_t nwg = (L.NRB + WPB - 1) / WPB;
+#ifndef PBL_PROTO_R
+#define PBL_PROTO_R 1            // records per wave: the workgroup stages x and its terms once for WPB * R consecutive records
+#endif
+    const uint32_t nwg = (L.NRB + WPB * PBL_PROTO_R - 1) / (WPB * PBL_PROTO_R);
     if (blockIdx.x >= nwg) return;
-    const uint32_t rb0 = blockIdx.x * WPB;
+    const uint32_t rb0 = blockIdx.x * WPB * PBL_PROTO_R;
     const int K = int(L.K), P = int(L.P);
     const int Kp = P * PBL_PANEL_COLS;
     const int xstride = Kp + 8;
@@ -581,10 +584,27 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_rowmajor_kernel(Proto
     float* xconst = reinterpret_cast<float*>(scales + size_t(4) * (Kp / 32));   // X, Xb
     float* tmpD = xconst + 4 + wave * 64;                                 // [16 rows][4 terms] per wave
 
-    const uint32_t rb = rb0 + wave;
-    const bool active = rb < L.NRB;
+    {   // stage x (fp16, for the salient gather) and its fp8 terms + scales + constants
+        const int nthr = WPB * PBL_WAVE;
+        const u32x4* src = reinterpret_cast<const u32x4*>(xg);
+        u32x4* dst = reinterpret_cast<u32x4*>(xs);
+        for (int i = tid; i < (K >> 3); i += nthr) dst[i] = src[i];
+        for (int i = K + tid; i < xstride; i += nthr) xs[i] = _Float16(0);
+        const int tbytes = 4 * Kp + 4 * (Kp / 32) + 16;
+        const u32x4* tsrc = reinterpret_cast<const u32x4*>(xtg);
+        u32x4* tdst = reinterpret_cast<u32x4*>(terms);
+#ifndef PBL_PROTO_ABLATE
+#define PBL_PROTO_ABLATE 0      // timing experiment only (wrong results): 1 = do not stage the fp8 terms
+#endif
+        if (!PBL_PROTO_ABLATE) for (int i = tid; i < (tbytes >> 4); i += nthr) tdst[i] = tsrc[i];
+    }
+    __syncthreads();
+    for (int it = 0; it < PBL_PROTO_R; ++it) {
+    const uint32_t rb = rb0 + uint32_t(it) * WPB + wave;
+    if (rb >= L.NRB) break;
+    const bool active = true;
     const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
-    const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[active ? rb : rb0];
+    const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[rb];
     const uint8_t* rec = blob + size_t(__builtin_amdgcn_readfirstlane(info.x)) * 16;
     const int nfull = __builtin_amdgcn_readfirstlane(info.y);
     const int ntail = __builtin_amdgcn_readfirstlane(info.z);
@@ -615,19 +635,6 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_rowmajor_kernel(Proto
             s_q4 = __builtin_nontemporal_load(codep + cc);
         }
     };
-    {   // stage x (fp16, for the salient gather) and its fp8 terms + scales + constants
-        const int nthr = WPB * PBL_WAVE;
-        const u32x4* src = reinterpret_cast<const u32x4*>(xg);
-        u32x4* dst = reinterpret_cast<u32x4*>(xs);
-        for (int i = tid; i < (K >> 3); i += nthr) dst[i] = src[i];
-        for (int i = K + tid; i < xstride; i += nthr) xs[i] = _Float16(0);
-        const int tbytes = 4 * Kp + 4 * (Kp / 32) + 16;
-        const u32x4* tsrc = reinterpret_cast<const u32x4*>(xtg);
-        u32x4* tdst = reinterpret_cast<u32x4*>(terms);
-        for (int i = tid; i < (tbytes >> 4); i += nthr) tdst[i] = tsrc[i];
-    }
-    __syncthreads();
-    if (!active) return;
 
     // ---- phase 1: sign plane on the matrix cores ------------------------------------------------------------------
     const int tok = lane & 15, kb = lane >> 4;
@@ -744,6 +751,9 @@ __global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_rowmajor_kernel(Proto
         if (args.y_f32) static_cast<float*>(yg)[row] = yv;
         else static_cast<_Float16*>(yg)[row] = _Float16(yv);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next record reuses this wave's partials and tmpD
+    __builtin_amdgcn_wave_barrier();
+    }   // records of this wave
 }
 #endif  // PBL_PROTO_ROWMAJOR
 
@@ -1425,7 +1435,7 @@ int pbl_proto_gemv_rowmajor(const pbl_layer* layers_dev, const void* const* x_de
     const void* k = wpb == 8 ? reinterpret_cast<const void*>(pbl_gemv_rowmajor_kernel<8>) : reinterpret_cast<const void*>(pbl_gemv_rowmajor_kernel<4>);
     if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) return PBL_ERR_LAUNCH;
     void* argv[] = {&a};
-    return hipLaunchKernel(k, dim3((max_NRB + wpb - 1) / wpb, Lc), dim3(wpb * PBL_WAVE), argv, lds, static_cast<hipStream_t>(stream)) == hipSuccess
+    return hipLaunchKernel(k, dim3((max_NRB + wpb * PBL_PROTO_R - 1) / (wpb * PBL_PROTO_R), Lc), dim3(wpb * PBL_WAVE), argv, lds, static_cast<hipStream_t>(stream)) == hipSuccess
                ? PBL_OK : PBL_ERR_LAUNCH;
 }
 #endif
