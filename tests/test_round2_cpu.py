@@ -188,3 +188,44 @@ def test_forward_routing_decisions_without_a_gpu():
     grp = layer(4096, 4096, 0.1, G=32)
     assert ws(grp, 2) == 0 and ws(grp, 3) > 0                 # column groups: two tokens per GEMV pass
     assert ws(layer(4096, 4096, 0.1, flags=0x4), 32) == 0     # a version-1 style blob without the slab index
+
+
+def test_fp16_checkpoint_entries_must_be_recognisable_in_the_kernel_tile():
+    """The matrix-core kernels keep fl16((-scale) (q - zero)) in their tile and tell entries from empty positions by "any bit
+    set" (pbl_host.cpp: sal16_storable).  The packer therefore codes a zero-valued salient only with a code whose negated
+    product is -0 (or a negative underflow), never +0; rows with scale 0 keep their salients as exceptions; and
+    pbl_blob_describe rejects a blob in which such an entry was forged."""
+    N, K = 16, 512
+    W = np.full((N, K), 0.5, np.float32)
+    W[:, 1::2] = -0.5
+    hi, lo = np.full(N, 0.5, np.float32), np.full(N, -0.5, np.float32)
+    ss, sz = np.full(N, 0.25, np.float32), np.full(N, 4.0, np.float32)
+    sal = np.zeros((N, K), np.uint8)
+    ss[1], sz[1] = 1e-9, 5.3            # every product underflows to +-0 in fp16; the zero point is no integer
+    ss[2] = 0.0                         # degenerate quantizer: nothing can be coded
+    for r in (0, 1, 2):
+        W[r, 40], W[r, 41] = 0.0, 0.0
+        sal[r, 40] = sal[r, 41] = 1
+    p = pack_dense(W, hi, lo, ss, sz, sal, sal_f16=True)
+    np.testing.assert_array_equal(F.decode(p.blob.numpy()), W)                  # exact either way
+    assert p.nexc == 2 and p.nnz == 4                                           # row 2: exceptions; rows 0, 1: coded
+    # the codes chosen for row 1 sit ABOVE the zero point (negated product negative -> -0), never below it
+    blob = p.blob.numpy().copy()
+    h = F.read_header(blob)
+    rb = blob[h["rb_off_pos"]: h["rb_off_pos"] + 32].view(np.uint32).reshape(2, 4)
+    off = int(rb[0, 0]) * 16
+    nfull, ntail = int(rb[0, 1]), int(rb[0, 2])
+    nch = nfull + ntail
+    sal_off = off + 512 + h["P"] * 1024
+    a128 = lambda v: (v + 127) & ~127                                           # noqa: E731  (PBL_SAL_*_OFF of include/pbl.h)
+    code_off = sal_off + a128(2 * nch) + a128(16 * nch)
+    codes = blob[code_off: code_off + 16 * nch].reshape(nch, 16)
+    crow_off = code_off + a128(16 * nch) + ((ntail + 15) & ~15)
+    crow = blob[crow_off: crow_off + nch]
+    row1 = [int(c) for ch in range(nch) if crow[ch] == 1 for c in codes[ch][:2]]
+    assert row1 and all(c >= 6 for c in row1), row1
+    # forge: move row 1's first code below the zero point -> its negated product would be +0
+    ch1 = int(np.flatnonzero(crow == 1)[0])
+    blob[code_off + 16 * ch1] = 5
+    layer = _lib.PblLayer()
+    assert _lib.lib().pbl_blob_describe(blob.ctypes.data, blob.size, C.byref(layer)) == _lib.PBL_ERR_BAD_BLOB
