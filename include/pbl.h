@@ -150,7 +150,7 @@ typedef enum {
  *   out_features N <= 2^24
  *   column groups: K % G == 0 and K / G a multiple of 128; the kernels additionally want K / G a power of two
  *   tokens per GEMV pass <= PBL_MAX_TOKENS_PER_LAUNCH (pbl_linear_f16 loops / routes to the matrix-core kernel beyond)
- *   matrix-core kernels: K % 8 == 0, x 16-byte aligned, <= 32 tokens per pass; GEMM-regime kernel: fp16-checkpoint layers, G == 1
+ *   matrix-core kernels: K % 8 == 0, x 16-byte aligned, <= 32 tokens per pass; GEMM-regime kernel: K % 8 == 0, groups of a multiple of 128 columns
  *   pbl_quant8_rows: K <= 16384 (prep.py falls back to the torch path above)
  */
 typedef struct {
@@ -292,14 +292,20 @@ int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, 
                          int L, int M, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch,
                          uint32_t max_nexc, int group_flags, int y_f32, void* stream);
 
-/* GEMM regime (M > 32 tokens: prefill, large batches) straight from the packed format: y[M,N] (fp16) = x[M,K] (fp16) @
- * W^T + bias with fp32 accumulation, for layers whose every weight is an fp16 number (PBL_FLAG_SAL_F16: packed from an
- * fp16 checkpoint; G == 1, K % 8 == 0, x and y 16-B aligned; else PBL_ERR_UNSUPPORTED and the caller falls back to
- * pbl_unpack_dev + a library GEMM).  A workgroup rebuilds the exact fp16 weight tile of 8 records x 128 columns in LDS
- * (sign plane through v_perm_b32, salients through the slab index) while the previous tile is multiplied with
- * v_mfma_f32_16x16x32_f16 against 256 tokens of x staged in LDS (csrc/pbl_gemm_big.hip); the dense weight never exists
- * in HBM.  Replaces nn.Linear over the dense fake-quant checkpoint at seq 2048 (gptq_pb/eval_ppl_utils.py:55-64). */
-int pbl_gemm_f16(const pbl_layer* layer, const void* x, void* y, int M, void* stream);
+/* GEMM regime (M > 32 tokens: prefill, large batches) straight from the packed format: y[M,N] = x[M,K] (fp16) @ W^T + bias
+ * with fp32 accumulation, y fp16 (y_f32 == 0) or fp32.  Every weight enters the contraction as the fp16 number
+ * pbl_unpack_dev(.., out_f32 = 0) would produce for it -- the row(-group)'s level, the fp16-rounded salient value, the
+ * exception value -- so the result is the one of a library fp16 GEMM on the unpacked layer up to summation order; exact
+ * weights for layers packed from an fp16 checkpoint (PBL_FLAG_SAL_F16).  Any layer with K % 8 == 0, PBL_FLAG_SLABS |
+ * PBL_FLAG_TAIL_REPEAT and column groups (if any) of a multiple of 128 columns; x and y 16-B aligned; otherwise
+ * PBL_ERR_UNSUPPORTED and the caller falls back to pbl_unpack_dev + a library GEMM.  A workgroup of 8 waves owns 8 records
+ * x 256 tokens: 4 producer waves rebuild the fp16 weight tile of the next 128 columns in LDS (sign plane through
+ * v_pk_mad_u16, salients through the slab index) while 4 consumer waves multiply the previous one with
+ * v_mfma_f32_32x32x16_f16 against x, which each consumer stages for its own 64 tokens by LDS-DMA
+ * (csrc/pbl_gemm_big.hip); the dense weight never exists in HBM.  Replaces nn.Linear over the dense fake-quant checkpoint
+ * at seq 2048 (gptq_pb/eval_ppl_utils.py:55-64, evaluate.py:126-145). */
+int pbl_gemm_f16_ex(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream);
+int pbl_gemm_f16(const pbl_layer* layer, const void* x, void* y, int M, void* stream);   /* = pbl_gemm_f16_ex(.., 0, ..) */
 
 /* Decode-time FUSED projections (q/k/v, gate/up: layers that read the same activation): L layers, ONE x [M, K] (fp16,
  * 16-B aligned rows are not required), ONE output matrix y [M, ldy] in which layer l owns the columns

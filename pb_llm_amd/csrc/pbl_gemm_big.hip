@@ -1,103 +1,133 @@
 // pbl_gemm_big.hip -- GEMM regime (more than 32 tokens: prefill, large batches) straight from the PBL1 packed format.
-// Replaces F.linear(x, W_fq, b) over the dense fp16 fake-quant weight (gptq_pb/eval_ppl_utils.py:55-64: the reference's
-// perplexity loop calls every nn.Linear with seq 2048 rows) WITHOUT the dense weight ever existing in HBM: round 1
-// unpacked the layer into a transient workspace and ran a library GEMM on it.
+// Replaces F.linear(x, W_fq, b) over the dense fp16 fake-quant weight (gptq_pb/eval_ppl_utils.py:55-64 and
+// evaluate.py:126-145: the reference's perplexity loops call every nn.Linear with seq 2048 rows) WITHOUT the dense weight
+// ever existing in HBM.
 //
-// For layers packed from an fp16 checkpoint (PBL_FLAG_SAL_F16, G == 1): every weight is an fp16 number -- one of the
-// row's two levels, the double-rounded fp16 salient value, or an explicit exception -- so the kernel rebuilds the EXACT
-// fp16 weight tile in LDS and feeds it to v_mfma_f32_16x16x32_f16.  The arithmetic is that of an fp16 GEMM with fp32
-// accumulation on the reference's own dense weight.
+// Every weight is rebuilt in LDS as the fp16 number a dense fp16 copy of the layer would hold -- one of the row's
+// (row-group's) two levels, the fp16-rounded salient value, or an explicit exception -- and fed to
+// v_mfma_f32_32x32x16_f16: the arithmetic is that of an fp16 GEMM with fp32 accumulation on pbl_unpack_dev's output, for
+// every layer kind (fp16-checkpoint and fp32-grid layers, with or without column groups; fp16 or fp32 result).
 //
-// Workgroup = 16 waves, SPECIALISED: 8 consumer waves that only read LDS and issue MFMAs, 8 producer waves that only
-// fetch and expand.  (A first version let every wave expand its own record between its MFMAs: 545 TFLOP/s -- every wave
-// waited half of the time, profiles/r02b, while the MFMA loop by itself ran at 1.24 PFLOP/s; so that loop gets waves of
-// its own.  4 producers could not keep up: ~450 instructions per sub-step each.)
-// Tile: 8 records (128 output rows) x 256 tokens; K is walked in half slabs of 128 columns = 2 sub-steps of 64.
-//   A operand  As[2][128 rows][128 + 8] fp16 (double buffered).  Producer p expands record p of the NEXT half slab: the
-//              sign plane in the even sub-step, the salients in the odd one.  Sign plane -- per (row, dword) shift / and /
-//              mad build a v_perm_b32 selector
-//              that picks {hi, lo} for two columns, one ds_write_b32 stores them; salient chunks of the slab through the
-//              packer's slab index, FOUR LANES PER CHUNK (4 entries each: short dependent chains, no idle lanes at low
-//              density; the lane's first column is col0 + a v_sad_u8 byte sum of the preceding deltas); exceptions last.
-//   B operand  Xs[2][256 tokens][64] fp16, XOR-swizzled 16-byte units (conflict-free b128 fragment reads without
-//              padding): the 512 producer threads keep sub-step u+1 in registers (requested a sub-step earlier), write it
-//              at the start of sub-step u and request u+2.
-//   MFMA       consumers as 2 (rows) x 4 (tokens): a wave owns 64 rows x 64 tokens = 16 accumulator tiles; per 32-column
-//              k-step 4 A + 4 B fragment reads feed 16 MFMAs.  No global memory access in their loop.
-//   Sync       one workgroup barrier per sub-step; a buffer is written in the sub-step(s) after its last readers have
-//              passed a barrier and read after the writers have passed the next one.
-//   Epilogue   accumulators -> LDS [token][row] -> contiguous 16-byte stores by all 1024 threads.
+// Round 3 rebuild (round 2's kernel: 16 waves, x through registers + ds_write, 4x4 accumulator tiles per wave: 570 TFLOP/s,
+// LDS ~90 % busy, producers' ~250 VALU per sub-step next to the MFMA waves).  What changed and why:
+//   * Workgroup = 8 waves, SPECIALISED, one consumer + one producer per SIMD.  Tile = 8 records (128 rows) x 256 tokens.
+//   * Consumer wave c owns ALL 128 rows x tokens [64 c, 64 c + 64): 8 accumulator tiles of 32 x 32 (128 registers).  Per
+//     64-column sub-step it reads 16 A + 8 B fragments (ds_read_b128) for 32 MFMAs: 96 KB of LDS reads per sub-step and
+//     workgroup instead of 128 KB, and the A tile is read by 4 waves instead of 8.
+//   * x never passes through a VGPR or a ds_write: each consumer stages the 64 tokens ONLY IT reads with
+//     buffer_load_dwordx4 ... lds (LDS-DMA, 8 x 1 KiB per sub-step, whole 128-byte lines) into a PRIVATE ring of three
+//     8 KiB slots; no other wave touches them, so x needs no workgroup barrier at all -- a counted vmcnt and the wave's own
+//     lgkmcnt order it.  The LDS image is lane-linear (the DMA's rule), the XOR swizzle that makes the b128 fragment reads
+//     conflict-free is applied to the SOURCE address.  Out-of-range tokens read zeros through the buffer descriptor.
+//   * Producer wave p expands records 2p, 2p+1 of the next 128-column half slab into As[2][128][128] fp16 (XOR-swizzled
+//     16-byte units, no padding).  Sign plane: (d >> pos) & 0x00010001 puts the bits of two columns into the two halves,
+//     ONE v_pk_mad_u16 with op_sel turns them into {hi, lo} bit patterns (lo + bit * (hi - lo) mod 2^16; the row's
+//     (hi - lo : lo) pair sits in one SGPR), one XOR forms the swizzled address: 4 VALU per weight pair and ds_write_b32,
+//     all 64 lanes busy.  Salients: the packer's slab index, four lanes per chunk, entries outside the half slab masked off.
+//   * Sync: ONE workgroup barrier per half slab (2 sub-steps).  Consumers pass it right after their last fragment read of
+//     the stage was issued and has returned, i.e. one k-step BEFORE the stage's last MFMAs, so those MFMAs cover the first
+//     fragment reads of the next stage; producers pass it when the next stage is complete and then have a whole half slab
+//     of time for the one after.
+//   * Epilogue per consumer wave through its own (now idle) ring: accumulators (+ bias) -> [token][row] -> 16-byte stores.
+// LDS: 2 x 32 KiB (A) + 4 x 24 KiB (x rings) = 160 KiB: one workgroup per CU, by design.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/pbl.h"
 
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #define GW 64
-#define NCONS 8                   // consumer (MFMA) waves
-#define NPROD 8                   // producer (expand + stage) waves, one record each
+#define NCONS 4                   // consumer (MFMA) waves: 64 tokens each
+#define NPROD 4                   // producer (expand) waves: 2 records each
 #define NREC 8                    // records per workgroup tile
 #define GB_ROWS (NREC * 16)
 #define GB_TOK 256
-#define GB_HS 128                 // columns per As buffer (half a slab)
-#define GB_ASTR (GB_HS + 8)       // halves per As row: 272 B, the 16 row-lanes of a b128 read hit distinct banks
-#define GB_XC 64                  // columns per x sub-step
-#define GB_AS_BYTES (size_t(GB_ROWS) * GB_ASTR * 2)
-#define GB_XS_BYTES (size_t(GB_TOK) * GB_XC * 2)
-#define GB_LDS (2 * GB_AS_BYTES + 2 * GB_XS_BYTES)
+#define GB_HS 128                 // columns per A stage (half a slab)
+#define GB_XC 64                  // columns per x slot (sub-step)
+#define GB_XSLOTS 3
+#define GB_AS_STAGE (GB_ROWS * GB_HS * 2)          // 32768 B
+#define GB_XSLOT_BYTES (64 * GB_XC * 2)            // 8192 B: 64 tokens x 64 columns
+#define GB_XRING_BYTES (GB_XSLOTS * GB_XSLOT_BYTES)
+#define GB_X_OFF (2 * GB_AS_STAGE)
+#define GB_LDS (GB_X_OFF + NCONS * GB_XRING_BYTES)  // 163840 B
 // performance-analysis hook (tools/build_variant.sh): bit 0 no expansion in the loop, 1 no x staging in the loop, 2 no MFMA,
-// 3 no sign-plane expansion, 4 no salient overlay.
-// 0 in every shipped build (results are wrong otherwise).
+// 3 no sign-plane expansion, 4 no salient overlay, 5 producers request nothing either (consumer loop alone).  0 in every
+// shipped build (results are wrong otherwise).
 #ifndef PBL_GEMM_ABLATE
 #define PBL_GEMM_ABLATE 0
+#endif
+// consumers at raised wave priority (measured variants: tools/build_variant.sh)
+#ifndef PBL_GEMM_PRIO
+#define PBL_GEMM_PRIO 0
 #endif
 
 namespace {
 
 __device__ __forceinline__ _Float16 round_f16_twice(float prod) {
-    asm volatile("" : "+v"(prod));   // keep the fp32 product: the checkpoint value is double rounded
+    asm volatile("" : "+v"(prod));   // keep the fp32 product: an fp16-checkpoint value is double rounded
     return _Float16(prod);
 }
+__device__ __forceinline__ uint32_t h16(float v) { return uint32_t(__builtin_bit_cast(uint16_t, _Float16(v))); }
 
 struct GemmArgs {
     pbl_layer L;
     const _Float16* x;      // [M, K]
-    _Float16* y;            // [M, N]
-    int M;
+    void* y;                // [M, N] fp16 / fp32
+    int M, y_f32;
 };
 
 struct Seq { int fb, fn, tb, tn; };            // the row's full / tail chunks that overlap a slab: first index, count
 
-// a quarter of a salient chunk as one lane holds it: all 16 byte steps (for the prefix), its 4 codes, the first column
+// a quarter of a salient chunk as one lane holds it: as requested (all 16 byte steps for the prefix, its 4 codes, the first
+// column) and as the expansion uses it (its own 4 byte steps, its 4 codes, the byte offset of its first entry minus the step)
 struct ChunkQ {
     u32x4 d4;
     uint32_t q;
     int col0;               // < 0: no chunk
 };
+struct QuarterQ {
+    uint32_t dd, q, off0;   // off0: byte offset in a 2 K-byte fp16 row of the entry BEFORE this quarter's first (0x40000000: no chunk)
+};
 
-// Everything a producer wave keeps per record it expands (two of these per wave).
+#define GB_PRE 4            // chunk rounds of a slab kept in registers (more rounds are fetched when they are needed: rare)
+
+// the chunks of one record that overlap one 256-column slab, as a producer lane holds them
+struct SlabData {
+    Seq sq;
+    ChunkQ c[GB_PRE];
+};
+struct SlabReady {          // the same slab once its requests have landed: 3 registers per round instead of 6
+    Seq sq;
+    QuarterQ c[GB_PRE];
+};
+
+// Everything a producer wave keeps per record (two of these per wave).  Data for the expansion two stages ahead is
+// requested right after a stage has been written: by the time it is needed a whole consumer half slab has passed.
 struct Rec {
-    const uint8_t* rec;     // record base
     const uint16_t* col0p;
     const u32x4* deltap;
     const uint32_t* codew;  // codes as dwords: chunk c, quarter s at [4 c + s]
     const uint2* exc;
-    const uint32_t* tabrow; // slab-index row of this lane's row
+    const float2* ghl;      // G > 1: per (row, group) levels
+    const uint32_t* tabrow; // slab-index row of this lane's row (lane >> 2)
     const uint32_t* tile_dw;
-    int nfull, nexc, NS, P;
+    const pbl_rowparams* params;
+    int nfull, nexc;
     pbl_rowinfo ri;         // this lane's row (lane >> 2)
     float ss, sz;           // ... and its code grid
-    uint32_t hilo_lane;     // lane (r & 15): fp16 {hi : lo} of row r
-    uint32_t e0, e1, e2;    // slab-index entries of slabs s, s+1, s+2 (s = the slab of the next expansion)
-    Seq sq;
-    ChunkQ c0, c1;          // rounds 0 and 1 of the slab of the next expansion
+    uint32_t tp, tc, tn;    // slab-index entries of slabs s - 1, s, s + 1, s = the next slab to be requested
+    SlabReady sd;           // the slab being expanded
+    SlabData sdn;           // the next one (requested 1.5 slabs ahead)
     uint32_t dcur, dnxt;    // sign-plane dwords of the next expansion and the one after
+    uint32_t hl[16];        // wave uniform: (hi - lo) mod 2^16 : lo, fp16 bit patterns, of the 16 rows (current column group)
 };
 
-__device__ __forceinline__ uint32_t tab_at(const Rec& R, int s) { return (s >= 0 && s < R.NS) ? R.tabrow[s] : 0u; }
 __device__ __forceinline__ Seq seq_of(uint32_t pe, uint32_t e) {
     Seq q;
     q.fb = int(PBL_SLAB_FE(pe)) - int(PBL_SLAB_FBACK(e)); q.fn = int(PBL_SLAB_FE(e)) - q.fb;
@@ -105,7 +135,7 @@ __device__ __forceinline__ Seq seq_of(uint32_t pe, uint32_t e) {
     return q;
 }
 // round j of the row's slab sequence (its full chunks, then its tail chunks): the same chunk for the 4 lanes of a row
-__device__ __forceinline__ ChunkQ load_chunkq(const Rec& R, int j, const Seq& sq, int sub) {
+__device__ __forceinline__ ChunkQ load_chunkq(const Rec& R, const Seq& sq, int j, int sub) {
     ChunkQ r;
     r.col0 = -1; r.d4 = u32x4{0, 0, 0, 0}; r.q = 0;
     int c = -1;
@@ -114,117 +144,164 @@ __device__ __forceinline__ ChunkQ load_chunkq(const Rec& R, int j, const Seq& sq
     if (c >= 0) { r.d4 = R.deltap[c]; r.q = R.codew[4 * c + sub]; r.col0 = int(R.col0p[c]); }
     return r;
 }
-__device__ __forceinline__ uint32_t load_dw(const Rec& R, int h) {      // dword (h & 3) of panel h >> 2 for this lane
-    return (h >> 2) < R.P ? __builtin_nontemporal_load(R.tile_dw + size_t(h >> 2) * 256 + (h & 3)) : 0u;
+__device__ __forceinline__ uint32_t load_dw(const Rec& R, int h, int P) {      // dword (h & 3) of panel h >> 2 for this lane
+    return (h >> 2) < P ? __builtin_nontemporal_load(R.tile_dw + size_t(h >> 2) * 256 + (h & 3)) : 0u;
+}
+// request the chunks of slab sn (its first GB_PRE rounds); the slab-index entry of the slab after it rides along
+__device__ __forceinline__ void request_slab(Rec& R, SlabData& d, int sn, int NS, int sub) {
+    d.sq = seq_of(R.tp, R.tc);                                   // (entries read a slab earlier: no dependent wait here)
+    if (sn >= NS) { d.sq.fn = 0; d.sq.tn = 0; }
+#pragma unroll
+    for (int j = 0; j < GB_PRE; ++j) d.c[j] = load_chunkq(R, d.sq, j, sub);
+    R.tp = R.tc; R.tc = R.tn;
+    R.tn = sn + 2 < NS ? R.tabrow[sn + 2] : 0u;
+}
+// the 16 level pairs of column group g as (hi - lo : lo) bit patterns in SGPRs
+__device__ __forceinline__ void load_levels(Rec& R, uint32_t G, uint32_t g, int lane) {
+    float hi, lo;
+    if (G > 1) { const float2 v = R.ghl[size_t(lane & 15) * G + g]; hi = v.x; lo = v.y; }
+    else { const pbl_rowparams pr = R.params[lane & 15]; hi = pr.hi; lo = pr.lo; }
+    const uint32_t hh = h16(hi), ll = h16(lo);
+    const uint32_t w = (((hh - ll) & 0xFFFFu) << 16) | ll;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R.hl[r] = __builtin_amdgcn_readlane(w, r);
 }
 
-// entries 4 sub .. 4 sub + 3 of one chunk -> the tile row (byte address arow_b), half slab starting at column cb.
-// Tail padding repeats the last entry (PBL_FLAG_TAIL_REPEAT), so a writer needs no count.
-__device__ __forceinline__ void scatter_q(const ChunkQ& c, int cb, int sub, uint32_t pad_b, char* arow_b, float ss, float sz) {
-    if (c.col0 < 0) return;
+// ds_write_b16 of the lanes whose byte offset lies inside the row.  Plain C++ (`if (off < 256) store`) compiles to the same
+// compare / saveexec / store / restore PLUS a branch over the store (LLVM skips DS instructions under an empty EXEC), and that
+// branch ends the basic block: one producer wave then runs every entry's dependent chain in sequence.  Without the branch the
+// whole overlay of a record is one block and the compiler interleaves the chains of all its entries.
+__device__ __forceinline__ void lds_store_b16_inrow(uint32_t addr, uint32_t val, uint32_t off) {
+    uint64_t sv;
+    asm volatile("v_cmp_gt_u32_e32 vcc, 0x100, %1\n\ts_and_saveexec_b64 %0, vcc\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(sv) : "v"(off), "v"(addr), "v"(val) : "vcc", "memory");
+}
+
+// what a lane needs of its chunk quarter, computed ONCE per slab (both half slabs use it): its own four byte steps and the
+// byte offset (in the whole fp16 row) its running sum starts from
+__device__ __forceinline__ QuarterQ finalize_q(const ChunkQ& c, int sub) {
     // byte sum of the deltas that precede this quarter (deltas are stored doubled = byte steps in an fp16 row)
     uint32_t pre = 0;
     pre = sub > 0 ? __builtin_amdgcn_sad_u8(c.d4[0], 0u, pre) : pre;
     pre = sub > 1 ? __builtin_amdgcn_sad_u8(c.d4[1], 0u, pre) : pre;
     pre = sub > 2 ? __builtin_amdgcn_sad_u8(c.d4[2], 0u, pre) : pre;
-    const uint32_t dd = sub == 0 ? c.d4[0] : (sub == 1 ? c.d4[1] : (sub == 2 ? c.d4[2] : c.d4[3]));
-    uint32_t off = uint32_t(2 * (c.col0 - cb)) + pre;          // byte offset in the row; wraps for entries left of the slab
+    // this quarter's four steps, picked with lane masks (a ?: chain compiles to divergent branches that end the basic block)
+    const uint32_t m0 = sub == 0 ? ~0u : 0u, m1 = sub == 1 ? ~0u : 0u, m2 = sub == 2 ? ~0u : 0u, m3 = sub == 3 ? ~0u : 0u;
+    QuarterQ r;
+    r.dd = (c.d4[0] & m0) | (c.d4[1] & m1) | (c.d4[2] & m2) | (c.d4[3] & m3);
+    r.q = c.q;
+    r.off0 = c.col0 < 0 ? 0x40000000u : uint32_t(2 * c.col0) + pre;
+    return r;
+}
+
+// entries 4 sub .. 4 sub + 3 of one chunk -> the tile row at LDS byte address rowaddr (a multiple of 256), half slab
+// starting at byte cb2 of the fp16 row.  Tail padding repeats the last entry (PBL_FLAG_TAIL_REPEAT): a writer needs no count.
+__device__ __forceinline__ void scatter_q(const QuarterQ& c, uint32_t cb2, uint32_t rowaddr, uint32_t swz, float ss, float sz) {
+    uint32_t off = c.off0 - cb2;        // wraps (>= 256) for entries left of the half slab; "no chunk" stays far out of range
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        off += (dd >> (8 * e)) & 0xFFu;
-        const uint32_t o = min(off, pad_b);                     // outside the half slab: one of the row's pad columns
+        off += (c.dd >> (8 * e)) & 0xFFu;
         const float qf = float((c.q >> (8 * e)) & 0xFFu);
-        *reinterpret_cast<uint16_t*>(arow_b + o) = __builtin_bit_cast(uint16_t, round_f16_twice(ss * (qf - sz)));
+        const uint32_t v = uint32_t(__builtin_bit_cast(uint16_t, round_f16_twice(ss * (qf - sz))));
+        lds_store_b16_inrow((off ^ swz) + rowaddr, v, off);
     }
 }
 
-// sign plane of half slab h (columns 128 h ..) of record R -> rows 16 slot .. of As[buf]: every column of the 16 rows
-__device__ __forceinline__ void expand_sign(Rec& R, const uint32_t (&hl)[16], _Float16* As, int buf, int slot, int lane) {
+// sign plane of one half slab of record R -> rows of the stage at LDS byte address recaddr (a multiple of 4096): lane l
+// holds columns 2l, 2l+1 of all 16 rows in ONE dword (include/pbl.h: bit 16 e + pos)
+template <bool TAIL>
+__device__ __forceinline__ void expand_sign(const Rec& R, char* smem, uint32_t recaddr, int lane, int kpairs /* valid column pairs */) {
     const uint32_t d = R.dcur;
-    uint32_t* base = reinterpret_cast<uint32_t*>(As + (size_t(buf) * GB_ROWS + slot * 16) * GB_ASTR) + lane;   // columns 2 lane, 2 lane + 1
+    // unit (l >> 2) ^ row, dword l & 3:  recaddr + 256 row + (((l >> 2) ^ row) << 4) + 4 (l & 3)  ==  v ^ (0x110 row)
+    const uint32_t v = recaddr + (uint32_t(lane >> 2) << 4) + (uint32_t(lane & 3) << 2);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int pos = r < 8 ? r + 8 : r - 8;
         const uint32_t m = (d >> pos) & 0x00010001u;
-        const uint32_t sel = m * 0x0202u + 0x01000100u;         // per half: bytes {1,0} (lo) or {3,2} (hi)
-        base[r * (GB_ASTR / 2)] = __builtin_amdgcn_perm(hl[r], hl[r], sel);
+        uint32_t val;
+        // per half: lo + bit * (hi - lo)  (mod 2^16): src1 = the pair's high half, src2 = its low half, for both lanes
+        asm("v_pk_mad_u16 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(val) : "v"(m), "s"(R.hl[r]));
+        if (TAIL && lane >= kpairs) val = 0;                          // columns beyond K (only the layer's last half slab)
+        *reinterpret_cast<uint32_t*>(smem + (v ^ uint32_t(0x110 * r))) = val;
     }
     asm volatile("" ::: "memory");
 }
 
-// Loads for the expansion of half slab hn and later, issued at the START of the even sub-step (right after x went to LDS
-// and BEFORE the next x request): vmcnt retires in order and hipcc waits vmcnt(0) in front of the LDS store of x, so a load
-// issued after an x request would put its whole latency into the next sub-step's critical path.
-__device__ __forceinline__ void prefetch_for(Rec& R, int hn, int sub) {
-    R.dcur = R.dnxt;                                            // (landed a half slab ago)
-    R.dnxt = load_dw(R, hn + 1);
-    if (!(hn & 1)) {                                            // hn opens slab hn / 2: its chunks (first used one sub-step from now)
-        const int sn = hn >> 1;
-        if (sn < R.NS) {
-            R.sq = seq_of(R.e0, R.e1);
-            R.c0 = load_chunkq(R, 0, R.sq, sub);
-            R.c1 = load_chunkq(R, 1, R.sq, sub);
-        }
-        R.e0 = R.e1; R.e1 = R.e2; R.e2 = tab_at(R, sn + 2);
-    }
-}
-
-// salients + exceptions of half slab h over the plane written one sub-step earlier
-__device__ __forceinline__ void expand_sal(Rec& R, int h, _Float16* As, int buf, int slot, int lane) {
-    const int cb = h * GB_HS, rho = lane >> 2, sub = lane & 3;
-    char* arow_b = reinterpret_cast<char*>(As + (size_t(buf) * GB_ROWS + slot * 16 + rho) * GB_ASTR);
-    const uint32_t pad_b = uint32_t(2 * (GB_HS + (lane & 7)));
-    scatter_q(R.c0, cb, sub, pad_b, arow_b, R.ss, R.sz);        // rounds 0 and 1 were loaded a half slab ahead
-    scatter_q(R.c1, cb, sub, pad_b, arow_b, R.ss, R.sz);
-    {
-        const int n = R.sq.fn + R.sq.tn;
-        for (int j = 2; __any(j < n); ++j) scatter_q(load_chunkq(R, j, R.sq, sub), cb, sub, pad_b, arow_b, R.ss, R.sz);
-    }
+// salients + exceptions of half slab h of record R over the plane the same wave has just written (LDS keeps a wave's
+// accesses in order)
+__device__ __forceinline__ void expand_sal(Rec& R, int h, char* smem, uint32_t recaddr, int lane) {
+    const int rho = lane >> 2, sub = lane & 3;
+    const uint32_t cb2 = uint32_t(h) * (2 * GB_HS);
+    const uint32_t rowaddr = recaddr + uint32_t(rho) * 256u, swz = uint32_t(rho) << 4;
+    const int n = R.sd.sq.fn + R.sd.sq.tn;
+    // a round is skipped when NO row of the record has a chunk in it (wave uniform): at 5 % salients most slabs need 2 rounds
+#pragma unroll
+    for (int j = 0; j < GB_PRE; ++j)
+        if (__any(j < n)) scatter_q(R.sd.c[j], cb2, rowaddr, swz, R.ss, R.sz);
+    for (int j = GB_PRE; __any(j < n); ++j)
+        scatter_q(finalize_q(load_chunkq(R, R.sd.sq, j, sub), sub), cb2, rowaddr, swz, R.ss, R.sz);
     asm volatile("" ::: "memory");
     for (int k = lane; k < R.nexc; k += GW) {                   // explicit values last
         const uint2 ex = R.exc[k];
-        const uint32_t col = (ex.x & 0xFFFFu) - uint32_t(cb);
+        const uint32_t col = (ex.x & 0xFFFFu) - uint32_t(h * GB_HS), row = ex.x >> 16;
         if (col < uint32_t(GB_HS))
-            reinterpret_cast<uint16_t*>(As + (size_t(buf) * GB_ROWS + slot * 16 + (ex.x >> 16)) * GB_ASTR)[col] =
+            *reinterpret_cast<uint16_t*>(smem + recaddr + row * 256u + ((2u * col) ^ (row << 4))) =
                 __builtin_bit_cast(uint16_t, _Float16(__builtin_bit_cast(float, ex.y)));
     }
     asm volatile("" ::: "memory");
 }
 
+// the requested slab becomes the current one (its loads were issued 1.5 slabs ago)
+__device__ __forceinline__ void adopt_slab(Rec& R, int sub) {
+    R.sd.sq = R.sdn.sq;
+#pragma unroll
+    for (int j = 0; j < GB_PRE; ++j) R.sd.c[j] = finalize_q(R.sdn.c[j], sub);
+}
+
 __device__ __forceinline__ void init_rec(Rec& R, const pbl_layer& L, uint32_t rb, int lane) {
     const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
     const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[rb];
-    R.rec = blob + size_t(__builtin_amdgcn_readfirstlane(info.x)) * 16;
+    const uint8_t* rec = blob + size_t(__builtin_amdgcn_readfirstlane(info.x)) * 16;
     R.nfull = __builtin_amdgcn_readfirstlane(info.y);
     const int ntail = __builtin_amdgcn_readfirstlane(info.z);
     R.nexc = __builtin_amdgcn_readfirstlane(info.w);
     const uint32_t nchu = uint32_t(R.nfull + ntail);
-    R.P = int(L.P);
-    R.NS = int((L.K + PBL_SLAB_COLS - 1) / PBL_SLAB_COLS);
-    const uint32_t tiles_off = PBL_TILES_OFF(1u);
-    const uint8_t* sal = R.rec + tiles_off + uint32_t(R.P) * 1024u;
+    const int NS = int((L.K + PBL_SLAB_COLS - 1) / PBL_SLAB_COLS);
+    const bool has_crow = (L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16)) != 0;
+    const uint32_t tiles_off = PBL_TILES_OFF(L.G);
+    const uint8_t* sal = rec + tiles_off + L.P * 1024u;
     R.col0p = reinterpret_cast<const uint16_t*>(sal);
     R.deltap = reinterpret_cast<const u32x4*>(sal + PBL_SAL_DELTA_OFF(nchu));
     R.codew = reinterpret_cast<const uint32_t*>(sal + PBL_SAL_CODE_OFF(nchu));
-    R.exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), true));
-    const uint32_t* slabtab = reinterpret_cast<const uint32_t*>(sal + PBL_SAL_SLAB_OFF(nchu, uint32_t(ntail), uint32_t(R.nexc), true));
-    R.tabrow = slabtab + (lane >> 2) * R.NS;
-    R.tile_dw = reinterpret_cast<const uint32_t*>(R.rec + tiles_off) + lane * 4;
-    const pbl_rowparams* params = reinterpret_cast<const pbl_rowparams*>(R.rec + PBL_REC_PARAMS_OFF);
-    R.ri = reinterpret_cast<const pbl_rowinfo*>(R.rec + PBL_REC_ROWINFO_OFF)[lane >> 2];
-    const pbl_rowparams ps = params[lane >> 2];
+    R.exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), has_crow));
+    const uint32_t* slabtab = reinterpret_cast<const uint32_t*>(sal + PBL_SAL_SLAB_OFF(nchu, uint32_t(ntail), uint32_t(R.nexc), has_crow));
+    R.tabrow = slabtab + (lane >> 2) * NS;
+    R.tile_dw = reinterpret_cast<const uint32_t*>(rec + tiles_off) + lane * 4;
+    R.params = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
+    R.ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
+    R.ri = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF)[lane >> 2];
+    const pbl_rowparams ps = R.params[lane >> 2];
     R.ss = ps.sscale; R.sz = ps.szero;
-    const pbl_rowparams pr = params[lane & 15];
-    const uint32_t hh = __builtin_bit_cast(uint16_t, _Float16(pr.hi)), ll = __builtin_bit_cast(uint16_t, _Float16(pr.lo));
-    R.hilo_lane = (hh << 16) | ll;
-    R.e0 = tab_at(R, 0); R.e1 = tab_at(R, 1); R.e2 = tab_at(R, 2);
-    R.sq = seq_of(0u, R.e0);
-    R.c0 = load_chunkq(R, 0, R.sq, lane & 3);
-    R.c1 = load_chunkq(R, 1, R.sq, lane & 3);
-    R.dcur = load_dw(R, 0);
-    R.dnxt = load_dw(R, 1);
+    R.tp = 0; R.tc = R.tabrow[0]; R.tn = NS > 1 ? R.tabrow[1] : 0u;
+    request_slab(R, R.sdn, 0, NS, lane & 3);                     // slab 0 (stages 0, 1), then slab 1 (stages 2, 3)
+    adopt_slab(R, lane & 3);
+    request_slab(R, R.sdn, 1, NS, lane & 3);
+    R.dcur = load_dw(R, 0, int(L.P));
+    R.dnxt = load_dw(R, 1, int(L.P));
+    load_levels(R, L.G, 0, lane);
 }
 
+// ---- consumer helpers -------------------------------------------------------------------------------------------------
+struct Frag { v8h a[4], b[2]; };
+
+__device__ __forceinline__ void load_frag(Frag& f, const char* smem, uint32_t aaddr, uint32_t baddr) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) f.a[rt] = *reinterpret_cast<const v8h*>(smem + aaddr + rt * 8192);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) f.b[tt] = *reinterpret_cast<const v8h*>(smem + baddr + tt * 4096);
+}
+
+template <bool Y32>
 __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -232,157 +309,230 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
     const pbl_layer& L = a.L;
     const int K = int(L.K), M = a.M;
     const int NS = (K + PBL_SLAB_COLS - 1) / PBL_SLAB_COLS;
-    const int NH = 2 * NS, NU = 4 * NS;                  // half slabs, 64-column sub-steps
-    // XCD-aware work order (speed only; measured neutral so far): workgroup b runs on XCD b % 8; every XCD gets a CONTIGUOUS
-    // range of the token-tile-major work list, so the workgroups resident on an XCD share one 256-token slab of x.
+    const int NH = (K + GB_HS - 1) / GB_HS, NU = (K + GB_XC - 1) / GB_XC;      // half slabs, 64-column sub-steps
+    // XCD-aware work order (speed only): workgroup b runs on XCD b % 8; every XCD gets a CONTIGUOUS range of the
+    // token-tile-major work list, so the workgroups resident on an XCD share one 256-token slab of x in its L2.
     const uint32_t nrbk = (L.NRB + NREC - 1) / NREC, nwg = gridDim.x;
     const uint32_t xq = nwg >> 3, xr_ = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
     const uint32_t wg = (xcd < xr_ ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq) + xi;
     const uint32_t rowblk = wg % nrbk;
     const int tok0 = int(wg / nrbk) * GB_TOK;
 
-    _Float16* As = reinterpret_cast<_Float16*>(smem_b);                              // [2][128][GB_ASTR]
-    _Float16* Xs = reinterpret_cast<_Float16*>(smem_b + 2 * GB_AS_BYTES);            // [2][256][64], 16-byte units XOR (token >> 1) & 7
-
-    v4f acc[4][4];
-    const int row_a = lane & 15, kblk = lane >> 4;       // fragment coordinates
-    const int wr = (wave >> 2) & 1, wc = wave & 3;       // consumer wave's 64-row x 64-token block
-
     if (wave >= NCONS) {
         // =================================== producer waves =========================================================
-        const int p = wave - NCONS, pt = tid - NCONS * GW;                         // producer index = record slot, producer thread 0..511
-        Rec R;
-        init_rec(R, L, min(rowblk * NREC + p, L.NRB - 1), lane);   // (a record beyond the layer mirrors the last one; its rows are never stored)
-        uint32_t hl[16];                                 // the record's 16 level pairs, wave uniform: 16 SGPRs for the whole kernel
+        const int p = wave - NCONS;
+        Rec R[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hl[r] = __builtin_amdgcn_readlane(R.hilo_lane, r);
-        // x staging: producer thread -> 4 x (token, 16-byte unit) of a 64-column sub-step: tokens (pt >> 3) + 64 j, unit pt & 7
-        const int xtok = pt >> 3, xun = pt & 7;
-        const _Float16* xsrc = a.x + size_t(tok0 + xtok) * K + xun * 8;
-        const size_t xjs = size_t(64) * K;
-        _Float16* xdst = Xs + size_t(xtok) * GB_XC + (xun ^ ((xtok >> 1) & 7)) * 8;     // (token + 64 j) >> 1 & 7 == (token >> 1) & 7
-        u32x4 xr[4];
-        auto load_x = [&](int u) {
-            const bool colok = u * GB_XC + xun * 8 < K;
+        for (int i = 0; i < 2; ++i) init_rec(R[i], L, min(rowblk * NREC + 2 * p + i, L.NRB - 1), lane);   // (a record beyond the layer mirrors the last one; its rows are never stored)
+        const uint32_t gs = L.K / L.G;                            // columns per group (a multiple of 128)
+        // stage 0, then one stage ahead of the consumers; barrier b (b = 0 .. NH-1) closes stage b
+        for (int h = 0; h < NH; ++h) {
+            const uint32_t stage = uint32_t(h & 1) * GB_AS_STAGE;
+            const int kpairs = min(GB_HS, K - h * GB_HS) >> 1;
+            const bool work = !(PBL_GEMM_ABLATE & 1) || h == 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                u32x4 v = {0, 0, 0, 0};
-                if (colok && tok0 + xtok + 64 * j < M) v = *reinterpret_cast<const u32x4*>(xsrc + j * xjs + size_t(u) * GB_XC);
-                xr[j] = v;
-            }
-        };
-        auto store_x = [&](int buf) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(xdst + (size_t(buf) * GB_TOK + 64 * j) * GB_XC) = xr[j];
-        };
-        load_x(0);
-        expand_sign(R, hl, As, 0, p, lane);
-        expand_sal(R, 0, As, 0, p, lane);
-        store_x(0);
-        if (1 < NU) load_x(1);
-        __syncthreads();
-        for (int u = 0; u < NU; ++u) {
-            const int hn = (u >> 1) + 1;
-            const bool ex = !(PBL_GEMM_ABLATE & 1) && hn < NH;
-            if (!(PBL_GEMM_ABLATE & 2) && u + 1 < NU) store_x((u + 1) & 1);   // x(u+1), requested a sub-step ago; its buffer was last read in sub-step u-1
-            if (ex && !(u & 1)) prefetch_for(R, hn, lane & 3);                 // before the x request (see prefetch_for)
-            if (!(PBL_GEMM_ABLATE & 2) && u + 2 < NU) load_x(u + 2);
-            if (ex) {                                    // into the buffer last read in half slab h-1: plane first, salients a sub-step later
-                if (u & 1) { if (!(PBL_GEMM_ABLATE & 16)) expand_sal(R, hn, As, hn & 1, p, lane); }
-                else if (!(PBL_GEMM_ABLATE & 8)) expand_sign(R, hl, As, hn & 1, p, lane);
-            }
-            __syncthreads();
-        }
-    } else {
-        // =================================== consumer waves =========================================================
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = v4f{0.f, 0.f, 0.f, 0.f};
-        __syncthreads();
-        for (int u = 0; u < NU; ++u) {
-            const int abuf = (u >> 1) & 1, colbase = (u & 1) * GB_XC, xbuf = u & 1;
-            const _Float16* ap = As + (size_t(abuf) * GB_ROWS + wr * 64 + row_a) * GB_ASTR + colbase + kblk * 8;
-            const _Float16* xp = Xs + (size_t(xbuf) * GB_TOK + wc * 64 + row_a) * GB_XC;
-            if (!(PBL_GEMM_ABLATE & 4)) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    v8h af[4], bf[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const v8h*>(ap + size_t(i) * 16 * GB_ASTR + ks * 32);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        // token t = wc*64 + 16 j + row_a: (t >> 1) & 7 == (row_a >> 1) & 7
-                        const int un = (ks * 4 + kblk) ^ ((row_a >> 1) & 7);
-                        bf[j] = *reinterpret_cast<const v8h*>(xp + size_t(j) * 16 * GB_XC + un * 8);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t recaddr = stage + uint32_t(2 * p + i) * 4096u;
+                if (work && !(PBL_GEMM_ABLATE & 8)) {
+                    if (kpairs < GB_HS / 2) expand_sign<true>(R[i], smem_b, recaddr, lane, kpairs);
+                    else expand_sign<false>(R[i], smem_b, recaddr, lane, kpairs);
                 }
+                if (work && !(PBL_GEMM_ABLATE & 16)) expand_sal(R[i], h, smem_b, recaddr, lane);
             }
-            __syncthreads();
+            // requests for stage h + 2 (the sign-plane dword) and, when stage h + 1 opens a slab, for the slab after that one
+            // (1.5 slabs ahead); what stage h + 1 needs was requested an iteration ago
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (PBL_GEMM_ABLATE & 32) break;
+                R[i].dcur = R[i].dnxt;
+                R[i].dnxt = load_dw(R[i], h + 2, int(L.P));
+                if (h & 1) {
+                    adopt_slab(R[i], lane & 3);
+                    request_slab(R[i], R[i].sdn, ((h + 1) >> 1) + 1, NS, lane & 3);
+                }
+                if (L.G > 1 && h + 1 < NH && uint32_t((h + 1) * GB_HS) % gs == 0) load_levels(R[i], L.G, uint32_t((h + 1) * GB_HS) / gs, lane);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the stage is in LDS
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
+        return;
     }
 
-    // ---- epilogue: consumers' accumulators -> Ys[token][row] (fp16, + bias) in LDS -> contiguous stores by everybody ----
-    _Float16* Ys = reinterpret_cast<_Float16*>(smem_b);                  // [256][GB_ASTR]: the A tiles are dead
-    if (wave < NCONS) {
+    // =================================== consumer waves =============================================================
+    const int c = wave;
+    const int i32 = lane & 31, g = lane >> 5;
+    const uint32_t xring = GB_X_OFF + uint32_t(c) * GB_XRING_BYTES;
+    // x through a buffer descriptor that starts at this workgroup's first token: tokens >= M read zeros
+    const char* xbase = reinterpret_cast<const char*>(a.x) + size_t(tok0) * size_t(K) * 2;
+    const size_t xrem = size_t(min(M - tok0, GB_TOK)) * size_t(K) * 2;          // <= 256 * 32767 * 2 < 2^24
+    __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, int(xrem), 0x00020000);
+    // DMA piece q (1 KiB) of a slot = tokens 8q .. 8q+7 x 128 B; lane l lands on unit l & 7 of token 8q + (l >> 3), which holds
+    // the LOGICAL unit (l & 7) ^ ((token >> 1) & 7)
+    uint32_t xvoff[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rloc = wr * 64 + i * 16 + 4 * kblk;                // 4 consecutive rows held by this lane
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (L.bias) {
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t tl = uint32_t(8 * q + (lane >> 3));                           // token within the wave's 64
+        xvoff[q] = (uint32_t(64 * c) + tl) * uint32_t(K) * 2u + ((uint32_t(lane & 7) ^ ((tl >> 1) & 7)) << 4);
+    }
+    // K % 64 != 0: the units of the LAST sub-step that lie beyond K would hold the next token row; their source offset is
+    // pushed out of the descriptor's range instead, so they read zeros (and the producers zero the weights there too).
+    // Piece q, lane l holds logical unit (l & 7) ^ (((l >> 4) | 4 (q & 1))): two lane masks, for even and odd q.
+    const uint32_t ktail_units = uint32_t(K & (GB_XC - 1)) >> 3;                 // valid units of the last sub-step (0: no tail)
+    uint32_t xbad[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+        xbad[o] = (ktail_units && ((uint32_t(lane & 7) ^ (uint32_t(lane >> 4) | uint32_t(4 * o))) >= ktail_units)) ? 0x40000000u : 0u;
+    auto issue_x = [&](int u, int q) {       // piece q of sub-step u into ring slot u % 3
+        const uint32_t dst = xring + uint32_t(u % GB_XSLOTS) * GB_XSLOT_BYTES + uint32_t(q) * 1024u;
+        const uint32_t vo = xvoff[q] + uint32_t(u) * (GB_XC * 2) + (u == NU - 1 ? xbad[q & 1] : 0u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_b + dst), 16, int(vo), 0, 0, 0);
+    };
+    // fragment addresses: A unit (2 ks8 + g) ^ (i32 & 15) of row i32 (+ 32 rt), ks8 = 4 (u & 1) + k: the odd sub-step's units
+    // are the even one's with bit 3 flipped (byte 128); x unit (2 k + g) ^ ((i32 >> 1) & 7) of token i32 (+ 32 tt)
+    uint32_t aq[4], bq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) aq[k] = uint32_t(i32) * 256u + ((uint32_t(2 * k + g) ^ uint32_t(i32 & 15)) << 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bq[k] = xring + uint32_t(i32) * 128u + ((uint32_t(2 * k + g) ^ uint32_t((i32 >> 1) & 7)) << 4);
+
+    v16f acc[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rt][tt][e] = 0.f;
+
+    // prologue: the first three sub-steps of x on their way, stage 0 of A behind barrier 0
+#pragma unroll
+    for (int u = 0; u < GB_XSLOTS; ++u)
+        if (u < NU)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) issue_x(u, q);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // slot 0 has landed when at most the pieces of sub-steps 1, 2 are outstanding
+    if (NU >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (NU == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if PBL_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(PBL_GEMM_PRIO);
+#endif
+    Frag f0, f1;
+    load_frag(f0, smem_b, aq[0], bq[0]);      // (stage 0, first half: no offsets)
+
+    // One 64-column sub-step = 4 k-steps of 16 columns; fragments of k-step kk+1 are read while k-step kk multiplies.
+    auto mma = [&](const Frag& f) {
+        if (!(PBL_GEMM_ABLATE & 4)) {
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[rt], f.b[tt], acc[rt][tt], 0, 0, 0);
+        }
+    };
+    for (int u = 0; u < NU; ++u) {
+        const uint32_t abuf = uint32_t((u >> 1) & 1) * GB_AS_STAGE, ahalf = uint32_t(u & 1) * 128u;
+        const uint32_t xslot = uint32_t(u % GB_XSLOTS) * GB_XSLOT_BYTES;
+        const bool last = u + 1 >= NU;
+        // pieces of sub-step u+2's x go out two per k-step: its slot, (u+2) % 3 == (u-1) % 3, was last read in sub-step u-1
+        const bool stage_x = !(PBL_GEMM_ABLATE & 2) && u >= 1 && u + 2 < NU;
+        // k-step 0
+        load_frag(f1, smem_b, (aq[1] ^ ahalf) + abuf, bq[1] + xslot);
+        if (stage_x) { issue_x(u + 2, 0); issue_x(u + 2, 1); }
+        mma(f0);
+        // k-step 1
+        load_frag(f0, smem_b, (aq[2] ^ ahalf) + abuf, bq[2] + xslot);
+        if (stage_x) { issue_x(u + 2, 2); issue_x(u + 2, 3); }
+        mma(f1);
+        // k-step 2
+        load_frag(f1, smem_b, (aq[3] ^ ahalf) + abuf, bq[3] + xslot);
+        if (stage_x) { issue_x(u + 2, 4); issue_x(u + 2, 5); }
+        mma(f0);
+        // k-step 3: every read of this sub-step's x slot -- and, in an odd sub-step, of the A stage -- has been issued
+        if (stage_x) { issue_x(u + 2, 6); issue_x(u + 2, 7); }
+        if (!last) {
+            // x of sub-step u+1: its pieces were issued during sub-step u-1 (or in the prologue); younger: sub-step u+2's
+            if (u + 2 < NU) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (u & 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the stage have returned
+                __builtin_amdgcn_s_barrier();                            // ... the next stage is complete
+                asm volatile("" ::: "memory");
+            }
+            const uint32_t nabuf = uint32_t(((u + 1) >> 1) & 1) * GB_AS_STAGE, nahalf = uint32_t((u + 1) & 1) * 128u;
+            load_frag(f0, smem_b, (aq[0] ^ nahalf) + nabuf, bq[0] + uint32_t((u + 1) % GB_XSLOTS) * GB_XSLOT_BYTES);
+        }
+        mma(f1);
+    }
+#if PBL_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+
+    // ---- epilogue, per consumer wave: accumulators (+ bias) -> Ys[32 tokens][128 rows] in the wave's own ring -> 16-byte stores
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    typedef typename std::conditional<Y32, float, _Float16>::type yt;
+    constexpr uint32_t YSTR = Y32 ? 528u : 264u;              // bytes per token row: 128 rows + 16 / 8 B (conflict-free 16 / 8-byte writes)
+    const uint32_t row0 = rowblk * GB_ROWS;
+    const bool vec = (L.N & (Y32 ? 3 : 7)) == 0 && row0 + GB_ROWS <= L.N;     // whole 16-byte units, all rows exist
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int rloc = rt * 32 + 8 * q4 + 4 * g;        // 4 consecutive rows held by this lane: D row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+                yt h[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const uint32_t row = rowblk * GB_ROWS + rloc + r;
-                    b4[r] = row < L.N ? L.bias[row] : 0.f;
+                    const uint32_t row = row0 + uint32_t(rloc + r);
+                    const float b = (L.bias && row < L.N) ? L.bias[row] : 0.f;
+                    h[r] = yt(acc[rt][tt][4 * q4 + r] + b);
+                }
+                char* dst = smem_b + xring + uint32_t(i32) * YSTR + uint32_t(rloc) * sizeof(yt);
+                if (Y32) *reinterpret_cast<v4f*>(dst) = v4f{float(h[0]), float(h[1]), float(h[2]), float(h[3])};
+                else {
+                    uint2 pk;
+                    pk.x = uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[0]))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[1]))) << 16);
+                    pk.y = uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[2]))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[3]))) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t = wc * 64 + j * 16 + row_a;
-                _Float16 h[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = _Float16(acc[i][j][r] + b4[r]);
-                uint2 pk;
-                pk.x = uint32_t(__builtin_bit_cast(uint16_t, h[0])) | (uint32_t(__builtin_bit_cast(uint16_t, h[1])) << 16);
-                pk.y = uint32_t(__builtin_bit_cast(uint16_t, h[2])) | (uint32_t(__builtin_bit_cast(uint16_t, h[3])) << 16);
-                *reinterpret_cast<uint2*>(Ys + size_t(t) * GB_ASTR + rloc) = pk;
-            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int UPR = GB_ROWS * int(sizeof(yt)) / 16;      // 16-byte units per token row: 16 (fp16) / 32 (fp32)
+        for (int idx = lane; idx < 32 * UPR; idx += GW) {
+            const int t = idx / UPR, un = idx % UPR, tok = tok0 + 64 * c + 32 * tt + t;
+            if (tok >= M) continue;
+            constexpr int EPU = 16 / int(sizeof(yt));            // elements per unit
+            yt* dstg = static_cast<yt*>(a.y) + size_t(tok) * L.N + row0 + un * EPU;
+            const yt* src = reinterpret_cast<const yt*>(smem_b + xring + uint32_t(t) * YSTR) + un * EPU;
+            if (vec) *reinterpret_cast<u32x4*>(dstg) = *reinterpret_cast<const u32x4*>(src);
+            else
+                for (int e = 0; e < EPU; ++e)
+                    if (row0 + un * EPU + e < L.N) dstg[e] = src[e];
         }
-    }
-    __syncthreads();
-    const uint32_t row0 = rowblk * GB_ROWS;
-    const bool vec = (L.N & 7) == 0 && row0 + GB_ROWS <= L.N;            // whole 16-byte units, all rows exist
-    for (int idx = tid; idx < GB_TOK * (GB_ROWS / 8); idx += (NCONS + NPROD) * GW) {
-        const int t = idx >> 4, un = idx & 15, tok = tok0 + t;
-        if (tok >= M) continue;
-        _Float16* dst = a.y + size_t(tok) * L.N + row0 + un * 8;
-        const _Float16* src = Ys + size_t(t) * GB_ASTR + un * 8;
-        if (vec) *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
-        else
-            for (int e = 0; e < 8; ++e)
-                if (row0 + un * 8 + e < L.N) dst[e] = src[e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done before the next half overwrites the buffer
     }
 }
 
 }  // namespace
 
-extern "C" int pbl_gemm_f16(const pbl_layer* layer, const void* x, void* y, int M, void* stream) {
+extern "C" int pbl_gemm_f16_ex(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream) {
     if (!layer || !layer->blob || !x || !y || M < 1) return PBL_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(layer->blob) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
         return PBL_ERR_MISALIGNED;
-    // exact only when every weight is an fp16 number: layers packed from an fp16 checkpoint
-    if (layer->G != 1 || (layer->K & 7) || !(layer->flags & PBL_FLAG_SAL_F16) || !(layer->flags & PBL_FLAG_SLABS) ||
-        !(layer->flags & PBL_FLAG_TAIL_REPEAT))
-        return PBL_ERR_UNSUPPORTED;
+    if ((layer->K & 7) || !(layer->flags & PBL_FLAG_SLABS) || !(layer->flags & PBL_FLAG_TAIL_REPEAT)) return PBL_ERR_UNSUPPORTED;
+    if (layer->G < 1 || (layer->G > 1 && (layer->K % layer->G || (layer->K / layer->G) % GB_HS))) return PBL_ERR_UNSUPPORTED;
     GemmArgs a;
-    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = static_cast<_Float16*>(y); a.M = M;
-    const void* k = reinterpret_cast<const void*>(pbl_gemm_kernel);
+    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32;
+    const void* k = y_f32 ? reinterpret_cast<const void*>(pbl_gemm_kernel<true>) : reinterpret_cast<const void*>(pbl_gemm_kernel<false>);
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(GB_LDS)) != hipSuccess) return PBL_ERR_LAUNCH;
     void* argv[] = {&a};
     const dim3 grid(((layer->NRB + NREC - 1) / NREC) * uint32_t((M + GB_TOK - 1) / GB_TOK));
     return hipLaunchKernel(k, grid, dim3((NCONS + NPROD) * GW), argv, GB_LDS, static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+extern "C" int pbl_gemm_f16(const pbl_layer* layer, const void* x, void* y, int M, void* stream) {
+    return pbl_gemm_f16_ex(layer, x, y, M, 0, stream);
 }

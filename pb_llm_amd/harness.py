@@ -132,11 +132,15 @@ def quant_sequential_(model: nn.Module, calib_ids, low_frac: float, salient_metr
 
 
 class _FusedMember(nn.Module):
-    """Stands where q_proj / k_proj / v_proj (or gate_proj / up_proj) stood.  The first member called with an activation
-    launches the whole group once (runtime.FusedGemv) and the others pick their slice up, as long as they are called
-    with the same tensor (HF attention / MLP modules call the projections back to back on one hidden_states).  More than
-    4 rows, or a non-fp16 activation: each member runs its own PBLinear (matrix-core / GEMM regime), bit-identical to the
-    unfused model."""
+    """Stands where q_proj / k_proj / v_proj (or gate_proj / up_proj) stood.  WHICHEVER member is called first with an
+    activation launches the whole group once (runtime.FusedGemv) and the others pick their slice up when they are called
+    with the SAME tensor object (HF attention / MLP modules pass one hidden_states to all projections).  The group keeps
+    a reference to that tensor until the next launch: an identity match can therefore not be a recycled device address
+    (the caching allocator hands the next token's activation the address of the previous one), and the call order of the
+    members does not matter.  A member called with another tensor -- a view, a copy, the next token -- launches again;
+    launches that served no other member are counted (`_FusedGroup.solo_launches`) and reported once, because a model
+    that never shares the tensor pays the whole group per projection.  More than 4 rows, or a non-fp16 activation: each
+    member runs its own PBLinear (matrix-core / GEMM regime), bit-identical to the unfused model."""
 
     def __init__(self, group: "_FusedGroup", index: int, own: PBLinear):
         super().__init__()
@@ -150,25 +154,50 @@ class _FusedMember(nn.Module):
         rows = x.numel() // x.shape[-1]
         if x.dtype != torch.float16 or rows > 4 or not x.is_cuda or (torch.is_grad_enabled() and x.requires_grad):
             return self.own(x)
-        key = (x.data_ptr(), x._version, tuple(x.shape))
-        if self._index == 0:
-            # the leader always launches: the allocator hands the next token's activation the same address, so a key
-            # match alone does not prove the cached outputs belong to this tensor
-            g.outs = g.fused(x.reshape(rows, x.shape[-1]).contiguous())
-            g.key, g.pending = key, set(range(1, len(g.outs)))
-            return g.outs[0].reshape(*x.shape[:-1], self.out_features)
-        if g.key == key and self._index in g.pending:      # each launch serves each follower once
+        if g.x_ref is x and g.x_version == x._version and self._index in g.pending:     # each launch serves each member once
             g.pending.discard(self._index)
+            g.served += 1
             return g.outs[self._index].reshape(*x.shape[:-1], self.out_features)
-        return self.own(x)
+        g.launch(x, rows, self._index)
+        return g.outs[self._index].reshape(*x.shape[:-1], self.out_features)
 
 
 class _FusedGroup:
+    """One fused launch (runtime.FusedGemv) over the member PBLinears.  The launch descriptors snapshot the members' blobs
+    (device pointers, LDS sizing): they are rebuilt when a member's blob moved or was rewritten (.to(), load_state_dict)."""
+    SOLO_WARN_AFTER = 32
+
     def __init__(self, mods: list[PBLinear]):
+        self.mods = mods
+        self.x_ref, self.x_version, self.outs, self.pending = None, -1, None, set()
+        self.launches = self.served = self.solo_launches = 0
+        self._warned = False
+        self._build()
+
+    def _stamp(self):
+        return tuple((m.pbl_blob.data_ptr(), m.pbl_blob._version, None if m.pbl_bias is None else m.pbl_bias.data_ptr())
+                     for m in self.mods)
+
+    def _build(self):
         from .runtime import FusedGemv
-        dev = mods[0].pbl_blob.device
-        self.fused = FusedGemv([m.packed for m in mods], [m.pbl_bias for m in mods], dev)
-        self.key, self.outs, self.pending = None, None, set()
+        dev = self.mods[0].pbl_blob.device
+        self.fused = FusedGemv([m.packed for m in self.mods], [m.pbl_bias for m in self.mods], dev)
+        self.stamp = self._stamp()
+
+    def launch(self, x, rows, index):
+        if self.pending and self.launches and len(self.pending) == len(self.mods) - 1:
+            self.solo_launches += 1          # the previous launch served nobody but its caller
+            if self.solo_launches == self.SOLO_WARN_AFTER and not self._warned:
+                import warnings
+                self._warned = True
+                warnings.warn("pb_llm_amd.harness: fused projection group keeps launching for single members -- the model does "
+                              "not pass one tensor object to its q/k/v (gate/up) projections; fuse_decode_ gains nothing here")
+        if self._stamp() != self.stamp:
+            self._build()
+        self.outs = self.fused(x.reshape(rows, x.shape[-1]).contiguous())
+        self.x_ref, self.x_version = x, x._version
+        self.pending = set(range(len(self.mods))) - {index}
+        self.launches += 1
 
 
 FUSE_SETS = (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))     # LLaMA naming (HF)

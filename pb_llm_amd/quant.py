@@ -41,20 +41,28 @@ class BinaryInterface:
 # Layers the matrix-core kernel cannot take (odd group sizes, K % 8) switch to the dense path at GEMM_THRESHOLD.
 MFMA_MAX = 32
 GEMM_THRESHOLD = 12
-# GEMM regime backend: "fused" = pbl_gemm_f16, the hand-written kernel that rebuilds exact fp16 weight tiles in LDS from the
-# packed records (fp16-checkpoint layers); "library" = pbl_unpack_dev into a transient dense buffer + torch's GEMM (always
-# used for fp32 / column-group layers, which the fused kernel does not take).  Measured on MI355X at llama-7b shapes, seq 2048
-# (profiles/r02c): fused 450-560 TFLOP/s, unpack + library 730-960, so the library path stays the default; the fused kernel
-# is the one that never materialises the dense weight.
-GEMM_BACKEND = "library"
+# GEMM regime backend: "fused" (default) = pbl_gemm_f16_ex, the hand-written kernel that rebuilds fp16 weight tiles in LDS from
+# the packed records and never materialises the dense weight (fp16 activations, fp16 dense dtype, any layer kind the kernel
+# takes -- see fused_gemm_ok); "library" = pbl_unpack_dev into a transient dense buffer + torch's GEMM, which also serves
+# everything the fused kernel does not take (fp32 / bf16 activations, fp32 dense dtype, odd group sizes, K % 8).
+GEMM_BACKEND = "fused"
 
 
-def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor) -> torch.Tensor:
-    """pbl_gemm_f16: x2 [M, K] fp16 contiguous -> [M, N] fp16; raises PblError(UNSUPPORTED) for layers it does not take"""
-    y = torch.empty(x2.shape[0], packed.N, dtype=torch.float16, device=x2.device)
+def fused_gemm_ok(packed: PackedWeight) -> bool:
+    """layers pbl_gemm_f16_ex takes (include/pbl.h): K % 8 == 0, slab index + repeat-padded tails, groups of k * 128 columns"""
+    need = _lib.PBL_FLAG_SLABS | _lib.PBL_FLAG_TAIL_REPEAT
+    if packed.K % 8 or (packed.flags & need) != need:
+        return False
+    return packed.G == 1 or (packed.K % packed.G == 0 and (packed.K // packed.G) % 128 == 0)
+
+
+def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False) -> torch.Tensor:
+    """pbl_gemm_f16_ex: x2 [M, K] fp16 contiguous -> [M, N] fp16 (fp32 with out_f32); raises PblError(UNSUPPORTED) for layers
+    it does not take"""
+    y = torch.empty(x2.shape[0], packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
     layer = packed.layer_struct(bias_f32)
-    _lib.check(_lib.lib().pbl_gemm_f16(C.byref(layer), x2.data_ptr(), y.data_ptr(), x2.shape[0],
-                                       torch.cuda.current_stream(x2.device).cuda_stream), "gemm_f16")
+    _lib.check(_lib.lib().pbl_gemm_f16_ex(C.byref(layer), x2.data_ptr(), y.data_ptr(), x2.shape[0], int(out_f32),
+                                          torch.cuda.current_stream(x2.device).cuda_stream), "gemm_f16")
     return y
 
 
@@ -154,10 +162,10 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         # reference executes (F.linear over the dense fake-quant weight).  fp16 weights when
         # the layer is fp16-exact (packed from an fp16 checkpoint), else fp32.
         wdt = torch.float16 if (x.dtype == torch.float16 and dense_dtype in (None, torch.float16)) else torch.float32
-        if (GEMM_BACKEND == "fused" and wdt == torch.float16 and not out_f32 and mfma_ok and packed.flags & _lib.PBL_FLAG_SAL_F16):
+        if GEMM_BACKEND == "fused" and wdt == torch.float16 and fused_gemm_ok(packed):
             xc = x2.contiguous()
             if xc.data_ptr() % 16 == 0:
-                return fused_gemm_forward(packed, bias_f32, xc).reshape(*lead, packed.N)
+                return fused_gemm_forward(packed, bias_f32, xc, out_f32).reshape(*lead, packed.N)
         W = unpack_on_device(packed, wdt)
         y = torch.nn.functional.linear(x2.to(wdt), W, None if bias_f32 is None else bias_f32.to(wdt))
         y = y.float() if out_f32 else y.to(x.dtype)

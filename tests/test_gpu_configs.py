@@ -394,6 +394,62 @@ def test_fused_decode_and_graph_replay_bit_for_bit():
             assert torch.equal(g.replay(tok), plain(tok, use_cache=False).logits), t
 
 
+def test_fused_members_in_any_call_order_and_after_moves():
+    """harness._FusedMember: whichever member is called first launches the group, the others are served only for the SAME
+    tensor object (held by the group, so a recycled device address cannot match); followers called before the leader,
+    across consecutive tokens whose activations reuse one address, give the unfused results bit for bit; a model that
+    passes views launches per member (counted); rewriting a member's blob in place rebuilds the launch descriptors."""
+    from pb_llm_amd import harness as H
+    import torch.nn as nn
+    K = 512
+    mods, refs = [], []
+    for i, N in enumerate((96, 160, 64)):
+        W = synth.llm_weight(N, K, seed=30 + i)
+        mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        mods.append(Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV))
+        refs.append(r["W_fq"])
+
+    class Attn(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q_proj, self.k_proj, self.v_proj = mods
+    holder = Attn()
+    plain = [m for m in mods]
+    assert H.fuse_decode_(holder) == 1
+    fused = [holder.q_proj, holder.k_proj, holder.v_proj]
+    grp = fused[0]._group[0]
+    for step, order in enumerate([(1, 0, 2), (2, 1, 0), (0, 1, 2), (1, 2, 0)]):
+        x = T(synth.activations((1, K), 50 + step, 21))           # a fresh tensor per "token": the allocator may reuse the address
+        outs = {i: fused[i](x) for i in order}
+        for i in range(3):
+            assert torch.equal(outs[i], plain[i](x)), (step, i)
+        del x, outs
+    assert grp.launches == 4 and grp.served == 8 and grp.solo_launches == 0
+    # a different tensor object of the same storage is NOT served from the cache: every member launches
+    x = T(synth.activations((2, K), 60, 21))
+    before = grp.launches
+    for i in (1, 0, 2):
+        assert torch.equal(fused[i](x.view(2, K)), plain[i](x))
+    assert grp.launches == before + 3 and grp.solo_launches >= 2
+    # an in-place edit of x between two member calls invalidates the cached outputs
+    ya = fused[0](x)
+    x.mul_(2)
+    assert torch.equal(fused[1](x), plain[1](x)) and not torch.equal(fused[0](x), ya)
+    # load_state_dict into a member rewrites its blob in place: the group rebuilds its descriptors
+    W = synth.llm_weight(160, K, seed=99)
+    mask = O.ptq_low_mask(W, 0.8, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    other = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
+    if other.pbl_blob.numel() == mods[1].pbl_blob.numel():       # (same size needed for an in-place copy; else skip this leg)
+        mods[1].load_state_dict(other.state_dict())
+    x2 = T(synth.activations((1, K), 61, 21))
+    got = [fused[i](x2) for i in (2, 1, 0)][::-1]
+    for i in range(3):
+        assert torch.equal(got[i], plain[i](x2))
+    assert_parity(got[1], O.dense_linear(x2.cpu().numpy(), mods[1].weight.float().cpu().numpy()))
+
+
 # ------------------------------------------------------------------------------------------- GEMM regime, fused kernel
 @pytest.mark.parametrize("N,K,M,lf,bias", [(256, 512, 33, 0.9, True), (130, 1288, 300, 0.8, False), (4096, 4096, 2048, 0.95, False),
                                            (1000, 11008, 257, 0.95, True)])

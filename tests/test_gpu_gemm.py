@@ -1,0 +1,149 @@
+"""-m gpu: the GEMM-regime kernel pbl_gemm_f16_ex (csrc/pbl_gemm_big.hip; more than 32 rows of x: prefill, the reference's
+perplexity loops gptq_pb/eval_ppl_utils.py:55-64, evaluate.py:126-145 call every nn.Linear with seq 2048 rows) on every layer
+kind it takes: fp16-checkpoint and fp32-grid layers, column groups, fp16 and fp32 results, bias, exceptions, ragged N / K / M,
+the BASELINE configs[2] layers (hessian salients: many short chunks, whole columns salient) at 11008-wide shapes -- against the
+float64 oracle on the weights a dense fp16 copy of the layer holds, and against the library GEMM on pbl_unpack_dev's output
+(same operands, different summation order).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pb_oracle as O
+from pb_llm_amd import _lib, synth
+from pb_llm_amd import quant as Q
+from pb_llm_amd.packing import pack_dense
+from cfg_shapes import hessian_layer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    import __graft_entry__ as g
+    g.build()
+    assert torch.cuda.is_available()
+
+
+def T(a, dev=DEV):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def assert_parity(y, ref, tol=1e-3):
+    y = y.detach().float().cpu().numpy() if isinstance(y, torch.Tensor) else y
+    rel, ratio = O.parity_errors(y, ref)
+    assert rel < tol and ratio < 1.0, f"rel_max={rel:.3e} allclose_ratio={ratio:.3f}"
+
+
+def sample_rows(N, n=160):
+    return np.unique(np.concatenate([np.arange(0, N, max(1, N // n)), [N - 1, max(N - 17, 0), min(127, N - 1), min(128, N - 1)]]))
+
+
+def rtn_layer(N, K, gs, seed, low_frac, fp16, exceptions=0, metric="magnitude"):
+    """RTN partially-binarized weight (per-(row, group) levels), packed; fp16: as an fp16 checkpoint holds it
+    (gptq_pb/gptq.py:182).  Returns (packed, dense fp32 weight the blob unpacks to)."""
+    if metric == "hessian":
+        W, mask, r = hessian_layer(N, K, low_frac, seed)
+    else:
+        W = synth.llm_weight(N, K, seed=seed, heavy_tail=True)
+        mask = O.ptq_low_mask(W, low_frac, "magnitude", None, gs)
+        r = O.ptq_rtn(W, mask, 8, gs)
+    G = 1 if gs == -1 else K // gs
+    hi = (r["scale"] + r["mean"]).reshape(G, N).T
+    lo = (-r["scale"] + r["mean"]).reshape(G, N).T
+    Wd = r["W_fq"].astype(np.float32).copy()
+    if fp16:
+        Wd = Wd.astype(np.float16).astype(np.float32)
+        hi, lo = hi.astype(np.float16).astype(np.float32), lo.astype(np.float16).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    for _ in range(exceptions):                      # off-grid values anywhere
+        Wd[rng.integers(0, N), rng.integers(0, K)] = np.float32(np.float16(rng.standard_normal()))
+    p = pack_dense(Wd, hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8), sal_f16=fp16)
+    assert p.G == G and bool(p.flags & _lib.PBL_FLAG_SAL_F16) == fp16
+    return p, Wd
+
+
+CASES = [
+    # N, K, M, groupsize, low_frac, fp16 checkpoint, exceptions, metric
+    (256, 512, 33, -1, 0.9, True, 2, "magnitude"),
+    (130, 1288, 300, -1, 0.8, True, 3, "magnitude"),            # ragged N, K % 64 = 8, ragged M
+    (130, 1288, 300, -1, 0.8, False, 3, "magnitude"),           # ... fp32 grid: weights rounded to fp16 in the tile
+    (72, 200, 40, -1, 0.9, False, 0, "magnitude"),              # K < one slab, K % 64 = 8
+    (1000, 4096, 257, 128, 0.9, True, 4, "magnitude"),          # column groups of 128: levels change every half slab
+    (272, 2048, 129, 256, 0.85, False, 2, "magnitude"),         # groups of 256, fp32 grid
+    (144, 1536, 64, 512, 0.9, True, 0, "magnitude"),
+    (4096, 4096, 2048, -1, 0.95, True, 0, "magnitude"),         # the configs[2] token count on the headline shape
+    (11008, 4096, 512, -1, 0.95, True, 0, "hessian"),           # configs[2] gate/up: hessian salients
+    (4096, 11008, 512, -1, 0.95, True, 0, "hessian"),           # configs[2] down: K = 86 half slabs
+    (4096, 11008, 300, 128, 0.95, False, 0, "magnitude"),       # groupsize 128, fp32 grid, 11008 wide
+]
+
+
+@pytest.mark.parametrize("N,K,M,gs,lf,fp16,exc,metric", CASES)
+def test_gemm_regime_kernel(N, K, M, gs, lf, fp16, exc, metric):
+    p, Wd = rtn_layer(N, K, gs, seed=N + K + M, low_frac=lf, fp16=fp16, exceptions=exc, metric=metric)
+    assert p.nexc >= exc // 2 and Q.fused_gemm_ok(p)
+    pd = p.to(DEV)
+    W16 = Wd.astype(np.float16).astype(np.float32)               # what a dense fp16 copy of the layer holds
+    b = synth.normal((N,), 2, 3, 0.1)
+    x = synth.activations((M, K), N + 3, 21)
+    xt = T(x)
+    rows = np.arange(N) if N * K * M < 2e9 else sample_rows(N)
+    ridx = torch.from_numpy(rows).to(DEV)
+    y = Q.fused_gemm_forward(pd, T(b), xt)
+    assert y.shape == (M, N) and y.dtype == torch.float16
+    assert_parity(y[:, ridx], O.dense_linear(x, W16[rows], b[rows]))
+    y32 = Q.fused_gemm_forward(pd, None, xt, out_f32=True)
+    assert y32.dtype == torch.float32
+    assert_parity(y32[:, ridx], O.dense_linear(x, W16[rows]), 3e-4)       # fp32 accumulation of exact fp16 products, unrounded
+    assert torch.equal(y, Q.fused_gemm_forward(pd, T(b), xt))             # deterministic
+    # the library backend on the unpacked layer: same operands, different summation order
+    Wdev = Q.unpack_on_device(pd, torch.float16)
+    np.testing.assert_array_equal(Wdev.float().cpu().numpy()[rows], W16[rows])
+    y_lib = torch.nn.functional.linear(xt, Wdev, T(b).half())
+    assert_parity(y, y_lib.float().cpu().numpy().astype(np.float64), 2e-3)
+
+
+def test_module_routes_the_gemm_regime_to_the_fused_kernel():
+    """PBLinear above 32 rows: the fused kernel by default (fp16 activations), the library backend on request and for
+    bf16 / fp32 activations; the two backends agree; a leading batch dimension and a non-contiguous input are handled."""
+    p, Wd = rtn_layer(512, 1024, -1, seed=5, low_frac=0.9, fp16=True, exceptions=1)
+    layer = Q.PBLinear(p.to(DEV), T(synth.normal((512,), 3, 3, 0.1)))
+    x = synth.activations((3, 40, 1024), 8, 21)
+    xt = T(x)
+    assert Q.GEMM_BACKEND == "fused"
+    y = layer(xt)
+    ref = O.dense_linear(x.reshape(-1, 1024), Wd, layer.pbl_bias.cpu().numpy()).reshape(3, 40, 512)
+    assert y.shape == (3, 40, 512) and y.dtype == torch.float16
+    assert_parity(y, ref)
+    assert torch.equal(y.reshape(120, 512), Q.fused_gemm_forward(layer.packed, layer.pbl_bias, xt.reshape(120, 1024)))
+    old = Q.GEMM_BACKEND
+    try:
+        Q.GEMM_BACKEND = "library"
+        y_lib = layer(xt)
+    finally:
+        Q.GEMM_BACKEND = old
+    assert_parity(y, y_lib.float().cpu().numpy().astype(np.float64), 2e-3)
+    xs = T(synth.activations((120, 2048), 9, 21))[:, ::2]               # strided view
+    assert_parity(layer(xs), O.dense_linear(xs.cpu().numpy(), Wd, layer.pbl_bias.cpu().numpy()))
+    # bf16 activations take the library backend (fp32 dense weight); the result is rounded to bf16 (8 significand bits)
+    yb = layer(xt.bfloat16())
+    refb = O.dense_linear(xt.bfloat16().float().cpu().numpy().reshape(-1, 1024), Wd, layer.pbl_bias.cpu().numpy()).reshape(3, 40, 512)
+    assert yb.dtype == torch.bfloat16 and O.parity_errors(yb.float().cpu().numpy(), refb)[0] < 1e-2
+
+
+def test_gemm_regime_properties_at_full_size():
+    """size-independent properties on the headline shape at seq 2048: linearity in x (exact for power-of-two scaling),
+    token rows independent of their neighbours (a batch is its rows), zero rows give the bias."""
+    N = K = 4096
+    p, Wd = rtn_layer(N, K, -1, seed=41, low_frac=0.9, fp16=True)
+    pd = p.to(DEV)
+    b = T(synth.normal((N,), 5, 3, 0.1))
+    x = T(synth.activations((2048, K), 12, 21))
+    y = Q.fused_gemm_forward(pd, None, x, out_f32=True)
+    assert torch.equal(Q.fused_gemm_forward(pd, None, x * 2, out_f32=True), y * 2)
+    sub = Q.fused_gemm_forward(pd, None, x[700:1000].contiguous(), out_f32=True)       # other tile positions, ragged count
+    assert torch.equal(sub, y[700:1000])
+    z = Q.fused_gemm_forward(pd, b, torch.zeros(64, K, dtype=torch.float16, device=DEV), out_f32=True)
+    assert torch.equal(z, b.expand(64, N))

@@ -13,8 +13,16 @@ SHAPES = tuple((s_, float(f)) for s_, f in (t.split(":") for t in os.environ.get
 ONLY = os.environ.get("PBL_BENCH_ONLY", "")
 
 
-def timeit(fn, n=20):
+PREHEAT_S = float(os.environ.get("PBL_BENCH_PREHEAT_S", 1.0))     # the same launch for this long before timing: a cold MI355X idles its clocks
+
+
+def timeit(fn, n=50):
+    import time
     fn(); torch.cuda.synchronize()
+    t0 = time.time()
+    while time.time() - t0 < PREHEAT_S:
+        for _ in range(20): fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
@@ -40,5 +48,5 @@ for shp, lf in SHAPES:
         res["unpack_plus_library_us"] = round(timeit(lambda: layer(x)), 1)
         Q.GEMM_BACKEND = "fused"
         res["dense_library_us"] = round(timeit(lambda: torch.nn.functional.linear(x, Wd)), 1)
-    out = dict(shape=shp, low_frac=lf, M=M, us=res, tflops={k.replace("_us", ""): round(flops / v / 1e6, 1) for k, v in res.items()})
+    out = dict(shape=shp, low_frac=lf, M=M, preheat_s=PREHEAT_S, us=res, tflops={k.replace("_us", ""): round(flops / v / 1e6, 1) for k, v in res.items()})
     print(json.dumps(out), flush=True)
