@@ -18,8 +18,9 @@ uint8 code and 8-bit index per salient + row params + row pointers + fp16 x and 
 --gpus N > 1 (BASELINE configs[4]): the SAME L layers are sharded over N ranks with the
 LLaMA tensor-parallel mapping -- layer i plays role i % 7 of a decoder layer: q, k, v, gate, up are
 N-split (each rank owns a slice of the output rows, no exchange), o and down are K-split (each rank
-owns a slice of the input columns; the fp32 partial outputs of all K-split layers are summed by ONE
-all-reduce per step: RCCL, or the library's one-shot peer-to-peer all-reduce with --collective p2p).
+owns a slice of the input columns; the fp32 partial outputs of the K-split layers are summed by one
+all-reduce per K-split layer -- 64 per step, as a decoder runs them; --tp-collectives stacked: ONE for all of them --:
+RCCL, or the library's one-shot peer-to-peer all-reduce with --collective p2p).
 Total work is fixed: strong scaling.  `--parallel dp` keeps round 1's independent streams per rank.
 Run directly, `bench.py --gpus N` starts the N ranks itself (torch.distributed.run); started by
 torch.distributed.run it checks WORLD_SIZE == N.
@@ -237,6 +238,9 @@ def main():
                          "layer streams per rank (weak scaling, no collective)")
     ap.add_argument("--collective", choices=["rccl", "p2p"], default="rccl",
                     help="tp all-reduce: RCCL (torch.distributed) or libpbl's one-shot peer-to-peer all-reduce")
+    ap.add_argument("--tp-collectives", choices=["per-layer", "stacked"], default="per-layer",
+                    help="tp: per-layer = one all-reduce of [M, N] fp32 per K-split layer (64 per step, 16 KB each at M = 1: what a "
+                         "decoder executes); stacked = ONE all-reduce of all K-split partials per step (the easy case)")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
                     help="cfg2 = BASELINE configs[1], the headline GEMV stream (default, what the driver runs); cfg3 / cfg4: "
                          "configs[2] / configs[3] as side lines (see run_side_workload)")
@@ -338,10 +342,12 @@ def main():
                 kev.append((e0, e1))
             if tp:
                 gk = groups[1][0]
-                if comm is not None:
-                    comm.all_reduce_(gk.y_all)
-                else:
-                    dist.all_reduce(gk.y_all)
+                parts = gk.y if a.tp_collectives == "per-layer" else [gk.y_all]
+                for t in parts:
+                    if comm is not None:
+                        comm.all_reduce_(t)
+                    else:
+                        dist.all_reduce(t)
         else:
             for m, x in singles:
                 m(x)
@@ -420,9 +426,11 @@ def main():
         per_launch_s = kern_s / (a.steps * nl)
         achieved = b_alg / nl / per_launch_s / 1e9
         if tp:
-            par = (f"tp{world}: llama mapping, q/k/v/gate/up N-split (no exchange), o/down K-split + one "
-                   f"{'libpbl one-shot p2p' if a.collective == 'p2p' else 'RCCL'} all-reduce of "
-                   f"[{len(groups[1][0].packed)},{a.M},{a.N}] fp32 per step")
+            nk = len(groups[1][0].packed)
+            coll = 'libpbl one-shot p2p' if a.collective == 'p2p' else 'RCCL'
+            par = (f"tp{world}: llama mapping, q/k/v/gate/up N-split (no exchange), o/down K-split + " +
+                   (f"{nk} {coll} all-reduces of [{a.M},{a.N}] fp32 per step (one per K-split layer)" if a.tp_collectives == "per-layer"
+                    else f"one {coll} all-reduce of [{nk},{a.M},{a.N}] fp32 per step"))
         else:
             par = f"dp{world} (independent layer streams, no collective)"
         out = {
@@ -444,7 +452,10 @@ def main():
                          "packed_bytes_per_launch": packed_b / nl,
                          "us_per_launch": 1e6 * per_launch_s,
                          "us_per_layer": 1e6 * kern_s / (a.steps * a.layers),
-                         "note": ("per rank: bytes of rank 0's shards / the GEMV launches of a step" if tp else
+                         "us_per_step": 1e6 * dev_s / a.steps,
+                         "collective_us_per_step": (1e6 * (dev_s - kern_s) / a.steps) if tp else 0.0,
+                         "note": ("per rank: bytes of rank 0's shards / the GEMV launches of a step; us_per_step is the whole step "
+                                  "on the device, collectives included (max over ranks)" if tp else
                                   "one grouped launch = the whole stream")},
         }
         if not a.no_cpu_baseline and world == 1:

@@ -305,6 +305,15 @@ int pbl_gemv_f16_grouped(const pbl_layer* layers_dev, const void* const* x_dev, 
  * (csrc/pbl_gemm_big.hip); the dense weight never exists in HBM.  Replaces nn.Linear over the dense fake-quant checkpoint
  * at seq 2048 (gptq_pb/eval_ppl_utils.py:55-64, evaluate.py:126-145). */
 int pbl_gemm_f16_ex(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream);
+/* The same with a transient workspace (device, 16-B aligned, pbl_gemm_workspace_bytes(layer, M) bytes; 0 = none wanted: at most
+ * one 256-token tile, or K > 16256).  A workgroup of the GEMM kernel decodes a record's salient chunks once per token tile and
+ * half slab, in a single in-order producer wave -- the critical path at 5-10 % salients.  With the workspace a small kernel
+ * ahead of the GEMM decodes every chunk ONCE per call into 4-byte words {position in the stage image : fp16 value}, grouped
+ * per (record, 128-column half slab), and the GEMM's producers copy them: 4 B per salient entry of scratch (the dense weight
+ * would be 2 B per WEIGHT), identical results bit for bit.  workspace == NULL or too small: pbl_gemm_f16_ex. */
+size_t pbl_gemm_workspace_bytes(const pbl_layer* layer, int M);
+int pbl_gemm_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* workspace, size_t workspace_bytes,
+                    void* stream);
 int pbl_gemm_f16(const pbl_layer* layer, const void* x, void* y, int M, void* stream);   /* = pbl_gemm_f16_ex(.., 0, ..) */
 
 /* Decode-time FUSED projections (q/k/v, gate/up: layers that read the same activation): L layers, ONE x [M, K] (fp16,
@@ -383,13 +392,19 @@ int pbl_gptq_block(float* W, uint32_t N, uint32_t K, uint32_t c0, uint32_t ncols
  * allocation), exports it (pbl_ipc_export -> 64-byte handle, exchanged by the host layer, e.g. torch.distributed
  * all_gather), opens the other ranks' handles (pbl_ipc_open) and then calls pbl_p2p_allreduce_f32 with the table of
  * mapped pointers: x[0:n] (fp32, device) <- sum over ranks, in rank order (bit-identical on every rank), as ONE kernel:
- * push to the peers' slots over xGMI, flag, bounded wait, local sum (csrc/pbl_comm.hip).  seq: 1, 2, 3, ... the same on
- * every rank; max_elems: the capacity the buffers were sized for.  Asynchronous on `stream`, graph-capturable for a
- * fixed seq parity pattern only (seq is a launch argument), so eager launches are the intended use. */
+ * push to the peers' slots over xGMI, flag, bounded wait, local sum (csrc/pbl_comm.hip).  max_elems: the capacity the
+ * buffers were sized for (pbl_p2p_buffer_bytes_world(max_elems, world); pbl_p2p_buffer_bytes sizes for 16 ranks).
+ * The call number that tags the flags is either an argument (pbl_p2p_allreduce_f32: seq = 1, 2, 3, ... the same on every
+ * rank) or kept in the buffer itself (pbl_p2p_allreduce_f32_dev): the launch then has no per-call argument, so it can be
+ * captured in a hipGraph together with the K-split GEMV in front of it and replayed; y_f16 (optional, device, n halves)
+ * additionally receives the sum rounded to fp16 -- the K-split layer's output dtype -- which saves the cast launch.  Use ONE of
+ * the two forms per buffer.  A wait that times out (3 s: a peer died or never launched) sets the buffer's status word
+ * (pbl_p2p_check) and writes NaN over the slice: a wrong sum is never silent. */
 #define PBL_P2P_MAX_WORLD 16
 #define PBL_P2P_MAX_BLOCKS 64
 #define PBL_IPC_HANDLE_BYTES 64
 size_t pbl_p2p_buffer_bytes(size_t max_elems);
+size_t pbl_p2p_buffer_bytes_world(size_t max_elems, int world);
 int pbl_comm_alloc(size_t bytes, void** dev_ptr_out);          /* zero-filled device memory, uncached where supported */
 int pbl_comm_free(void* dev_ptr);
 int pbl_ipc_export(void* dev_ptr, void* handle64_out);
@@ -397,6 +412,8 @@ int pbl_ipc_open(const void* handle64, void** dev_ptr_out);
 int pbl_ipc_close(void* dev_ptr);
 int pbl_p2p_allreduce_f32(void* const* peer_bufs, int rank, int world, float* x, size_t n, size_t max_elems, uint32_t seq,
                           void* stream);
+int pbl_p2p_allreduce_f32_dev(void* const* peer_bufs, int rank, int world, float* x, void* y_f16, size_t n, size_t max_elems,
+                              void* stream);
 int pbl_p2p_check(const void* own_buf);                        /* SYNCHRONOUS debugging aid: 1 if a wait ever timed out */
 
 #ifdef __cplusplus

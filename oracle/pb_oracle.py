@@ -266,23 +266,11 @@ def ptq_rtn(W: np.ndarray, mask: np.ndarray, high_bit: int = 8, groupsize: int =
     return dict(W_fq=out, mean=mean, scale=scale, hscale=hscale, hzero=hzero)
 
 
-def ptq_gptq(W: np.ndarray, H: np.ndarray, low_frac: float, metric: str = "magnitude",
-             high_bit: int = 8, groupsize: int = -1, blocksize: int = 128, percdamp: float = 0.01):
-    """Full LowHighGPT.fasterquant with GPTQ error feedback (gptq_pb/gptq.py:54-187).
-    numpy float32 restatement of the blocked column loop (:129-168)."""
-    W = W.astype(F32).copy()
+def gptq_blocks(W: np.ndarray, U: np.ndarray, mask: np.ndarray, hscale, hzero, maxq, mean, scale, gs: int, blocksize: int = 128):
+    """The blocked column loop of LowHighGPT.fasterquant (gptq_pb/gptq.py:129-168) IN PLACE on W (fp32 [N, K]) for a given
+    upper Cholesky factor U of H^-1, low mask and quantizer state; returns the per-row losses (:160,166).  Split out of
+    ptq_gptq so that the loop can be checked against the reference with the reference's own U (golden G5 stores it)."""
     N, K = W.shape
-    gs = K if groupsize == -1 else groupsize
-    G = math.ceil(K / gs)
-    hscale, hzero, maxq = high_calibrate(W, high_bit)              # :62-63
-    U, dead = hinv_cholesky_upper(H, percdamp)                     # :67-81
-    W[:, dead] = 0
-    mask = ptq_low_mask(W, low_frac, metric, np.diag(U), groupsize)  # :83-99
-    mean = np.zeros((G, N, 1), F32)
-    scale = np.zeros((G, N, 1), F32)
-    for g in range(G):
-        st, ed = g * gs, min((g + 1) * gs, K)
-        mean[g], scale[g] = low_xnor_calibrate((W[:, st:ed] * mask[:, st:ed]).astype(F32))
     losses = np.zeros(N, F32)
     for c0 in range(0, K, blocksize):
         c1 = min(c0 + blocksize, K)
@@ -307,6 +295,27 @@ def ptq_gptq(W: np.ndarray, H: np.ndarray, low_frac: float, metric: str = "magni
         W[:, c0:c1] = Q1
         losses += L1.sum(1) / 2
         W[:, c1:] -= E1 @ U[c0:c1, c1:]
+    return losses
+
+
+def ptq_gptq(W: np.ndarray, H: np.ndarray, low_frac: float, metric: str = "magnitude",
+             high_bit: int = 8, groupsize: int = -1, blocksize: int = 128, percdamp: float = 0.01):
+    """Full LowHighGPT.fasterquant with GPTQ error feedback (gptq_pb/gptq.py:54-187).
+    numpy float32 restatement of the blocked column loop (:129-168)."""
+    W = W.astype(F32).copy()
+    N, K = W.shape
+    gs = K if groupsize == -1 else groupsize
+    G = math.ceil(K / gs)
+    hscale, hzero, maxq = high_calibrate(W, high_bit)              # :62-63
+    U, dead = hinv_cholesky_upper(H, percdamp)                     # :67-81
+    W[:, dead] = 0
+    mask = ptq_low_mask(W, low_frac, metric, np.diag(U), groupsize)  # :83-99
+    mean = np.zeros((G, N, 1), F32)
+    scale = np.zeros((G, N, 1), F32)
+    for g in range(G):
+        st, ed = g * gs, min((g + 1) * gs, K)
+        mean[g], scale[g] = low_xnor_calibrate((W[:, st:ed] * mask[:, st:ed]).astype(F32))
+    losses = gptq_blocks(W, U, mask, hscale, hzero, maxq, mean, scale, gs, blocksize)
     return dict(W_fq=W, mask=mask, mean=mean, scale=scale, hscale=hscale, hzero=hzero,
                 loss=float(losses.astype(np.float64).sum()), hinv_diag=np.diag(U).copy())
 

@@ -49,11 +49,11 @@ _lib = None
 
 EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_pack_dev_count", "pbl_pack_dev_write", "pbl_blob_describe",
            "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_linear_f16_ws", "pbl_gemm_mfma_f16",
-           "pbl_gemm_mfma_f16_ws", "pbl_mfma_workspace_bytes", "pbl_linear_workspace_bytes", "pbl_gemv_f16_grouped", "pbl_gemv_f16_fused", "pbl_gemv_f16_fused_host", "pbl_gemm_f16", "pbl_gemm_f16_ex",
+           "pbl_gemm_mfma_f16_ws", "pbl_mfma_workspace_bytes", "pbl_linear_workspace_bytes", "pbl_gemv_f16_grouped", "pbl_gemv_f16_fused", "pbl_gemv_f16_fused_host", "pbl_gemm_f16", "pbl_gemm_f16_ex", "pbl_gemm_f16_ws", "pbl_gemm_workspace_bytes",
            "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad",
            "pbl_prep_workspace_bytes", "pbl_kth_pair", "pbl_outlier_mask", "pbl_quant8_rows", "pbl_high_calibrate", "pbl_gptq_block",
            "pbl_p2p_buffer_bytes", "pbl_comm_alloc", "pbl_comm_free", "pbl_ipc_export", "pbl_ipc_open", "pbl_ipc_close",
-           "pbl_p2p_allreduce_f32", "pbl_p2p_check"]
+           "pbl_p2p_allreduce_f32", "pbl_p2p_allreduce_f32_dev", "pbl_p2p_buffer_bytes_world", "pbl_p2p_check"]
 
 
 def lib() -> C.CDLL:
@@ -103,6 +103,10 @@ def lib() -> C.CDLL:
     L.pbl_gemm_f16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, vp]
     L.pbl_gemm_f16_ex.restype = C.c_int
     L.pbl_gemm_f16_ex.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
+    L.pbl_gemm_f16_ws.restype = C.c_int
+    L.pbl_gemm_f16_ws.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, sz, vp]
+    L.pbl_gemm_workspace_bytes.restype = sz
+    L.pbl_gemm_workspace_bytes.argtypes = [C.POINTER(PblLayer), C.c_int]
     L.pbl_gemv_f16_fused.restype = C.c_int
     L.pbl_gemv_f16_fused.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, u32, u32, u32, u32, C.c_int, C.c_int, vp]
     L.pbl_gemv_f16_fused_host.restype = C.c_int
@@ -141,6 +145,10 @@ def lib() -> C.CDLL:
     L.pbl_ipc_close.argtypes = [vp]
     L.pbl_p2p_allreduce_f32.restype = C.c_int
     L.pbl_p2p_allreduce_f32.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp, sz, sz, u32, vp]
+    L.pbl_p2p_allreduce_f32_dev.restype = C.c_int
+    L.pbl_p2p_allreduce_f32_dev.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp, vp, sz, sz, vp]
+    L.pbl_p2p_buffer_bytes_world.restype = sz
+    L.pbl_p2p_buffer_bytes_world.argtypes = [sz, C.c_int]
     L.pbl_p2p_check.restype = C.c_int
     L.pbl_p2p_check.argtypes = [vp]
     _lib = L

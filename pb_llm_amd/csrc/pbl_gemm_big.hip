@@ -43,7 +43,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #define GW 64
-#define NCONS 4                   // consumer (MFMA) waves: 64 tokens each
+#ifndef NCONS
+#define NCONS 8                   // consumer (MFMA) waves: 256 / NCONS tokens each.  8 = two per SIMD: one's waits are the other's MFMAs
+#endif
+#define GB_TPC (256 / NCONS)      // tokens per consumer wave (64 / 32)
+#define GB_TT (GB_TPC / 32)       // 32-token accumulator tiles per consumer (2 / 1)
+#define GB_PQ (GB_TPC / 8)        // 1 KiB DMA pieces per x slot (8 / 4)
 #define NPROD 4                   // producer (expand) waves: 2 records each
 #define NREC 8                    // records per workgroup tile
 #define GB_ROWS (NREC * 16)
@@ -52,12 +57,13 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define GB_XC 64                  // columns per x slot (sub-step)
 #define GB_XSLOTS 3
 #define GB_AS_STAGE (GB_ROWS * GB_HS * 2)          // 32768 B
-#define GB_XSLOT_BYTES (64 * GB_XC * 2)            // 8192 B: 64 tokens x 64 columns
+#define GB_XSLOT_BYTES (GB_TPC * GB_XC * 2)         // 8192 / 4096 B: the consumer's tokens x 64 columns
 #define GB_XRING_BYTES (GB_XSLOTS * GB_XSLOT_BYTES)
 #define GB_X_OFF (2 * GB_AS_STAGE)
 #define GB_LDS (GB_X_OFF + NCONS * GB_XRING_BYTES)  // 163840 B
 // performance-analysis hook (tools/build_variant.sh): bit 0 no expansion in the loop, 1 no x staging in the loop, 2 no MFMA,
-// 3 no sign-plane expansion, 4 no salient overlay, 5 producers request nothing either (consumer loop alone).  0 in every
+// 3 no sign-plane expansion, 4 no salient overlay, 5 producers request nothing either (consumer loop alone), 6 no fragment
+// reads in the loop, 7 no barriers in the loop.  0 in every
 // shipped build (results are wrong otherwise).
 #ifndef PBL_GEMM_ABLATE
 #define PBL_GEMM_ABLATE 0
@@ -65,6 +71,11 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // consumers at raised wave priority (measured variants: tools/build_variant.sh)
 #ifndef PBL_GEMM_PRIO
 #define PBL_GEMM_PRIO 0
+#endif
+// producers at raised wave priority: their ~200 VALU / LDS instructions per half slab otherwise get the issue slots the MFMA
+// waves of the same SIMD leave over, and the stage (hence the barrier, hence the MFMA waves) is late
+#ifndef PBL_GEMM_PPRIO
+#define PBL_GEMM_PPRIO 1
 #endif
 
 namespace {
@@ -80,6 +91,11 @@ struct GemmArgs {
     const _Float16* x;      // [M, K]
     void* y;                // [M, N] fp16 / fp32
     int M, y_f32;
+    // LIST mode (pbl_gemm_f16_ws): the salient entries of every (record, half slab) as ready-to-store words, built once per
+    // call by pbl_gemm_prep_kernel
+    const uint32_t* ofs;    // [NRB][ofs_stride]: entry ranges per half slab, ofs[rb][h] .. ofs[rb][h + 1]
+    const uint32_t* lst;    // [NRB][cap]: (byte offset in the record's 16 x 256-byte stage image << 16) | fp16 value
+    uint32_t ofs_stride, cap;
 };
 
 struct Seq { int fb, fn, tb, tn; };            // the row's full / tail chunks that overlap a slab: first index, count
@@ -95,7 +111,7 @@ struct QuarterQ {
     uint32_t dd, q, off0;   // off0: byte offset in a 2 K-byte fp16 row of the entry BEFORE this quarter's first (0x40000000: no chunk)
 };
 
-#define GB_PRE 4            // chunk rounds of a slab kept in registers (more rounds are fetched when they are needed: rare)
+#define GB_PRE 3            // chunk rounds of a slab kept in registers (more rounds are fetched when they are needed; 3 keeps the 12-wave build free of spills)
 
 // the chunks of one record that overlap one 256-column slab, as a producer lane holds them
 struct SlabData {
@@ -144,7 +160,8 @@ __device__ __forceinline__ ChunkQ load_chunkq(const Rec& R, const Seq& sq, int j
     if (c >= 0) { r.d4 = R.deltap[c]; r.q = R.codew[4 * c + sub]; r.col0 = int(R.col0p[c]); }
     return r;
 }
-__device__ __forceinline__ uint32_t load_dw(const Rec& R, int h, int P) {      // dword (h & 3) of panel h >> 2 for this lane
+template <typename REC>
+__device__ __forceinline__ uint32_t load_dw(const REC& R, int h, int P) {      // dword (h & 3) of panel h >> 2 for this lane
     return (h >> 2) < P ? __builtin_nontemporal_load(R.tile_dw + size_t(h >> 2) * 256 + (h & 3)) : 0u;
 }
 // request the chunks of slab sn (its first GB_PRE rounds); the slab-index entry of the slab after it rides along
@@ -209,9 +226,8 @@ __device__ __forceinline__ void scatter_q(const QuarterQ& c, uint32_t cb2, uint3
 
 // sign plane of one half slab of record R -> rows of the stage at LDS byte address recaddr (a multiple of 4096): lane l
 // holds columns 2l, 2l+1 of all 16 rows in ONE dword (include/pbl.h: bit 16 e + pos)
-template <bool TAIL>
-__device__ __forceinline__ void expand_sign(const Rec& R, char* smem, uint32_t recaddr, int lane, int kpairs /* valid column pairs */) {
-    const uint32_t d = R.dcur;
+template <bool TAIL, typename REC>
+__device__ __forceinline__ void expand_sign(const REC& R, uint32_t d, char* smem, uint32_t recaddr, int lane, int kpairs /* valid column pairs */) {
     // unit (l >> 2) ^ row, dword l & 3:  recaddr + 256 row + (((l >> 2) ^ row) << 4) + 4 (l & 3)  ==  v ^ (0x110 row)
     const uint32_t v = recaddr + (uint32_t(lane >> 2) << 4) + (uint32_t(lane & 3) << 2);
 #pragma unroll
@@ -291,17 +307,211 @@ __device__ __forceinline__ void init_rec(Rec& R, const pbl_layer& L, uint32_t rb
     load_levels(R, L.G, 0, lane);
 }
 
-// ---- consumer helpers -------------------------------------------------------------------------------------------------
-struct Frag { v8h a[4], b[2]; };
+// ---- LIST mode ---------------------------------------------------------------------------------------------------------
+// A workgroup of the GEMM kernel decodes a record's salient chunks once per token tile and per half slab; at seq 2048 that is
+// 8 x 2 decodes of the same chunk, by ONE producer wave whose in-order stream is the kernel's critical path (measured: 4096^2,
+// 5 % salients: 102 us with the decode in the loop, 77 us without it).  So calls with more than one token tile decode ONCE, in
+// a small kernel ahead of the GEMM: per (record, half slab) the entries become 4-byte words {offset in the stage image : fp16
+// value} in a transient workspace (4 B per entry; the dense weight is 2 B per WEIGHT), and the GEMM's producers only copy them.
+// One workgroup per record: count per half slab (LDS atomics), scan, fill.  Entry order inside a half slab is arbitrary:
+// positions are distinct (tail padding repeats an entry with the same value), so the image is deterministic.
+#define GB_LIST_MAX_NH 127          // entry ranges live in two registers per lane (NH + 1 <= 128): K <= 16256
+#define GB_LPF 4                    // entry words per lane requested ahead: 256 entries of a (record, half slab) -- 12.5 % salients,
+                                    // or the hot columns of a hessian mask (16 rows x 16 salient columns) -- never wait in the loop
 
-__device__ __forceinline__ void load_frag(Frag& f, const char* smem, uint32_t aaddr, uint32_t baddr) {
+#define GB_PREP_THREADS 1024
+__global__ __launch_bounds__(GB_PREP_THREADS) void pbl_gemm_prep_kernel(pbl_layer L, uint32_t* __restrict__ ofs, uint32_t* __restrict__ lst,
+                                                                         uint32_t ofs_stride, uint32_t cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    // LDS: cnt[128] cur[128] (u32), ss[16] sz[16] (f32), rowinfo[16], crow[nch] (u8: the row each chunk belongs to)
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem_p);
+    uint32_t* s_cur = s_cnt + (GB_LIST_MAX_NH + 1);
+    float* s_ss = reinterpret_cast<float*>(s_cur + (GB_LIST_MAX_NH + 1));
+    float* s_sz = s_ss + 16;
+    pbl_rowinfo* s_ri = reinterpret_cast<pbl_rowinfo*>(s_sz + 16);
+    uint8_t* s_crow = reinterpret_cast<uint8_t*>(s_ri + 16);
+    const uint32_t rb = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int NH = int((L.K + GB_HS - 1) / GB_HS);
+    const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
+    const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[rb];
+    const uint8_t* rec = blob + size_t(info.x) * 16;
+    const int nfull = int(info.y), ntail = int(info.z), nexc = int(info.w), nch = nfull + ntail;
+    const uint32_t nchu = uint32_t(nch);
+    const bool has_crow = (L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16)) != 0;
+    const uint8_t* sal = rec + PBL_TILES_OFF(L.G) + L.P * 1024u;
+    const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
+    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + PBL_SAL_DELTA_OFF(nchu));
+    const uint32_t* codew = reinterpret_cast<const uint32_t*>(sal + PBL_SAL_CODE_OFF(nchu));
+    const uint2* exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), has_crow));
+    // this thread's first unit (chunk u >> 2, quarter u & 3): requested before anything else is waited for
+    const int u0 = tid;
+    u32x4 d4 = {0, 0, 0, 0};
+    uint32_t q0 = 0, c00 = 0;
+    if (u0 < 4 * nch) { d4 = deltap[u0 >> 2]; q0 = codew[u0]; c00 = col0p[u0 >> 2]; }
+    if (tid < 16) {
+        s_ri[tid] = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF)[tid];
+        const pbl_rowparams ps = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF)[tid];
+        s_ss[tid] = ps.sscale; s_sz[tid] = ps.szero;
+    }
+    for (int h = tid; h <= NH; h += GB_PREP_THREADS) { s_cnt[h] = 0; s_cur[h] = 0; }
+    __syncthreads();
+    for (int r = 0; r < 16; ++r) {                           // chunk -> row (rowinfo: full chunks [start, +nfull), tails [tailidx, +ntail))
+        const pbl_rowinfo ri = s_ri[r];
+        for (int k = tid; k < int(ri.nfull) + int(ri.ntail); k += GB_PREP_THREADS)
+            s_crow[k < int(ri.nfull) ? int(ri.start) + k : nfull + int(ri.tailidx) + (k - int(ri.nfull))] = uint8_t(r);
+    }
+    __syncthreads();
+    uint32_t* out = lst + size_t(rb) * cap;
+    // pass 0 counts, pass 1 writes; a quarter's entries are column sorted, so runs inside one half slab share one atomic
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int u = tid; u < 4 * nch; u += GB_PREP_THREADS) {
+            const int c = u >> 2, sub = u & 3;
+            u32x4 dv = d4; uint32_t q = q0, cc = c00;
+            if (u != u0) { dv = deltap[c]; q = codew[u]; cc = col0p[c]; }       // (more than 256 chunks in the record)
+            const uint32_t row = s_crow[c];
+            uint32_t pre = 0;
+            pre = sub > 0 ? __builtin_amdgcn_sad_u8(dv[0], 0u, pre) : pre;
+            pre = sub > 1 ? __builtin_amdgcn_sad_u8(dv[1], 0u, pre) : pre;
+            pre = sub > 2 ? __builtin_amdgcn_sad_u8(dv[2], 0u, pre) : pre;
+            const uint32_t dd = sub == 0 ? dv[0] : (sub == 1 ? dv[1] : (sub == 2 ? dv[2] : dv[3]));
+            uint32_t off[4];
+            off[0] = 2u * cc + pre + (dd & 0xFFu);           // byte offsets in the fp16 row
+            off[1] = off[0] + ((dd >> 8) & 0xFFu); off[2] = off[1] + ((dd >> 16) & 0xFFu); off[3] = off[2] + (dd >> 24);
+            const float ss = s_ss[row], sz = s_sz[row];
+            uint32_t pos = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t h = off[e] >> 8;
+                const bool first = e == 0 || h != (off[e - 1] >> 8);
+                if (first) {                                 // entries e .. of this quarter in half slab h
+                    uint32_t run = 1;
+#pragma unroll
+                    for (int f = e + 1; f < 4; ++f) run += (off[f] >> 8) == h ? 1u : 0u;
+                    if (pass == 0) atomicAdd(&s_cnt[h], run);
+                    else pos = s_cnt[h] + atomicAdd(&s_cur[h], run);
+                }
+                if (pass == 1) {
+                    const float qf = float((q >> (8 * e)) & 0xFFu);
+                    const uint32_t v = uint32_t(__builtin_bit_cast(uint16_t, round_f16_twice(ss * (qf - sz))));
+                    out[pos++] = ((row * 256u + ((off[e] & 0xFFu) ^ (row << 4))) << 16) | v;
+                }
+            }
+        }
+        for (int k = tid; k < nexc; k += GB_PREP_THREADS) {
+            const uint2 ex = exc[k];
+            const uint32_t col = ex.x & 0xFFFFu, row = ex.x >> 16, h = col >> 7, o = (2u * col) & 0xFFu;
+            if (pass == 0) atomicAdd(&s_cnt[h], 1u);
+            else {
+                const uint32_t v = uint32_t(__builtin_bit_cast(uint16_t, _Float16(__builtin_bit_cast(float, ex.y))));
+                out[s_cnt[h] + atomicAdd(&s_cur[h], 1u)] = ((row * 256u + (o ^ (row << 4))) << 16) | v;
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            // exclusive scan of the NH counts by wave 0 (two elements per lane)
+            if (tid < 64) {
+                const uint32_t a0 = 2 * tid < NH ? s_cnt[2 * tid] : 0u, a1 = 2 * tid + 1 < NH ? s_cnt[2 * tid + 1] : 0u;
+                uint32_t incl = a0 + a1;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(incl, d, 64);
+                    if (tid >= d) incl += t;
+                }
+                const uint32_t excl = incl - (a0 + a1);
+                if (2 * tid <= NH) s_cnt[2 * tid] = excl;
+                if (2 * tid + 1 <= NH) s_cnt[2 * tid + 1] = excl + a0;
+            }
+            __syncthreads();
+            for (int h = tid; h <= NH; h += GB_PREP_THREADS) ofs[size_t(rb) * ofs_stride + h] = s_cnt[h];
+        }
+    }
+}
+
+// what a producer keeps per record in LIST mode
+struct RecL {
+    const uint32_t* lst;    // the record's entry words
+    const uint32_t* tile_dw;
+    const pbl_rowparams* params;
+    const float2* ghl;
+    uint32_t ofs0, ofs1;    // lane l: ofs[l], ofs[64 + l]  (entry ranges of all half slabs)
+    // even / odd stages keep their own registers: a stage's registers are re-requested for the stage after next right after
+    // their last use, so a request has two stages to land and is never touched (copied) before it is needed
+    uint32_t d[2];          // sign-plane dword
+    uint32_t e[2][GB_LPF];  // entries lane, lane + 64, ... of the stage's range
+    uint32_t hl[16];
+};
+__device__ __forceinline__ uint32_t ofs_at(const RecL& R, int h) {          // wave uniform
+    return h < 64 ? __builtin_amdgcn_readlane(R.ofs0, h) : __builtin_amdgcn_readlane(R.ofs1, h - 64);
+}
+__device__ __forceinline__ void request_list(const RecL& R, int h, int NH, int lane, uint32_t (&e)[GB_LPF]) {
+#pragma unroll
+    for (int k = 0; k < GB_LPF; ++k) e[k] = 0;
+    if (h >= NH) return;
+    const uint32_t lo = ofs_at(R, h), n = ofs_at(R, h + 1) - lo;
+#pragma unroll
+    for (int k = 0; k < GB_LPF; ++k)
+        if (uint32_t(lane) + 64u * k < n) e[k] = R.lst[lo + lane + 64 * k];
+}
+__device__ __forceinline__ void store_entry(char* smem, uint32_t recaddr, uint32_t w) {
+    *reinterpret_cast<uint16_t*>(smem + recaddr + (w >> 16)) = uint16_t(w & 0xFFFFu);
+}
+// the half slab's salient and exception words over the plane the same wave has just written
+__device__ __forceinline__ void expand_list(const RecL& R, int h, const uint32_t (&e)[GB_LPF], char* smem, uint32_t recaddr, int lane) {
+    const uint32_t lo = ofs_at(R, h), n = ofs_at(R, h + 1) - lo;
+#pragma unroll
+    for (int k = 0; k < GB_LPF; ++k)
+        if (__any(uint32_t(lane) + 64u * k < n)) {             // (wave uniform: most half slabs stop after one or two)
+            if (uint32_t(lane) + 64u * k < n) store_entry(smem, recaddr, e[k]);
+        }
+    for (uint32_t i = 64u * GB_LPF + uint32_t(lane); __any(i < n); i += 64u)
+        if (i < n) store_entry(smem, recaddr, R.lst[lo + i]);
+    asm volatile("" ::: "memory");
+}
+template <typename REC>
+__device__ __forceinline__ void load_levels_t(REC& R, uint32_t G, uint32_t g, int lane) {
+    float hi, lo;
+    if (G > 1) { const float2 v = R.ghl[size_t(lane & 15) * G + g]; hi = v.x; lo = v.y; }
+    else { const pbl_rowparams pr = R.params[lane & 15]; hi = pr.hi; lo = pr.lo; }
+    const uint32_t hh = h16(hi), ll = h16(lo);
+    const uint32_t w = (((hh - ll) & 0xFFFFu) << 16) | ll;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R.hl[r] = __builtin_amdgcn_readlane(w, r);
+}
+// start-up in two phases so that the requests of BOTH records of a wave are in flight together (a wave that finishes one
+// record's dependent chain before it starts the other's pays four memory round trips instead of two)
+__device__ __forceinline__ uint4 init_list_a(RecL& R, const GemmArgs& a, uint32_t rb, int NH, int lane) {
+    const uint8_t* blob = static_cast<const uint8_t*>(a.L.blob);
+    const uint32_t* ofs = a.ofs + size_t(rb) * a.ofs_stride;
+    R.ofs0 = lane <= NH ? ofs[lane] : 0u;
+    R.ofs1 = lane + 64 <= NH ? ofs[lane + 64] : 0u;
+    R.lst = a.lst + size_t(rb) * a.cap;
+    return reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[rb];
+}
+__device__ __forceinline__ void init_list_b(RecL& R, const GemmArgs& a, const uint4& info, int NH, int lane) {
+    const pbl_layer& L = a.L;
+    const uint8_t* rec = static_cast<const uint8_t*>(L.blob) + size_t(__builtin_amdgcn_readfirstlane(info.x)) * 16;
+    R.tile_dw = reinterpret_cast<const uint32_t*>(rec + PBL_TILES_OFF(L.G)) + lane * 4;
+    R.params = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
+    R.ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
+    R.d[0] = load_dw(R, 0, int(L.P));
+    R.d[1] = load_dw(R, 1, int(L.P));
+    request_list(R, 0, NH, lane, R.e[0]);
+    request_list(R, 1, NH, lane, R.e[1]);
+}
+
+// ---- consumer helpers -------------------------------------------------------------------------------------------------
+struct Frag { v8h a[4], b[GB_TT]; };
+
+__device__ __forceinline__ void load_frag(Frag& f, const char* smem, uint32_t aaddr, uint32_t baddr, bool inloop = true) {
+    if ((PBL_GEMM_ABLATE & 64) && inloop) { asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0])); return; }
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) f.a[rt] = *reinterpret_cast<const v8h*>(smem + aaddr + rt * 8192);
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) f.b[tt] = *reinterpret_cast<const v8h*>(smem + baddr + tt * 4096);
+    for (int tt = 0; tt < GB_TT; ++tt) f.b[tt] = *reinterpret_cast<const v8h*>(smem + baddr + tt * 4096);
 }
 
-template <bool Y32>
+template <bool Y32, bool LIST>
 __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -321,10 +531,52 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
     if (wave >= NCONS) {
         // =================================== producer waves =========================================================
         const int p = wave - NCONS;
+        const uint32_t gs = L.K / L.G;                            // columns per group (a multiple of 128)
+#if PBL_GEMM_PPRIO
+        __builtin_amdgcn_s_setprio(PBL_GEMM_PPRIO);
+#endif
+        if constexpr (LIST) {
+            // the salient entries come ready to store from the per-call workspace (pbl_gemm_prep_kernel)
+            RecL R[2];
+            uint4 info[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) info[i] = init_list_a(R[i], a, min(rowblk * NREC + 2 * p + i, L.NRB - 1), NH, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) init_list_b(R[i], a, info[i], NH, lane);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) load_levels_t(R[i], L.G, 0, lane);
+            auto produce = [&](int h, auto par_tag) {             // stage h from register set PAR = h & 1
+                constexpr int PAR = decltype(par_tag)::value;
+                const uint32_t stage = uint32_t(PAR) * GB_AS_STAGE;
+                const int kpairs = min(GB_HS, K - h * GB_HS) >> 1;
+                const bool work = !(PBL_GEMM_ABLATE & 1) || h == 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const uint32_t recaddr = stage + uint32_t(2 * p + i) * 4096u;
+                    if (work && !(PBL_GEMM_ABLATE & 8)) {
+                        if (kpairs < GB_HS / 2) expand_sign<true>(R[i], R[i].d[PAR], smem_b, recaddr, lane, kpairs);
+                        else expand_sign<false>(R[i], R[i].d[PAR], smem_b, recaddr, lane, kpairs);
+                    }
+                    if (work && !(PBL_GEMM_ABLATE & 16)) expand_list(R[i], h, R[i].e[PAR], smem_b, recaddr, lane);
+                    if (!(PBL_GEMM_ABLATE & 32)) {            // this set's next use: stage h + 2
+                        R[i].d[PAR] = load_dw(R[i], h + 2, int(L.P));
+                        request_list(R[i], h + 2, NH, lane, R[i].e[PAR]);
+                    }
+                    if (L.G > 1 && h + 1 < NH && uint32_t((h + 1) * GB_HS) % gs == 0) load_levels_t(R[i], L.G, uint32_t((h + 1) * GB_HS) / gs, lane);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the stage is in LDS
+                if (!(PBL_GEMM_ABLATE & 128) || h == 0) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            };
+            for (int h = 0; h < NH; h += 2) {
+                produce(h, std::integral_constant<int, 0>{});
+                if (h + 1 < NH) produce(h + 1, std::integral_constant<int, 1>{});
+            }
+            return;
+        }
         Rec R[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) init_rec(R[i], L, min(rowblk * NREC + 2 * p + i, L.NRB - 1), lane);   // (a record beyond the layer mirrors the last one; its rows are never stored)
-        const uint32_t gs = L.K / L.G;                            // columns per group (a multiple of 128)
         // stage 0, then one stage ahead of the consumers; barrier b (b = 0 .. NH-1) closes stage b
         for (int h = 0; h < NH; ++h) {
             const uint32_t stage = uint32_t(h & 1) * GB_AS_STAGE;
@@ -334,8 +586,8 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
             for (int i = 0; i < 2; ++i) {
                 const uint32_t recaddr = stage + uint32_t(2 * p + i) * 4096u;
                 if (work && !(PBL_GEMM_ABLATE & 8)) {
-                    if (kpairs < GB_HS / 2) expand_sign<true>(R[i], smem_b, recaddr, lane, kpairs);
-                    else expand_sign<false>(R[i], smem_b, recaddr, lane, kpairs);
+                    if (kpairs < GB_HS / 2) expand_sign<true>(R[i], R[i].dcur, smem_b, recaddr, lane, kpairs);
+                    else expand_sign<false>(R[i], R[i].dcur, smem_b, recaddr, lane, kpairs);
                 }
                 if (work && !(PBL_GEMM_ABLATE & 16)) expand_sal(R[i], h, smem_b, recaddr, lane);
             }
@@ -369,11 +621,11 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
     __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, int(xrem), 0x00020000);
     // DMA piece q (1 KiB) of a slot = tokens 8q .. 8q+7 x 128 B; lane l lands on unit l & 7 of token 8q + (l >> 3), which holds
     // the LOGICAL unit (l & 7) ^ ((token >> 1) & 7)
-    uint32_t xvoff[8];
+    uint32_t xvoff[GB_PQ];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const uint32_t tl = uint32_t(8 * q + (lane >> 3));                           // token within the wave's 64
-        xvoff[q] = (uint32_t(64 * c) + tl) * uint32_t(K) * 2u + ((uint32_t(lane & 7) ^ ((tl >> 1) & 7)) << 4);
+    for (int q = 0; q < GB_PQ; ++q) {
+        const uint32_t tl = uint32_t(8 * q + (lane >> 3));                           // token within the wave's own
+        xvoff[q] = (uint32_t(GB_TPC * c) + tl) * uint32_t(K) * 2u + ((uint32_t(lane & 7) ^ ((tl >> 1) & 7)) << 4);
     }
     // K % 64 != 0: the units of the LAST sub-step that lie beyond K would hold the next token row; their source offset is
     // pushed out of the descriptor's range instead, so they read zeros (and the producers zero the weights there too).
@@ -396,11 +648,11 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
 #pragma unroll
     for (int k = 0; k < 4; ++k) bq[k] = xring + uint32_t(i32) * 128u + ((uint32_t(2 * k + g) ^ uint32_t((i32 >> 1) & 7)) << 4);
 
-    v16f acc[4][2];
+    v16f acc[4][GB_TT];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < GB_TT; ++tt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[rt][tt][e] = 0.f;
 
@@ -409,18 +661,19 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
     for (int u = 0; u < GB_XSLOTS; ++u)
         if (u < NU)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) issue_x(u, q);
+            for (int q = 0; q < GB_PQ; ++q) issue_x(u, q);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // slot 0 has landed when at most the pieces of sub-steps 1, 2 are outstanding
-    if (NU >= 3) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (NU == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (NU >= 3) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else if (NU == 2) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if PBL_GEMM_PRIO
     __builtin_amdgcn_s_setprio(PBL_GEMM_PRIO);
 #endif
     Frag f0, f1;
-    load_frag(f0, smem_b, aq[0], bq[0]);      // (stage 0, first half: no offsets)
+    load_frag(f0, smem_b, aq[0], bq[0], false);      // (stage 0, first half: no offsets)
+    if (PBL_GEMM_ABLATE & 64) load_frag(f1, smem_b, aq[1], bq[1], false);
 
     // One 64-column sub-step = 4 k-steps of 16 columns; fragments of k-step kk+1 are read while k-step kk multiplies.
     auto mma = [&](const Frag& f) {
@@ -428,7 +681,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
+                for (int tt = 0; tt < GB_TT; ++tt)
                     acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[rt], f.b[tt], acc[rt][tt], 0, 0, 0);
         }
     };
@@ -436,27 +689,27 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
         const uint32_t abuf = uint32_t((u >> 1) & 1) * GB_AS_STAGE, ahalf = uint32_t(u & 1) * 128u;
         const uint32_t xslot = uint32_t(u % GB_XSLOTS) * GB_XSLOT_BYTES;
         const bool last = u + 1 >= NU;
-        // pieces of sub-step u+2's x go out two per k-step: its slot, (u+2) % 3 == (u-1) % 3, was last read in sub-step u-1
+        // pieces of sub-step u+2's x go out GB_PQ / 4 per k-step: its slot, (u+2) % 3 == (u-1) % 3, was last read in sub-step u-1
         const bool stage_x = !(PBL_GEMM_ABLATE & 2) && u >= 1 && u + 2 < NU;
         // k-step 0
         load_frag(f1, smem_b, (aq[1] ^ ahalf) + abuf, bq[1] + xslot);
-        if (stage_x) { issue_x(u + 2, 0); issue_x(u + 2, 1); }
+        if (stage_x) { issue_x(u + 2, 0 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 0 * 2 + 1); }
         mma(f0);
         // k-step 1
         load_frag(f0, smem_b, (aq[2] ^ ahalf) + abuf, bq[2] + xslot);
-        if (stage_x) { issue_x(u + 2, 2); issue_x(u + 2, 3); }
+        if (stage_x) { issue_x(u + 2, 1 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 1 * 2 + 1); }
         mma(f1);
         // k-step 2
         load_frag(f1, smem_b, (aq[3] ^ ahalf) + abuf, bq[3] + xslot);
-        if (stage_x) { issue_x(u + 2, 4); issue_x(u + 2, 5); }
+        if (stage_x) { issue_x(u + 2, 2 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 2 * 2 + 1); }
         mma(f0);
         // k-step 3: every read of this sub-step's x slot -- and, in an odd sub-step, of the A stage -- has been issued
-        if (stage_x) { issue_x(u + 2, 6); issue_x(u + 2, 7); }
+        if (stage_x) { issue_x(u + 2, 3 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 3 * 2 + 1); }
         if (!last) {
             // x of sub-step u+1: its pieces were issued during sub-step u-1 (or in the prologue); younger: sub-step u+2's
-            if (u + 2 < NU) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (u + 2 < NU) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (u & 1) {
+            if ((u & 1) && !(PBL_GEMM_ABLATE & 128)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the stage have returned
                 __builtin_amdgcn_s_barrier();                            // ... the next stage is complete
                 asm volatile("" ::: "memory");
@@ -470,69 +723,119 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
     __builtin_amdgcn_s_setprio(0);
 #endif
 
-    // ---- epilogue, per consumer wave: accumulators (+ bias) -> Ys[32 tokens][128 rows] in the wave's own ring -> 16-byte stores
+    // ---- epilogue, per consumer wave: accumulators (+ bias) -> Ys[tokens][128 rows] in the wave's own ring -> 16-byte stores
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     typedef typename std::conditional<Y32, float, _Float16>::type yt;
-    constexpr uint32_t YSTR = Y32 ? 528u : 264u;              // bytes per token row: 128 rows + 16 / 8 B (conflict-free 16 / 8-byte writes)
+    constexpr uint32_t YSTR = Y32 ? 528u : 272u;              // bytes per token row: 128 rows + 16 B (every 16-byte read-back stays aligned)
+    constexpr int EPT = (32u * YSTR <= GB_XRING_BYTES) ? 32 : 16;     // tokens per pass: what the ring holds (fp32 result of 8 consumers: 16)
     const uint32_t row0 = rowblk * GB_ROWS;
     const bool vec = (L.N & (Y32 ? 3 : 7)) == 0 && row0 + GB_ROWS <= L.N;     // whole 16-byte units, all rows exist
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
+    for (int tt = 0; tt < GB_TT; ++tt) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int ph = 0; ph < 32 / EPT; ++ph) {
+            if (EPT == 32 || (i32 >> 4) == ph) {              // this lane's token (i32) belongs to the pass
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int rloc = rt * 32 + 8 * q4 + 4 * g;        // 4 consecutive rows held by this lane: D row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-                yt h[4];
+                for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t row = row0 + uint32_t(rloc + r);
-                    const float b = (L.bias && row < L.N) ? L.bias[row] : 0.f;
-                    h[r] = yt(acc[rt][tt][4 * q4 + r] + b);
-                }
-                char* dst = smem_b + xring + uint32_t(i32) * YSTR + uint32_t(rloc) * sizeof(yt);
-                if (Y32) *reinterpret_cast<v4f*>(dst) = v4f{float(h[0]), float(h[1]), float(h[2]), float(h[3])};
-                else {
-                    uint2 pk;
-                    pk.x = uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[0]))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[1]))) << 16);
-                    pk.y = uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[2]))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[3]))) << 16);
-                    *reinterpret_cast<uint2*>(dst) = pk;
-                }
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int rloc = rt * 32 + 8 * q4 + 4 * g;        // 4 consecutive rows held by this lane: D row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+                        yt h[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const uint32_t row = row0 + uint32_t(rloc + r);
+                            const float b = (L.bias && row < L.N) ? L.bias[row] : 0.f;
+                            h[r] = yt(acc[rt][tt][4 * q4 + r] + b);
+                        }
+                        char* dst = smem_b + xring + uint32_t(i32 & (EPT - 1)) * YSTR + uint32_t(rloc) * sizeof(yt);
+                        if (Y32) *reinterpret_cast<v4f*>(dst) = v4f{float(h[0]), float(h[1]), float(h[2]), float(h[3])};
+                        else {
+                            uint2 pk;
+                            pk.x = uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[0]))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[1]))) << 16);
+                            pk.y = uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[2]))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[3]))) << 16);
+                            *reinterpret_cast<uint2*>(dst) = pk;
+                        }
+                    }
             }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        constexpr int UPR = GB_ROWS * int(sizeof(yt)) / 16;      // 16-byte units per token row: 16 (fp16) / 32 (fp32)
-        for (int idx = lane; idx < 32 * UPR; idx += GW) {
-            const int t = idx / UPR, un = idx % UPR, tok = tok0 + 64 * c + 32 * tt + t;
-            if (tok >= M) continue;
-            constexpr int EPU = 16 / int(sizeof(yt));            // elements per unit
-            yt* dstg = static_cast<yt*>(a.y) + size_t(tok) * L.N + row0 + un * EPU;
-            const yt* src = reinterpret_cast<const yt*>(smem_b + xring + uint32_t(t) * YSTR) + un * EPU;
-            if (vec) *reinterpret_cast<u32x4*>(dstg) = *reinterpret_cast<const u32x4*>(src);
-            else
-                for (int e = 0; e < EPU; ++e)
-                    if (row0 + un * EPU + e < L.N) dstg[e] = src[e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int UPR = GB_ROWS * int(sizeof(yt)) / 16;      // 16-byte units per token row: 16 (fp16) / 32 (fp32)
+            for (int idx = lane; idx < EPT * UPR; idx += GW) {
+                const int t = idx / UPR, un = idx % UPR, tok = tok0 + GB_TPC * c + 32 * tt + EPT * ph + t;
+                if (tok >= M) continue;
+                constexpr int EPU = 16 / int(sizeof(yt));            // elements per unit
+                yt* dstg = static_cast<yt*>(a.y) + size_t(tok) * L.N + row0 + un * EPU;
+                const yt* src = reinterpret_cast<const yt*>(smem_b + xring + uint32_t(t) * YSTR) + un * EPU;
+                if (vec) *reinterpret_cast<u32x4*>(dstg) = *reinterpret_cast<const u32x4*>(src);
+                else
+                    for (int e = 0; e < EPU; ++e)
+                        if (row0 + un * EPU + e < L.N) dstg[e] = src[e];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done before the next pass overwrites the buffer
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done before the next half overwrites the buffer
     }
 }
 
 }  // namespace
 
-extern "C" int pbl_gemm_f16_ex(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream) {
+namespace {
+size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
+uint32_t list_cap(const pbl_layer* l) { return (16u * l->max_nch + l->max_nexc + 3u) & ~3u; }
+int check_layer(const pbl_layer* layer, const void* x, const void* y, int M) {
     if (!layer || !layer->blob || !x || !y || M < 1) return PBL_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(layer->blob) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
         return PBL_ERR_MISALIGNED;
     if ((layer->K & 7) || !(layer->flags & PBL_FLAG_SLABS) || !(layer->flags & PBL_FLAG_TAIL_REPEAT)) return PBL_ERR_UNSUPPORTED;
     if (layer->G < 1 || (layer->G > 1 && (layer->K % layer->G || (layer->K / layer->G) % GB_HS))) return PBL_ERR_UNSUPPORTED;
+    return PBL_OK;
+}
+}  // namespace
+
+// Bytes of transient device workspace pbl_gemm_f16_ws wants for M rows of x: the per-(record, half slab) entry ranges and
+// 4-byte entry words of LIST mode.  0: the call decodes inside the GEMM kernel (a single token tile, or a layer too wide for
+// the range registers) and needs no workspace.
+extern "C" size_t pbl_gemm_workspace_bytes(const pbl_layer* layer, int M) {
+    if (!layer || M <= GB_TOK) return 0;
+    const uint32_t NH = (layer->K + GB_HS - 1) / GB_HS;
+    if (NH > GB_LIST_MAX_NH) return 0;
+    const size_t ofs_stride = (NH + 1 + 3) & ~size_t(3);
+    return align16(size_t(layer->NRB) * ofs_stride * 4) + size_t(layer->NRB) * list_cap(layer) * 4;
+}
+
+extern "C" int pbl_gemm_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    const int st = check_layer(layer, x, y, M);
+    if (st != PBL_OK) return st;
     GemmArgs a;
     a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32;
-    const void* k = y_f32 ? reinterpret_cast<const void*>(pbl_gemm_kernel<true>) : reinterpret_cast<const void*>(pbl_gemm_kernel<false>);
+    a.ofs = nullptr; a.lst = nullptr; a.ofs_stride = 0; a.cap = 0;
+    const size_t want = pbl_gemm_workspace_bytes(layer, M);
+    const bool list = workspace && want && workspace_bytes >= want && !(reinterpret_cast<uintptr_t>(workspace) & 15);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (list) {
+        const uint32_t NH = (layer->K + GB_HS - 1) / GB_HS;
+        a.ofs_stride = (NH + 1 + 3) & ~3u;
+        a.cap = list_cap(layer);
+        uint32_t* ofs = static_cast<uint32_t*>(workspace);
+        uint32_t* lst = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + align16(size_t(layer->NRB) * a.ofs_stride * 4));
+        a.ofs = ofs; a.lst = lst;
+        pbl_layer lcopy = *layer;
+        void* pargv[] = {&lcopy, &ofs, &lst, &a.ofs_stride, &a.cap};
+        const size_t plds = size_t(2 * (GB_LIST_MAX_NH + 1)) * 4 + 32 * 4 + 16 * sizeof(pbl_rowinfo) + ((size_t(layer->max_nch) + 15) & ~size_t(15));
+        if (hipLaunchKernel(reinterpret_cast<const void*>(pbl_gemm_prep_kernel), dim3(layer->NRB), dim3(GB_PREP_THREADS), pargv, plds, s) != hipSuccess)
+            return PBL_ERR_LAUNCH;
+    }
+    const void* k = list ? (y_f32 ? reinterpret_cast<const void*>(pbl_gemm_kernel<true, true>) : reinterpret_cast<const void*>(pbl_gemm_kernel<false, true>))
+                         : (y_f32 ? reinterpret_cast<const void*>(pbl_gemm_kernel<true, false>) : reinterpret_cast<const void*>(pbl_gemm_kernel<false, false>));
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(GB_LDS)) != hipSuccess) return PBL_ERR_LAUNCH;
     void* argv[] = {&a};
     const dim3 grid(((layer->NRB + NREC - 1) / NREC) * uint32_t((M + GB_TOK - 1) / GB_TOK));
-    return hipLaunchKernel(k, grid, dim3((NCONS + NPROD) * GW), argv, GB_LDS, static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+    return hipLaunchKernel(k, grid, dim3((NCONS + NPROD) * GW), argv, GB_LDS, s) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+extern "C" int pbl_gemm_f16_ex(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream) {
+    return pbl_gemm_f16_ws(layer, x, y, M, y_f32, nullptr, 0, stream);
 }
 
 extern "C" int pbl_gemm_f16(const pbl_layer* layer, const void* x, void* y, int M, void* stream) {
-    return pbl_gemm_f16_ex(layer, x, y, M, 0, stream);
+    return pbl_gemm_f16_ws(layer, x, y, M, 0, nullptr, 0, stream);
 }

@@ -536,226 +536,11 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     }
 }
 
-#ifdef PBL_PROTO_ROWMAJOR
-// =====================================================================================================================
-// EXPERIMENT (tools/proto_rowmajor.py, build flag PBL_PROTO_ROWMAJOR; not in the shipped library): the GEMV with the
-// sign-plane phase on the MX matrix cores.  Reads blobs whose 1 KiB tiles were re-laid out ROW-MAJOR by the tool:
-//   lane L = 16 kb + r, dword j of a panel: bit (4 n + c) = sign of row r at column 128 j + k4(kb, 8 c + n),
-//   k4(kb, e) = 16 (4 (kb & 1) + 2 (e / 16) + (kb >> 1)) + e % 16      (where the 4-bit operand of the scaled MFMA keeps K)
-// so that (w & (0x11111111 << c)) | C_c is fragment dword c of an FP4 A operand ("nibble classes": {1, 1.5}, {0, 1}, {0, 2},
-// {1, -1}); x comes as four block-scaled E4M3 terms of A_c(col) * x (token columns 0..3; exact for fp16 x), prepared by the
-// tool together with X = sum x and Xb = sum B_c(col) x:  sum_j s_j x_j = sum_t D[row][t] - Xb.
-// Everything after the sign plane (salient chunks, exceptions, epilogue) is the shipped kernel's code.
-typedef int v8i_p __attribute__((ext_vector_type(8)));
-typedef float v4f_p __attribute__((ext_vector_type(4)));
-struct ProtoArgs {
-    const pbl_layer* layers;
-    const void* const* xs;          // fp16 x per layer (salient gather)
-    const uint8_t* const* xt;       // per layer: terms[4][Kp] u8, scales[4][Kp / 32] u8, float X, float Xb
-    void* const* ys;
-    int y_f32;
-};
-template <int WPB>
-__global__ __launch_bounds__(WPB * PBL_WAVE) void pbl_gemv_rowmajor_kernel(ProtoArgs args) {
-    constexpr int MB = 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const pbl_layer L = args.layers[blockIdx.y];
-    const _Float16* xg = static_cast<const _Float16*>(args.xs[blockIdx.y]);
-    const uint8_t* xtg = args.xt[blockIdx.y];
-    void* yg = args.ys[blockIdx.y];
-#ifndef PBL_PROTO_R
-#define PBL_PROTO_R 1            // records per wave: the workgroup stages x and its terms once for WPB * R consecutive records
+#ifdef PBL_PROTO_ROWMAJOR   // experimental build only: the row-major-plane GEMV prototype lives in tools/ (see the file's header)
+#define PBL_PROTO_SECTION_KERNEL
+#include "../../tools/proto_rowmajor_kernel.inc"
+#undef PBL_PROTO_SECTION_KERNEL
 #endif
-    const uint32_t nwg = (L.NRB + WPB * PBL_PROTO_R - 1) / (WPB * PBL_PROTO_R);
-    if (blockIdx.x >= nwg) return;
-    const uint32_t rb0 = blockIdx.x * WPB * PBL_PROTO_R;
-    const int K = int(L.K), P = int(L.P);
-    const int Kp = P * PBL_PANEL_COLS;
-    const int xstride = Kp + 8;
-    _Float16* xs = reinterpret_cast<_Float16*>(smem);
-    char* after_x = smem + ((size_t(xstride) * 2 + 15) & ~size_t(15));
-    float2* part_all = reinterpret_cast<float2*>(after_x);
-    char* after_part = after_x + size_t(WPB) * L.max_nch * sizeof(float2);
-    after_part = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(after_part) + 15) & ~uintptr_t(15));
-    uint8_t* terms = reinterpret_cast<uint8_t*>(after_part);              // [4][Kp]
-    uint8_t* scales = terms + size_t(4) * Kp;                             // [4][Kp / 32]
-    float* xconst = reinterpret_cast<float*>(scales + size_t(4) * (Kp / 32));   // X, Xb
-    float* tmpD = xconst + 4 + wave * 64;                                 // [16 rows][4 terms] per wave
-
-    {   // stage x (fp16, for the salient gather) and its fp8 terms + scales + constants
-        const int nthr = WPB * PBL_WAVE;
-        const u32x4* src = reinterpret_cast<const u32x4*>(xg);
-        u32x4* dst = reinterpret_cast<u32x4*>(xs);
-        for (int i = tid; i < (K >> 3); i += nthr) dst[i] = src[i];
-        for (int i = K + tid; i < xstride; i += nthr) xs[i] = _Float16(0);
-        const int tbytes = 4 * Kp + 4 * (Kp / 32) + 16;
-        const u32x4* tsrc = reinterpret_cast<const u32x4*>(xtg);
-        u32x4* tdst = reinterpret_cast<u32x4*>(terms);
-#ifndef PBL_PROTO_ABLATE
-#define PBL_PROTO_ABLATE 0      // timing experiment only (wrong results): 1 = do not stage the fp8 terms
-#endif
-        if (!PBL_PROTO_ABLATE) for (int i = tid; i < (tbytes >> 4); i += nthr) tdst[i] = tsrc[i];
-    }
-    __syncthreads();
-    for (int it = 0; it < PBL_PROTO_R; ++it) {
-    const uint32_t rb = rb0 + uint32_t(it) * WPB + wave;
-    if (rb >= L.NRB) break;
-    const bool active = true;
-    const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
-    const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[rb];
-    const uint8_t* rec = blob + size_t(__builtin_amdgcn_readfirstlane(info.x)) * 16;
-    const int nfull = __builtin_amdgcn_readfirstlane(info.y);
-    const int ntail = __builtin_amdgcn_readfirstlane(info.z);
-    const int nexc = __builtin_amdgcn_readfirstlane(info.w);
-    const int nch = nfull + ntail;
-    const uint32_t tiles_off = PBL_TILES_OFF(L.G);
-    const uint32_t off_sal = tiles_off + uint32_t(P) * 1024u;
-    const uint32_t nchu = uint32_t(nch);
-    const u32x4* tiles = reinterpret_cast<const u32x4*>(rec + tiles_off) + lane;
-    const uint8_t* sal = rec + off_sal;
-    const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
-    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + PBL_SAL_DELTA_OFF(nchu));
-    const u32x4* codep = reinterpret_cast<const u32x4*>(sal + PBL_SAL_CODE_OFF(nchu));
-    const uint8_t* tailcnt = sal + PBL_SAL_TAILCNT_OFF(nchu);
-
-    u32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
-    uint32_t s_c0 = 0;
-    u32x4 s_d4 = {0, 0, 0, 0}, s_q4 = {0, 0, 0, 0};
-    if (active) {
-        if (0 < P) t0 = __builtin_nontemporal_load(tiles);
-        if (1 < P) t1 = __builtin_nontemporal_load(tiles + 64);
-    }
-    auto first_salient_round = [&]() {       // requested two panels before the sign plane ends: nine registers less until then
-        if (nch > 0) {
-            const int cc = lane < nch ? lane : nch - 1;
-            s_c0 = col0p[cc];
-            s_d4 = __builtin_nontemporal_load(deltap + cc);
-            s_q4 = __builtin_nontemporal_load(codep + cc);
-        }
-    };
-
-    // ---- phase 1: sign plane on the matrix cores ------------------------------------------------------------------
-    const int tok = lane & 15, kb = lane >> 4;
-    uint32_t c22 = 0x22222222u, c00 = 0u;
-    asm volatile("" : "+v"(c22), "+v"(c00));
-    v4f_p acc = {0.f, 0.f, 0.f, 0.f};
-    // (LDS address space spelled out: through generic pointers hipcc emits FLAT loads here, which count against vmcnt AND
-    // lgkmcnt and serialise the x-term reads with the weight stream)
-    typedef const __attribute__((address_space(3))) uint8_t* lds_u8;
-    typedef const __attribute__((address_space(3))) u32x4* lds_x4;
-    const bool xlane = tok < 4;                                   // the 16 lanes that carry x terms
-    lds_u8 trow = (lds_u8)terms + size_t(tok & 3) * Kp + kb * 32;
-    lds_u8 srow = (lds_u8)scales + size_t(tok & 3) * (Kp / 32) + kb;
-    // (requesting the whole plane of the record up front -- 8 KB per wave in flight -- was slower: 260-268 us)
-    for (int p = 0; p < P; ++p) {
-        u32x4 t2 = t1;
-        if (p + 2 < P) t2 = __builtin_nontemporal_load(tiles + (p + 2) * 64);
-        if (p == (P > 1 ? P - 2 : 0)) first_salient_round();
-#pragma unroll 1
-        for (int j = 0; j < 4; ++j) {      // (not unrolled: hipcc otherwise keeps the x terms of all four steps in registers at once)
-            v8i_p B = {0, 0, 0, 0, 0, 0, 0, 0};
-            int sb = 0x7f;
-            if (xlane) {
-                const int step = 4 * p + j;
-                const u32x4 b0 = *(lds_x4)(trow + step * 128), b1 = *(lds_x4)(trow + step * 128 + 16);
-                B = v8i_p{int(b0[0]), int(b0[1]), int(b0[2]), int(b0[3]), int(b1[0]), int(b1[1]), int(b1[2]), int(b1[3])};
-                sb = srow[step * 4];
-            }
-            const uint32_t w = j == 0 ? t0[0] : (j == 1 ? t0[1] : (j == 2 ? t0[2] : t0[3]));
-            uint32_t f0, f1, f2, f3;
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(f0) : "v"(w), "s"(0x11111111u), "v"(c22));
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(f1) : "v"(w), "s"(0x22222222u), "v"(c00));
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(f2) : "v"(w), "s"(0x44444444u), "v"(c00));
-            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(f3) : "v"(w), "s"(0x88888888u), "v"(c22));
-            const v8i_p A = {int(f0), int(f1), int(f2), int(f3), 0, 0, 0, 0};
-            acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, acc, 4, 0, 0, 0x7f7f7f7f, 0, sb);
-        }
-        t0 = t1;
-        t1 = t2;
-    }
-    // D: lane (t = lane & 15, kb) holds rows 4 kb + r; sum the four term columns (a quad), hand each row to its owner lanes
-    typedef __attribute__((address_space(3))) float* lds_f32;
-    lds_f32 xconst3 = (lds_f32)xconst, tmpD3 = (lds_f32)tmpD;
-    const float X = xconst3[0], Xb = xconst3[1];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float v = quad_sum(acc[r]);
-        if (tok == 0) tmpD3[4 * kb + r] = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int rho = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-    const int sub = lane & 3;
-    const float ssum = tmpD3[rho] - Xb;       // sum_j s_j x_j of the lane's row
-
-    const pbl_rowparams pr = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF)[rho];
-    const pbl_rowinfo ri = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF)[rho];
-    uint32_t c_one = 0x3C003C00u;
-    asm volatile("" : "+v"(c_one));
-
-    // ---- phase 2: salient chunks (the shipped kernel's code) ---------------------------------------------------------
-    float2* part = part_all + size_t(wave) * L.max_nch * MB;
-    {
-        const uint32_t xbase = uint32_t(reinterpret_cast<uintptr_t>(xs));
-        const uint32_t tok_stride = uint32_t(xstride) * 2u;
-        const uint32_t zaddr = xbase + 2u * uint32_t(Kp);
-        for (int base = 0; base < nch; base += PBL_WAVE) {
-            const int c = base + lane;
-            const bool valid = c < nch;
-            const int cc = valid ? c : nch - 1;
-            const uint32_t c0 = s_c0;
-            const u32x4 d4 = s_d4, q4 = s_q4;
-            if (base + PBL_WAVE < nch) {
-                const int cn = c + PBL_WAVE < nch ? c + PBL_WAVE : nch - 1;
-                s_c0 = col0p[cn];
-                s_d4 = __builtin_nontemporal_load(deltap + cn);
-                s_q4 = __builtin_nontemporal_load(codep + cn);
-            }
-            float Q[MB], S[MB];
-            Q[0] = 0.f; S[0] = 0.f;
-            int cnt = 16;
-            if (base + PBL_WAVE > nfull) {
-                if (cc >= nfull) cnt = tailcnt[cc - nfull];
-                if (!valid) cnt = 0;
-            }
-            if (base + PBL_WAVE <= nfull) chunk_accumulate<MB, false, false>(xbase, tok_stride, c0, d4, q4, 16, zaddr, c_one, 0.f, 0.f, Q, S);
-            else chunk_accumulate<MB, true, false>(xbase, tok_stride, c0, d4, q4, cnt, zaddr, c_one, 0.f, 0.f, Q, S);
-            if (valid) part[c] = make_float2(fmaf(-1024.f, S[0], Q[0]), S[0]);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- phase 3 ---------------------------------------------------------------------------------------------------
-    const float alpha = 0.5f * (pr.hi - pr.lo), mu = 0.5f * (pr.hi + pr.lo);
-    const uint32_t row = rb * 16 + rho;
-    const uint2* exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), false));
-    float Q = 0.f, S = 0.f;
-    for (int k = sub; k < int(ri.nfull); k += 4) { const float2 v = part[ri.start + k]; Q += v.x; S += v.y; }
-    for (int k = sub; k < int(ri.ntail); k += 4) { const float2 v = part[nfull + ri.tailidx + k]; Q += v.x; S += v.y; }
-    Q = quad_sum(Q); S = quad_sum(S);
-    float e = 0.f;
-    for (int k = 0; k < nexc; ++k) {
-        const uint2 ex = exc[k];
-        if (int(ex.x >> 16) == rho) e += (__builtin_bit_cast(float, ex.y) - pr.hi) * float(xs[ex.x & 0xFFFFu]);
-    }
-    const float salv = fmaf(pr.sscale, fmaf(-pr.szero, S, Q), -(pr.hi * S));
-    float yv = fmaf(alpha, ssum, fmaf(mu, X, salv)) + e;
-#ifdef PBL_PROTO_DEBUG
-    yv = PBL_PROTO_DEBUG == 1 ? ssum : (PBL_PROTO_DEBUG == 2 ? tmpD3[rho] : X);
-#endif
-    if (L.bias && row < L.N) yv += L.bias[row];
-    if (sub == 0 && row < L.N) {
-        if (args.y_f32) static_cast<float*>(yg)[row] = yv;
-        else static_cast<_Float16*>(yg)[row] = _Float16(yv);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the next record reuses this wave's partials and tmpD
-    __builtin_amdgcn_wave_barrier();
-    }   // records of this wave
-}
-#endif  // PBL_PROTO_ROWMAJOR
 
 size_t lds_bytes(uint32_t P, uint32_t max_nch, int mb, int wpb, int split = 1) {
     const size_t xstride = size_t(P) * PBL_PANEL_COLS + 8;
@@ -1426,18 +1211,9 @@ static int fused_launch(GemvArgs& a, int Lc, int M, uint32_t max_NRB, uint32_t K
 }
 
 #ifdef PBL_PROTO_ROWMAJOR
-/* EXPERIMENT: grouped launch of the row-major-plane GEMV (see pbl_gemv_rowmajor_kernel); M = 1, G = 1, code salients. */
-int pbl_proto_gemv_rowmajor(const pbl_layer* layers_dev, const void* const* x_dev, const uint8_t* const* xt_dev, void* const* y_dev,
-                            int Lc, uint32_t max_NRB, uint32_t max_K, uint32_t max_nch, int wpb, int y_f32, void* stream) {
-    ProtoArgs a{layers_dev, x_dev, xt_dev, y_dev, y_f32};
-    const uint32_t P = (max_K + PBL_PANEL_COLS - 1) / PBL_PANEL_COLS, Kp = P * PBL_PANEL_COLS;
-    size_t lds = ((size_t(Kp + 8) * 2 + 15) & ~size_t(15)) + size_t(wpb) * max_nch * sizeof(float2) + 16 + size_t(4) * Kp + size_t(4) * (Kp / 32) + 16 + size_t(wpb) * 256 + 64;
-    const void* k = wpb == 8 ? reinterpret_cast<const void*>(pbl_gemv_rowmajor_kernel<8>) : reinterpret_cast<const void*>(pbl_gemv_rowmajor_kernel<4>);
-    if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess) return PBL_ERR_LAUNCH;
-    void* argv[] = {&a};
-    return hipLaunchKernel(k, dim3((max_NRB + wpb * PBL_PROTO_R - 1) / (wpb * PBL_PROTO_R), Lc), dim3(wpb * PBL_WAVE), argv, lds, static_cast<hipStream_t>(stream)) == hipSuccess
-               ? PBL_OK : PBL_ERR_LAUNCH;
-}
+#define PBL_PROTO_SECTION_HOST
+#include "../../tools/proto_rowmajor_kernel.inc"
+#undef PBL_PROTO_SECTION_HOST
 #endif
 
 }  // extern "C"

@@ -88,18 +88,49 @@ class P2PAllReduce:
     Every rank allocates one communication buffer through libpbl, the 64-byte IPC handles travel through
     torch.distributed (any backend: gloo in the one-GPU test, RCCL on a node), every rank maps the others' buffers.
     all_reduce_(t) then is a single kernel launch on the current stream: push to 7 peers over xGMI, flag, wait, local
-    sum in rank order (bit-identical on every rank).  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC)."""
+    sum in rank order (bit-identical on every rank).  The call number lives in the buffer (pbl_p2p_allreduce_f32_dev), so
+    the launch is hipGraph-capturable and replayable.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC).
 
-    def __init__(self, max_numel: int, device, group=None):
+    `P2PAllReduce.shared(device, group)` hands every K-split layer of a model the SAME communicator: one buffer of
+    2 * world * max_numel floats per rank (the slots are strided by the world size), allocated at the first all-reduce with
+    the largest message any layer registered -- a 7B model with 64 K-split layers used to allocate 64 buffers of 33 MB."""
+
+    _shared: dict = {}
+
+    def __init__(self, max_numel: int, device, group=None, lazy: bool = False):
         self.group, self.device = group, torch.device(device)
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         if self.world > 16:
             raise ValueError("at most 16 ranks")
         self.max_numel = int(max_numel)
+        self._own, self._opened, self._ptrs = None, [], None
+        if not lazy:
+            self._allocate()
+
+    @classmethod
+    def shared(cls, device, group=None, max_numel: int = 0) -> "P2PAllReduce":
+        """the communicator of (device, group), created on first use; max_numel only ever grows until the first all-reduce"""
+        key = (torch.device(device).index, id(group))
+        c = cls._shared.get(key)
+        if c is None:
+            c = cls._shared[key] = cls(max_numel, device, group, lazy=True)
+        c.reserve(max_numel)
+        return c
+
+    def reserve(self, numel: int):
+        if numel > self.max_numel:
+            if self._own is not None:
+                raise _lib.PblError(f"P2PAllReduce is already allocated for {self.max_numel} elements; {numel} requested")
+            self.max_numel = int(numel)
+
+    def _allocate(self):
+        """collective: every rank allocates, exports, maps (at the first all_reduce_ of a lazily created communicator:
+        all ranks run the same model, so they get here together)"""
         L = _lib.lib()
+        group = self.group
         with torch.cuda.device(self.device):
             own = C.c_void_p()
-            _lib.check(L.pbl_comm_alloc(L.pbl_p2p_buffer_bytes(self.max_numel), C.byref(own)), "comm_alloc")
+            _lib.check(L.pbl_comm_alloc(L.pbl_p2p_buffer_bytes_world(self.max_numel, self.world), C.byref(own)), "comm_alloc")
             self._own = own.value
             handle = (C.c_ubyte * 64)()
             _lib.check(L.pbl_ipc_export(self._own, handle), "ipc_export")
@@ -116,23 +147,31 @@ class P2PAllReduce:
                 _lib.check(L.pbl_ipc_open(buf, C.byref(ptr)), f"ipc_open(rank {r})")
                 self._ptrs[r] = ptr.value
                 self._opened.append(ptr.value)
-        self.seq = 0
         dist.barrier(group=group)            # nobody launches before everybody has mapped everybody
 
-    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+    def all_reduce_(self, t: torch.Tensor, out_f16: torch.Tensor | None = None) -> torch.Tensor:
+        """t (fp32, contiguous) <- sum over ranks, in place; out_f16 (optional, same numel, fp16) also receives the sum
+        rounded to fp16 by the same kernel"""
         if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
             raise _lib.PblError("P2PAllReduce: contiguous fp32 tensor on the communicator's device")
+        if out_f16 is not None and (out_f16.dtype != torch.float16 or not out_f16.is_contiguous() or out_f16.numel() != t.numel()):
+            raise _lib.PblError("P2PAllReduce: out_f16 must be a contiguous fp16 tensor of the same size")
+        if self._own is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.PblError("P2PAllReduce: run one all-reduce eagerly before capturing (the buffers are mapped on first use)")
+            self._allocate()
         if t.numel() > self.max_numel:
             raise _lib.PblError(f"P2PAllReduce sized for {self.max_numel} elements, got {t.numel()}")
-        self.seq += 1
         st = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(_lib.lib().pbl_p2p_allreduce_f32(self._ptrs, self.rank, self.world, t.data_ptr(), t.numel(), self.max_numel,
-                                                    self.seq, st), "p2p_allreduce")
+        _lib.check(_lib.lib().pbl_p2p_allreduce_f32_dev(self._ptrs, self.rank, self.world, t.data_ptr(),
+                                                        out_f16.data_ptr() if out_f16 is not None else None, t.numel(),
+                                                        self.max_numel, st), "p2p_allreduce")
         return t
 
     def check(self) -> None:
-        """synchronous: raises if any wait timed out since construction (a peer died or never launched)"""
-        if _lib.lib().pbl_p2p_check(self._own) != 0:
+        """synchronous: raises if any wait timed out since construction (a peer died or never launched; the affected
+        outputs were overwritten with NaN by the kernel)"""
+        if self._own is not None and _lib.lib().pbl_p2p_check(self._own) != 0:
             raise _lib.PblError("P2PAllReduce: a peer's flag did not arrive within the bounded wait")
 
     def close(self):
@@ -144,6 +183,9 @@ class P2PAllReduce:
                 L.pbl_ipc_close(p)
             L.pbl_comm_free(self._own)
             self._own, self._opened = None, []
+        for k, v in list(P2PAllReduce._shared.items()):
+            if v is self:
+                del P2PAllReduce._shared[k]
 
 
 class PBLinearNSplit(nn.Module):
@@ -183,9 +225,10 @@ class PBLinearKSplit(nn.Module):
         self.shard, self.cols, self.group, self.input_is_sharded = shard, cols, group, input_is_sharded
         if collective not in ("rccl", "p2p"):
             raise ValueError("collective must be 'rccl' or 'p2p'")
-        self.comm = None
+        self.comm, self.max_tokens = None, max_tokens
         if collective == "p2p":
-            self.comm = P2PAllReduce(max_tokens * shard.out_features, shard.pbl_blob.device, group)
+            # ONE communicator per (device, group) for all K-split layers, sized to the largest message
+            self.comm = P2PAllReduce.shared(shard.pbl_blob.device, group, max_tokens * shard.out_features)
 
     def local_forward(self, x_local):
         """fp32 partial y of this rank's column slice (bias lives on rank 0 only)."""
@@ -193,8 +236,12 @@ class PBLinearKSplit(nn.Module):
 
     def forward(self, x):
         xl = x if self.input_is_sharded else x[..., self.cols[0]:self.cols[1]]
-        y = self.local_forward(xl).float().contiguous()
+        y = self.local_forward(xl)               # fp32, contiguous: the kernels' own output
         if self.comm is not None and y.numel() <= self.comm.max_numel:
+            if x.dtype == torch.float16:         # the all-reduce kernel writes the fp16 result itself: no cast launch
+                out = torch.empty(y.shape, dtype=torch.float16, device=y.device)
+                self.comm.all_reduce_(y, out)
+                return out
             self.comm.all_reduce_(y)
         else:
             dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)

@@ -41,11 +41,17 @@ class BinaryInterface:
 # Layers the matrix-core kernel cannot take (odd group sizes, K % 8) switch to the dense path at GEMM_THRESHOLD.
 MFMA_MAX = 32
 GEMM_THRESHOLD = 12
-# GEMM regime backend: "fused" (default) = pbl_gemm_f16_ex, the hand-written kernel that rebuilds fp16 weight tiles in LDS from
-# the packed records and never materialises the dense weight (fp16 activations, fp16 dense dtype, any layer kind the kernel
-# takes -- see fused_gemm_ok); "library" = pbl_unpack_dev into a transient dense buffer + torch's GEMM, which also serves
-# everything the fused kernel does not take (fp32 / bf16 activations, fp32 dense dtype, odd group sizes, K % 8).
-GEMM_BACKEND = "fused"
+# GEMM regime backend (rows > 32: prefill).  Two complete implementations; `GEMM_BACKEND` picks one:
+#   "library"  pbl_unpack_dev expands the packed layer into a transient dense buffer (2 B per weight, from the caching
+#              allocator) and a library GEMM runs on it.  Default BECAUSE IT IS FASTER on MI355X at the llama shapes:
+#              seq 2048, low_frac 0.95: 4096^2 76 us, 11008x4096 188, 4096x11008 187; llama-7b-shaped forward 45.2 ms
+#              (dense fp16 39.4) -- gpurun_out/r3i, profiles/r03_gemm.md.
+#   "fused"    pbl_gemm_f16_ws (csrc/pbl_gemm_big.hip): the hand-written kernel that rebuilds fp16 weight tiles in LDS from
+#              the packed records and never materialises the dense weight; its only scratch is 4 B per SALIENT entry.  Any
+#              layer kind (see fused_gemm_ok), fp16 activations, fp16 or fp32 result.  Round 3: 91 / 243 / 217 us on the
+#              same shapes (round 2: 120 / 344 / 327), forward 57 ms.  Use it where the dense copy must not exist.
+# fp32 / bf16 activations, an fp32 dense dtype, odd group sizes and K % 8 != 0 always take the library path.
+GEMM_BACKEND = os.environ.get("PBL_GEMM_BACKEND", "library")
 
 
 def fused_gemm_ok(packed: PackedWeight) -> bool:
@@ -56,13 +62,19 @@ def fused_gemm_ok(packed: PackedWeight) -> bool:
     return packed.G == 1 or (packed.K % packed.G == 0 and (packed.K // packed.G) % 128 == 0)
 
 
-def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False) -> torch.Tensor:
-    """pbl_gemm_f16_ex: x2 [M, K] fp16 contiguous -> [M, N] fp16 (fp32 with out_f32); raises PblError(UNSUPPORTED) for layers
-    it does not take"""
-    y = torch.empty(x2.shape[0], packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
+def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False, workspace: bool = True) -> torch.Tensor:
+    """pbl_gemm_f16_ws: x2 [M, K] fp16 contiguous -> [M, N] fp16 (fp32 with out_f32); raises PblError(UNSUPPORTED) for layers
+    it does not take.  workspace: hand the kernel the transient scratch it asks for (more than one 256-token tile: the
+    salient entries are decoded once per call by a small kernel ahead of the GEMM; 4 B per entry from the caching allocator,
+    stream ordered) -- False decodes inside the GEMM kernel; the results are identical bit for bit."""
+    M = x2.shape[0]
+    y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
     layer = packed.layer_struct(bias_f32)
-    _lib.check(_lib.lib().pbl_gemm_f16_ex(C.byref(layer), x2.data_ptr(), y.data_ptr(), x2.shape[0], int(out_f32),
-                                          torch.cuda.current_stream(x2.device).cuda_stream), "gemm_f16")
+    L = _lib.lib()
+    nb = L.pbl_gemm_workspace_bytes(C.byref(layer), M) if workspace else 0
+    ws = torch.empty(nb, dtype=torch.uint8, device=x2.device) if nb else None
+    _lib.check(L.pbl_gemm_f16_ws(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), ws.data_ptr() if ws is not None else None, nb,
+                                 torch.cuda.current_stream(x2.device).cuda_stream), "gemm_f16")
     return y
 
 

@@ -71,11 +71,17 @@ def test_config3_llama7b_linears_hessian_m2048(name):
     col_frac = (~mask).mean(0)
     assert (col_frac > 0.9).sum() >= 8 and np.median(col_frac) < 0.05
     x = synth.activations((2048, K), 77, 21)
-    y = layer(T(x))
-    assert y.shape == (2048, N) and y.dtype == torch.float16
     rows = np.unique(np.concatenate([np.arange(0, N, max(1, N // 192)), [N - 1, N - 16, 15, 16]]))
     ref = O.dense_linear(x, W16.numpy()[rows])
-    assert_parity(y[:, torch.from_numpy(rows).to(DEV)], ref)
+    old = Q.GEMM_BACKEND
+    try:
+        for backend in ("library", "fused"):               # both GEMM-regime implementations on the hessian layers
+            Q.GEMM_BACKEND = backend
+            y = layer(T(x))
+            assert y.shape == (2048, N) and y.dtype == torch.float16
+            assert_parity(y[:, torch.from_numpy(rows).to(DEV)], ref)
+    finally:
+        Q.GEMM_BACKEND = old
     # the decode-time regimes of the same layer: GEMV (1 token) and the matrix-core kernel (32 tokens)
     for M in (1, 32):
         assert_parity(layer(T(x[:M])), O.dense_linear(x[:M], W16.numpy()))
@@ -160,6 +166,36 @@ def _tp_worker(rank, world, port, collective, out):
         if mod.comm is not None:
             for _ in range(5):            # more calls than buffer sets
                 same = same and bool(torch.equal(mod(x), y))
+            # a second K-split layer shares the communicator (one buffer per rank, sized to the largest message) ...
+            W2 = synth.llm_weight(128, K, seed=43, heavy_tail=True)
+            mask2 = O.ptq_low_mask(W2, 0.9, "magnitude", None, -1)
+            W2q = torch.from_numpy(O.ptq_rtn(W2, mask2, 8, -1)["W_fq"]).half()
+            shard2, cols2 = PP.shard_linear(W2q, None, torch.from_numpy(mask2), "k", rank, world)
+            mod2 = PP.PBLinearKSplit(shard2.to(dev), cols2, collective="p2p")
+            same = same and mod2.comm is mod.comm
+            # ... and layer + all-reduce are hipGraph-capturable: the call number lives in the buffer, so a REPLAY advances it.
+            # Both layers (two dependent all-reduces per replay) captured once, replayed 10 x with fresh inputs, against eager.
+            xs = torch.zeros_like(x)
+            s_ = torch.cuda.Stream()
+            s_.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s_), torch.no_grad():
+                for _ in range(2):
+                    mod2(xs); mod(xs)
+            torch.cuda.current_stream().wait_stream(s_)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                ya = mod(xs)
+                yb = mod2(xs * 0.5)
+            for it in range(10):
+                xi = torch.from_numpy(synth.activations((3, K), 60 + it, 21)).to(dev)
+                xs.copy_(xi)
+                g.replay()
+                torch.cuda.synchronize()
+                with torch.no_grad():
+                    same = same and bool(torch.equal(ya, mod(xi))) and bool(torch.equal(yb, mod2(xi * 0.5)))
+            rel2, ratio2 = O.parity_errors(yb.float().cpu().numpy(), O.dense_linear((xs * 0.5).cpu().numpy(), W2q.numpy()))
+            same = same and rel2 < 1e-3 and ratio2 < 1.0
             mod.comm.check()
             mod.comm.close()
         out[rank] = (rel, ratio, same)
@@ -183,7 +219,8 @@ def test_config5_ksplit_rccl_all_reduce(world):
 def test_config5_ksplit_p2p_all_reduce_two_processes():
     """libpbl's one-shot peer-to-peer all-reduce between two PROCESSES.  On a one-GPU box both ranks use cuda:0: the
     hipIpc mapping, the slot / flag protocol and the rank-ordered sum are exactly what runs over xGMI; only the link
-    differs.  (Handles travel over gloo there, RCCL refuses two ranks on one device.)"""
+    differs.  (Handles travel over gloo there, RCCL refuses two ranks on one device.)  Also: two K-split layers on one shared
+    communicator, and K-split layer + all-reduce captured in a hipGraph in both processes and replayed 10 times."""
     import torch.multiprocessing as mp
     out = mp.Manager().dict()
     mp.spawn(_tp_worker, args=(2, _free_port(), "p2p", out), nprocs=2, join=True)
@@ -270,6 +307,47 @@ def test_hessian_mask_module_on_gpu(tmp_path, monkeypatch):
     assert_parity(y_train, ref, 1e-4)
     m.eval()
     assert_parity(m(T(x)), ref, 2e-5)                     # packed kernels, fp32 module: split-x path
+
+
+def test_g9_hessian_mask_module_vs_reference_golden(tmp_path, monkeypatch):
+    """the same module against outputs of the REFERENCE class (tests/golden/g9, tools/gen_goldens.py G9: the reference's
+    BinaryXnorExceptOutliersLinearHessian picks up the mask its own gptq_pb run dumped): mask, 8-bit weights, outlier_nbits,
+    binary_scale, the train() forward, the eval() forward through the packed kernels, to_regular_linear; and the magnitude
+    fallback when the file is missing."""
+    import hashlib
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_hessian_mask_module.npz"))
+    monkeypatch.chdir(tmp_path)
+    N, K = 256, 512
+    W = synth.llm_weight(N, K, seed=9, heavy_tail=True).astype(np.float16).astype(np.float32)
+    b = synth.normal((N,), 9, 3, 0.1)
+    x = synth.normal((3, K), 9, 5, 1.0)
+    low = np.unpackbits(g["low_mask"])[:N * K].astype(bool).reshape(N, K)
+    pbio.save_low_mask(torch.from_numpy(low), 0.9, "golden/layer")
+    m = Q.BinaryXnorExceptOutliersLinearHessian(torch.from_numpy(W).clone(), torch.from_numpy(b), 0.1).to(DEV)
+    m.global_name = "golden/layer"
+    m.eval()
+    m.gen_outlier_mask()
+    np.testing.assert_array_equal(np.packbits(m.outlier_mask.cpu().numpy()), g["outlier_mask"])
+    assert m.binary_scale is None and bool(g["binary_scale_is_none"])
+    np.testing.assert_array_equal(m.weight.data.cpu().numpy(), g["w_hat"])
+    assert abs(m.outlier_nbits - float(g["outlier_nbits"])) < 1e-9
+    xt = T(x)
+    with torch.no_grad():
+        m.train()
+        y_train = m(xt)
+        np.testing.assert_allclose(m.binary_scale.float().cpu().numpy().reshape(-1), g["binary_scale"].reshape(-1), rtol=3e-6)
+        assert_parity(y_train, g["y_train"].astype(np.float64), 1e-4)
+        m.eval()
+        assert_parity(m(xt), g["y_eval"].astype(np.float64), 2e-5)        # packed kernels, fp32 module
+        w_sim = m.to_regular_linear().weight.data.float().cpu().numpy()
+    assert hashlib.sha256(np.ascontiguousarray(w_sim).tobytes()).hexdigest() == str(g["w_sim_sha"])
+    m2 = Q.BinaryXnorExceptOutliersLinearHessian(torch.from_numpy(W).clone(), torch.from_numpy(b), 0.1).to(DEV)
+    m2.global_name = "golden/other"                                       # no mask file: magnitude fallback
+    m2.eval()
+    with torch.no_grad():
+        m2.gen_outlier_mask()
+        np.testing.assert_array_equal(np.packbits(m2.outlier_mask.cpu().numpy()), g["fallback_mask"])
+        assert_parity(m2(xt), g["fallback_y_eval"].astype(np.float64), 2e-5)
 
 
 # ------------------------------------------------------------------------------------------- autograd / cache

@@ -5,6 +5,8 @@ the BASELINE configs[2] layers (hessian salients: many short chunks, whole colum
 float64 oracle on the weights a dense fp16 copy of the layer holds, and against the library GEMM on pbl_unpack_dev's output
 (same operands, different summation order).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -77,6 +79,7 @@ CASES = [
     (11008, 4096, 512, -1, 0.95, True, 0, "hessian"),           # configs[2] gate/up: hessian salients
     (4096, 11008, 512, -1, 0.95, True, 0, "hessian"),           # configs[2] down: K = 86 half slabs
     (4096, 11008, 300, 128, 0.95, False, 0, "magnitude"),       # groupsize 128, fp32 grid, 11008 wide
+    (48, 16512, 300, -1, 0.9, True, 2, "magnitude"),            # 129 half slabs: too wide for the workspace's range registers
 ]
 
 
@@ -98,6 +101,10 @@ def test_gemm_regime_kernel(N, K, M, gs, lf, fp16, exc, metric):
     assert y32.dtype == torch.float32
     assert_parity(y32[:, ridx], O.dense_linear(x, W16[rows]), 3e-4)       # fp32 accumulation of exact fp16 products, unrounded
     assert torch.equal(y, Q.fused_gemm_forward(pd, T(b), xt))             # deterministic
+    # more than one token tile: the salient entries were decoded once per call into the workspace; inside the kernel otherwise
+    assert (_lib.lib().pbl_gemm_workspace_bytes(C.byref(pd.layer_struct(None)), M) > 0) == (M > 256 and K <= 16256)
+    assert torch.equal(y, Q.fused_gemm_forward(pd, T(b), xt, workspace=False))
+    assert torch.equal(y32, Q.fused_gemm_forward(pd, None, xt, out_f32=True, workspace=False))
     # the library backend on the unpacked layer: same operands, different summation order
     Wdev = Q.unpack_on_device(pd, torch.float16)
     np.testing.assert_array_equal(Wdev.float().cpu().numpy()[rows], W16[rows])
@@ -106,27 +113,27 @@ def test_gemm_regime_kernel(N, K, M, gs, lf, fp16, exc, metric):
 
 
 def test_module_routes_the_gemm_regime_to_the_fused_kernel():
-    """PBLinear above 32 rows: the fused kernel by default (fp16 activations), the library backend on request and for
+    """PBLinear above 32 rows with GEMM_BACKEND = "fused": the hand-written kernel (fp16 activations), the library backend for
     bf16 / fp32 activations; the two backends agree; a leading batch dimension and a non-contiguous input are handled."""
     p, Wd = rtn_layer(512, 1024, -1, seed=5, low_frac=0.9, fp16=True, exceptions=1)
     layer = Q.PBLinear(p.to(DEV), T(synth.normal((512,), 3, 3, 0.1)))
     x = synth.activations((3, 40, 1024), 8, 21)
     xt = T(x)
-    assert Q.GEMM_BACKEND == "fused"
-    y = layer(xt)
-    ref = O.dense_linear(x.reshape(-1, 1024), Wd, layer.pbl_bias.cpu().numpy()).reshape(3, 40, 512)
-    assert y.shape == (3, 40, 512) and y.dtype == torch.float16
-    assert_parity(y, ref)
-    assert torch.equal(y.reshape(120, 512), Q.fused_gemm_forward(layer.packed, layer.pbl_bias, xt.reshape(120, 1024)))
     old = Q.GEMM_BACKEND
     try:
+        Q.GEMM_BACKEND = "fused"
+        y = layer(xt)
+        ref = O.dense_linear(x.reshape(-1, 1024), Wd, layer.pbl_bias.cpu().numpy()).reshape(3, 40, 512)
+        assert y.shape == (3, 40, 512) and y.dtype == torch.float16
+        assert_parity(y, ref)
+        assert torch.equal(y.reshape(120, 512), Q.fused_gemm_forward(layer.packed, layer.pbl_bias, xt.reshape(120, 1024)))
+        xs = T(synth.activations((120, 2048), 9, 21))[:, ::2]               # strided view
+        assert_parity(layer(xs), O.dense_linear(xs.cpu().numpy(), Wd, layer.pbl_bias.cpu().numpy()))
         Q.GEMM_BACKEND = "library"
         y_lib = layer(xt)
     finally:
         Q.GEMM_BACKEND = old
     assert_parity(y, y_lib.float().cpu().numpy().astype(np.float64), 2e-3)
-    xs = T(synth.activations((120, 2048), 9, 21))[:, ::2]               # strided view
-    assert_parity(layer(xs), O.dense_linear(xs.cpu().numpy(), Wd, layer.pbl_bias.cpu().numpy()))
     # bf16 activations take the library backend (fp32 dense weight); the result is rounded to bf16 (8 significand bits)
     yb = layer(xt.bfloat16())
     refb = O.dense_linear(xt.bfloat16().float().cpu().numpy().reshape(-1, 1024), Wd, layer.pbl_bias.cpu().numpy()).reshape(3, 40, 512)

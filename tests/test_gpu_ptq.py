@@ -69,6 +69,30 @@ def test_gptq_block_kernel_bit_exact_vs_oracle(N, ncols, feedback):
     np.testing.assert_allclose(losses.cpu().numpy(), loss, rtol=2e-6)
 
 
+@pytest.mark.parametrize("metric", ["magnitude", "hessian"])
+def test_gptq_column_loop_whole_layer_with_the_references_cholesky_factor(metric):
+    """gptq_blocks_ (pbl_gptq_block + the trailing-update GEMM) over ALL 768 columns, fed the reference's own upper Cholesky
+    factor, mask and quantizer state (golden G5 now stores U): the first 128-column block equals the reference BIT FOR BIT,
+    the whole layer to > 99.9 % of its fp16 weights (each block's trailing update is one fp32 GEMM whose summation order
+    neither torch-CPU nor rocBLAS pins), the loss to 1e-4; the oracle's loop on the same inputs agrees to the same degree."""
+    W16, Xcal, _, _ = g5_inputs()
+    g = golden(g5_name(metric, -1, False, 0.9))
+    U = np.ascontiguousarray(g["U"].astype(np.float32))
+    mask = np.unpackbits(g["mask"])[:768 * 768].astype(bool).reshape(768, 768)
+    W = W16.astype(np.float32)
+    hscale, hzero, maxq = O.high_calibrate(W, 8)
+    mean, scale = O.low_xnor_calibrate((W * mask).astype(F32))
+    Wd = T(W.copy())
+    losses = ptq.gptq_blocks_(Wd, T(U), T(mask), T(hscale), T(hzero), float(maxq), T(mean)[None], T(scale)[None], 768, True)
+    got, ref = Wd.cpu().numpy().astype(np.float16), g["W_fq"]
+    np.testing.assert_array_equal(got[:, :128], ref[:, :128])
+    assert (got != ref).mean() < 1e-3
+    assert abs(float(losses.double().sum()) - float(g["loss"])) / float(g["loss"]) < 1e-4
+    Wo = W.copy()
+    O.gptq_blocks(Wo, U, mask, hscale, hzero, maxq, mean[None], scale[None], 768, 128)
+    assert (got != Wo.astype(np.float16)).mean() < 1e-3
+
+
 def run_layer(W16, Xcal, lf, metric, gs, rtn):
     layer = nn.Linear(768, 768, bias=False)
     layer.weight.data = torch.from_numpy(W16).clone()

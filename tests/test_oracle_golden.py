@@ -190,6 +190,61 @@ def test_g5_ptq_gptq_loop(metric, gs):
     assert agree > 0.97, agree
 
 
+@pytest.mark.parametrize("metric", ["magnitude", "hessian"])
+def test_g5_gptq_loop_with_the_references_own_cholesky_factor(metric):
+    """gptq.py:129-168 over the WHOLE layer.  G5 stores the reference's upper Cholesky factor U of H^-1 (the part of the chain
+    LAPACK owns), its mask and its quantizer state; given those, the column loop is elementwise fp32 arithmetic plus one
+    fp32 GEMM per 128-column block (the trailing update, whose summation order torch does not pin).  So: the first block is
+    reproduced BIT FOR BIT (no GEMM feeds it), the whole layer to > 99.9 % identical fp16 weights (was: statistical, 97 %),
+    every difference one quantisation step, the loss to 1e-4."""
+    W16, Xcal, _, _ = g5_inputs()
+    g = golden(g5_name(metric, -1, False, 0.9))
+    U = g["U"].astype(np.float32)
+    np.testing.assert_array_equal(np.diag(U), g["hinv_diag"])
+    mask = np.unpackbits(g["mask"])[:768 * 768].astype(bool).reshape(768, 768)
+    W = W16.astype(np.float32).copy()
+    hscale, hzero, maxq = O.high_calibrate(W, 8)
+    np.testing.assert_array_equal(hscale.reshape(-1), g["hscale"].reshape(-1))
+    mean, scale = O.low_xnor_calibrate((W * mask).astype(np.float32))
+    np.testing.assert_allclose(mean, g["mean"].reshape(mean.shape), rtol=2e-5, atol=1e-9)
+    losses = O.gptq_blocks(W, U, mask, hscale, hzero, maxq, mean[None], scale[None], 768, 128)
+    got, ref = W.astype(np.float16), g["W_fq"]
+    np.testing.assert_array_equal(got[:, :128], ref[:, :128])
+    diff = got != ref
+    assert diff.mean() < 1e-3, diff.mean()
+    assert abs(float(losses.astype(np.float64).sum()) - float(g["loss"])) / float(g["loss"]) < 1e-4
+    # a differing entry sits one code step (salient) or one level flip (binarized) from the reference's
+    step = np.abs(got.astype(np.float32) - ref.astype(np.float32))[diff]
+    lim = np.maximum(np.broadcast_to(hscale.reshape(-1, 1), diff.shape)[diff] * 1.01, 2.02 * np.broadcast_to(scale.reshape(-1, 1), diff.shape)[diff])
+    assert (step <= lim).all()
+
+
+# ------------------------------------------------------------------ G9 (the Hessian-mask QAT module)
+def test_g9_hessian_mask_module_oracle():
+    """BinaryXnorExceptOutliersLinearHessian as the reference runs it (quant/outlier_quantizer.py:126-143): the loaded low
+    mask becomes ~outlier_mask, weights are 8-bit quantised, binary_scale is unset until a train() forward; and the
+    magnitude fallback when no mask file exists."""
+    g = golden("g9_hessian_mask_module")
+    N, K = 256, 512
+    W = synth.llm_weight(N, K, seed=9, heavy_tail=True).astype(np.float16).astype(np.float32)
+    b = synth.normal((N,), 9, 3, 0.1)
+    x = synth.normal((3, K), 9, 5, 1.0)
+    low = np.unpackbits(g["low_mask"])[:N * K].astype(bool).reshape(N, K)
+    om = np.unpackbits(g["outlier_mask"])[:N * K].astype(bool).reshape(N, K)
+    np.testing.assert_array_equal(om, ~low)
+    assert bool(g["binary_scale_is_none"]) and abs(om.mean() - 0.1) < 2e-3
+    W_hat = O.weight_quant_8bit(W)
+    np.testing.assert_array_equal(W_hat, g["w_hat"])
+    bs = O.refresh_binary_scale(W_hat, om)
+    np.testing.assert_allclose(bs.reshape(-1), g["binary_scale"].reshape(-1), rtol=1e-6)
+    y = O.pb_qat_forward(x, W_hat, om, bs, b)
+    assert O.parity_errors(g["y_train"], y)[0] < 2e-5 and O.parity_errors(g["y_eval"], y)[0] < 2e-5
+    assert abs(O.calc_outlier_nbits(W_hat, om) - float(g["outlier_nbits"])) < 1e-9
+    # fallback: magnitude mask on the SAME weights (gen_outlier_mask of the base class)
+    fm, _ = O.gen_outlier_mask_magnitude(W, 0.1)[:2]
+    np.testing.assert_array_equal(np.packbits(fm), g["fallback_mask"])
+
+
 # ------------------------------------------------------------------ G6 (large, hashes)
 def test_g6_llama7b_qproj_rtn_hashes():
     g = golden("g6_llama7b_qproj_4096_lf0.9")

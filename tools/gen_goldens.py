@@ -173,6 +173,7 @@ def run_ptq(W16, Xcal, low_frac, metric, groupsize, disable_gptq, high_bit=8, wa
              hzero=hq.zero.numpy().copy(), loss=np.array(info["error"]))
     if want_hdiag:
         r["hinv_diag"] = torch.diag(stash["U"]).numpy().copy()
+        r["U"] = stash["U"].numpy().copy()
     return r
 
 
@@ -192,9 +193,14 @@ def g5(out):
                     y32 = F.linear(T(x32), Wfq).numpy()
                     y32_f32 = F.linear(T(x32).float(), Wfq.float()).numpy()
                     tag = f"g5_ptq_{metric}_gs{gs if gs > 0 else 'all'}_{'rtn' if rtn else 'gptq'}_lf{lf}"
+                    extra = {}
+                    if not rtn and gs == -1:
+                        # the full upper Cholesky factor of H^-1 (768^2 fp32) for the two GPTQ runs without groups: with it
+                        # gptq.py:129-168 is reproducible column by column over the WHOLE layer, not on the diagonal only
+                        extra["U"] = r["U"]
                     save(out, tag, mask=np.packbits(r["mask"]), W_fq=r["W_fq"], mean=r["mean"],
                          scale=r["scale"], hscale=r["hscale"], hzero=r["hzero"], loss=r["loss"],
-                         hinv_diag=r["hinv_diag"], y1=y1, y32=y32, y32_f32=y32_f32)
+                         hinv_diag=r["hinv_diag"], y1=y1, y32=y32, y32_f32=y32_f32, **extra)
 
 
 def big_rtn(out, tag, N, K, low_frac, M, seed):
@@ -263,7 +269,71 @@ def g8(out):
     save(out, "g8_qat_step", **res)
 
 
-ALL = dict(G1=g1_g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8)
+def g9(out):
+    """BinaryXnorExceptOutliersLinearHessian (quant/outlier_quantizer.py:126-143) driven the way qat/run_qat.py drives it:
+    the low-mask file gptq_pb dumped (gptq.py:108-114) is found under gptq_pb/outputs/mask/, becomes ~outlier_mask, the
+    weights are 8-bit quantised, binary_scale stays None until a train() forward computes it.  Stored: the mask as loaded,
+    W_hat, outlier_nbits, the train-mode forward and the eval forward after it, to_regular_linear's weight hash; and the
+    fallback (no file -> magnitude mask) for the same weights."""
+    N, K = 256, 512
+    W16 = synth.llm_weight(N, K, seed=9, heavy_tail=True).astype(np.float16)
+    Xcal = synth.calib_inputs(4, 128, K, seed=9)
+    b = synth.normal((N,), 9, 3, 0.1)
+    x = synth.normal((3, K), 9, 5, 1.0)
+    res = dict(b=b)
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "outputs"))
+        os.makedirs(os.path.join(td, "gptq_pb", "outputs", "mask"))
+        os.chdir(td)
+        try:
+            # 1. the reference's own PTQ run writes outputs/mask/mask_0.9_golden_layer.pkl (hessian metric, RTN values)
+            layer = nn.Linear(K, N, bias=False)
+            layer.weight.data = T(W16).clone()
+            layer.global_name = "golden/layer"
+            lq = LowQuantizer(layer.weight, method="xnor", groupsize=-1)
+            hq = HighQuantizer(8, perchannel=True, sym=False, mse=False)
+            g = LowHighGPT(layer, lq, hq, salient_metric="hessian", disable_gptq=True)
+            for s_ in range(Xcal.shape[0]):
+                g.add_batch(T(Xcal[s_:s_ + 1]), None)
+            with quiet():
+                g.fasterquant(0.9, blocksize=128, percdamp=0.01)
+            src = os.path.join(td, "outputs", "mask", "mask_0.9_golden_layer.pkl")
+            low_mask = torch.load(src).numpy()
+            os.replace(src, os.path.join(td, "gptq_pb", "outputs", "mask", "mask_0.9_golden_layer.pkl"))
+            res["low_mask"] = np.packbits(low_mask)
+            # 2. the QAT module picks the file up (fp32 master weights, as qat/run_qat.py loads the model)
+            m = quant.BinaryXnorExceptOutliersLinearHessian(T(W16).float(), T(b), 0.1)
+            m.global_name = "golden/layer"
+            m.eval()
+            with quiet():
+                m.gen_outlier_mask()
+            res["outlier_mask"] = np.packbits(m.outlier_mask.numpy())
+            res["binary_scale_is_none"] = np.array(m.binary_scale is None)
+            res["w_hat"] = m.weight.data.numpy().copy()
+            res["outlier_nbits"] = np.array(m.outlier_nbits)
+            xt = T(x)
+            with torch.no_grad():
+                m.train()
+                res["y_train"] = m(xt).numpy()
+                res["binary_scale"] = m.binary_scale.numpy().copy()
+                m.eval()
+                res["y_eval"] = m(xt).numpy()
+                res["w_sim_sha"] = np.array(sha(m.to_regular_linear().weight.data.numpy()))
+            # 3. no mask file for this name: the magnitude fallback
+            m2 = quant.BinaryXnorExceptOutliersLinearHessian(T(W16).float(), T(b), 0.1)
+            m2.global_name = "golden/other"
+            m2.eval()
+            with quiet(), torch.no_grad():
+                m2.gen_outlier_mask()
+                res["fallback_mask"] = np.packbits(m2.outlier_mask.numpy())
+                res["fallback_y_eval"] = m2(xt).numpy()
+        finally:
+            os.chdir(cwd)
+    save(out, "g9_hessian_mask_module", **res)
+
+
+ALL = dict(G1=g1_g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
