@@ -155,6 +155,25 @@ def lib() -> C.CDLL:
     return L
 
 
+NATIVE_PATH = os.path.join(_HERE, "libpbl_torch.so")
+_native = None
+
+
+def native_linear():
+    """`torch.ops.pbllm_native.linear` (csrc/pbl_torch.cpp): the decode-regime forward as ONE native call -- checks, output and
+    workspace allocation, stream lookup and the launch in C++ instead of ~25 us of interpreter work around a ctypes call.
+    None when the dispatcher is not built or disabled (PBL_NATIVE=0): the ctypes path then serves the same kernels."""
+    global _native
+    if _native is None:
+        _native = False
+        if os.environ.get("PBL_NATIVE", "1") != "0" and os.path.exists(NATIVE_PATH) and not os.environ.get("PBL_LIB"):
+            import torch
+            lib()                                    # libpbl.so first: the dispatcher links against it
+            torch.ops.load_library(NATIVE_PATH)
+            _native = torch.ops.pbllm_native.linear
+    return _native or None
+
+
 def check(status: int, what: str = "") -> None:
     if status != 0:
         msg = lib().pbl_status_string(status).decode()

@@ -74,6 +74,52 @@ def load_pb(model: nn.Module, load_path: str) -> nn.Module:
     return model
 
 
+def save_bnn(model: nn.Module, save_path: str) -> dict:
+    """The REFERENCE's layout (utils.py:87-94), for interchange: meta.json {module name -> class name} and weights.pth
+    {name + "_weight": the module's weight parameter as fp16 (get_save_weight_dict, quant/quantizer.py:70-72), name + "_bias"}."""
+    os.makedirs(save_path, exist_ok=True)
+    meta, weights = {}, {}
+    for name, m in model.named_modules():
+        if isinstance(m, BinaryInterface):
+            meta[name] = m.__class__.__name__
+            for k, v in m.get_save_weight_dict().items():
+                weights[name + "_" + k] = v.detach().cpu() if isinstance(v, torch.Tensor) else v
+    with open(os.path.join(save_path, "meta.json"), "w") as f:
+        json.dump(meta, f)
+    torch.save(weights, os.path.join(save_path, "weights.pth"))
+    return meta
+
+
+def load_bnn(model: nn.Module, load_path: str, device=None, **ctor_kwargs) -> nn.Module:
+    """Read a directory written by the reference's save_bnn (utils.py:87-94) the way its load_bnn does (utils.py:97-124): every
+    nn.Linear named in meta.json is replaced by the class of that name from pb_llm_amd.quant, built from the stored fp16 weight
+    and bias -- here the MI355X-backed class, on `device` (default: the replaced module's).  The reference calls
+    `Class(weight, bias)`; classes that need more (BinaryXnorExceptOutliersLinear: outlier_fraction, which the reference's
+    dead-code loader cannot supply) take it from ctor_kwargs."""
+    from . import quant as Q
+    with open(os.path.join(load_path, "meta.json")) as f:
+        meta = json.load(f)
+    weights = torch.load(os.path.join(load_path, "weights.pth"), weights_only=False)
+    modules = dict(model.named_modules())
+    for name, module in modules.items():
+        if not isinstance(module, nn.Linear) or name not in meta:
+            continue
+        cls = getattr(Q, meta[name], None)
+        if cls is None or not (isinstance(cls, type) and issubclass(cls, BinaryInterface)):
+            raise ValueError(f"{name}: unknown binarization class {meta[name]!r}")
+        w, b = weights[name + "_weight"], weights.get(name + "_bias")
+        if tuple(w.shape) != (module.out_features, module.in_features):
+            raise ValueError(f"{name}: stored weight is {tuple(w.shape)}, the model's Linear is {(module.out_features, module.in_features)}")
+        dev = device if device is not None else module.weight.device
+        b = b.data if isinstance(b, nn.Parameter) else b
+        new = cls(w.to(dev), None if b is None else b.to(dev), **ctor_kwargs) if ctor_kwargs else cls(w.to(dev), None if b is None else b.to(dev))
+        new.global_name = name.replace(".", "/")
+        ind = name.rfind(".")
+        father = modules[""] if ind == -1 else modules[name[:ind]]
+        setattr(father, name[ind + 1:], new.to(dev))
+    return model
+
+
 def mask_path(low_frac, global_name: str, root: str = "gptq_pb/outputs/mask") -> str:
     """File name gptq_pb uses for a layer's low (= binarized) mask (gptq.py:111-114)."""
     return os.path.join(root, f"mask_{low_frac}_{global_name.replace('/', '_')}.pkl")

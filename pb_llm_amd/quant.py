@@ -138,6 +138,11 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     Differentiable in x (see _PackedLinearFn); the kernels themselves never run under autograd."""
     if torch.is_grad_enabled() and x.requires_grad:
         return _PackedLinearFn.apply(x, (packed, bias_f32), out_f32, dense_dtype)
+    if x.dtype == torch.float16 and x.is_cuda and 0 < x.numel() <= MFMA_MAX * packed.K:
+        nat = _lib.native_linear()                   # decode regime: one native call (csrc/pbl_torch.cpp)
+        if nat is not None:
+            return nat(packed.blob, bias_f32, x, packed.N, packed.K, packed.P, packed.G, packed.NRB, packed.flags,
+                       packed.max_nch, packed.max_nexc, out_f32)
     with torch.no_grad():
         return _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype)
 
@@ -246,6 +251,10 @@ class PBLinear(nn.Module, BinaryInterface):
         """From a dense fake-quant weight as gptq_pb writes it back (gptq.py:180-184).
         low_mask (True = binarized, gptq.py:92,99) and the HighQuantizer scale/zero are
         optional: without them the structure is inferred from the values."""
+        if W_fq.is_cuda and low_mask is not None and high_scale is not None:
+            p = _from_dense_dev(W_fq, low_mask, groupsize, high_scale, high_zero)
+            if p is not None:
+                return cls(p, bias, W_fq.dtype)
         Wn = W_fq.detach().cpu().float().numpy()
         lm = low_mask.detach().cpu().numpy().astype(bool) if isinstance(low_mask, torch.Tensor) else low_mask
         hi, lo = infer_levels(Wn, groupsize, lm)
@@ -336,6 +345,37 @@ class PBLinear(nn.Module, BinaryInterface):
         p = self._meta
         return (f"in_features={p.K}, out_features={p.N}, bias={self.pbl_bias is not None}, groups={p.G}, "
                 f"salient={p.nnz} ({p.nnz / (p.N * p.K):.3%}), exceptions={p.nexc}, packed_bytes={p.nbytes}")
+
+
+def _from_dense_dev(W_fq: torch.Tensor, low_mask, groupsize: int, high_scale, high_zero) -> PackedWeight | None:
+    """PBLinear.from_dense without leaving the GPU, for the PTQ case (mask and HighQuantizer state known): the two levels of
+    every (row, group) are the extremes of its binarized positions -- what packing.infer_levels finds as "the two most
+    frequent values" whenever a third value (sign(0) -> mu) is rarer than both, which is checked on the device; the blob
+    then comes from the device packer, byte-identical to the host path's.  None: the check failed (fall back to the host)."""
+    dev = W_fq.device
+    W = W_fq.detach().float()
+    N, K = W.shape
+    gs = K if groupsize == -1 else groupsize
+    if K % gs:
+        return None
+    G = K // gs
+    lm = torch.as_tensor(low_mask, device=dev).bool().reshape(N, G, gs)
+    Wg = W.reshape(N, G, gs)
+    inf = torch.tensor(float("inf"), device=dev)
+    hi = torch.where(lm, Wg, -inf).amax(-1)
+    lo = torch.where(lm, Wg, inf).amin(-1)
+    n = lm.sum(-1)
+    chi = (lm & (Wg == hi.unsqueeze(-1))).sum(-1)
+    clo = (lm & (Wg == lo.unsqueeze(-1))).sum(-1)
+    third = n - torch.where(hi == lo, chi, chi + clo)
+    ok = (n == 0) | (third < torch.minimum(chi, clo)) | ((hi == lo) & (third == 0))
+    if not bool(ok.all()):
+        return None
+    empty = n == 0
+    hi = torch.where(empty, torch.zeros_like(hi), hi)
+    lo = torch.where(empty, torch.zeros_like(lo), lo)
+    f = lambda t: torch.as_tensor(np.asarray(t) if not isinstance(t, torch.Tensor) else t, device=dev).float().reshape(-1)   # noqa: E731
+    return pack_dense_dev(W, hi, lo, f(high_scale), f(high_zero), (~lm).reshape(N, K), sal_f16=W_fq.dtype == torch.float16)
 
 
 def _pack_sign_like(w_sim: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor) -> PackedWeight:

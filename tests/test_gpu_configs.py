@@ -350,6 +350,21 @@ def test_g9_hessian_mask_module_vs_reference_golden(tmp_path, monkeypatch):
         assert_parity(m2(xt), g["fallback_y_eval"].astype(np.float64), 2e-5)
 
 
+def test_g10_reference_save_bnn_directory_runs_on_the_gpu(tmp_path):
+    """a checkpoint directory in the reference's save_bnn layout (utils.py:87-94; tests/golden/g10 was written by the
+    reference's own save_bnn) loaded by pb_llm_amd.io.load_bnn into the MI355X-backed classes: the forward equals what the
+    reference's modules computed after ITS load_bnn round trip"""
+    from test_round3_cpu import Net, write_reference_directory
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g10_save_bnn_directory.npz"))
+    write_reference_directory(g, str(tmp_path / "ckpt"))
+    net = pbio.load_bnn(Net().to(DEV), str(tmp_path / "ckpt")).eval()
+    assert net.fc1.weight.is_cuda and isinstance(net.blk[0], Q.BinaryLinear)
+    x = synth.normal((4, 256), 10, 5, 1.0)
+    with torch.no_grad():
+        assert_parity(net.fc1(T(x)), g["y_fc1_loaded"].astype(np.float64), 2e-5)
+        assert_parity(net(T(x)), g["y_loaded"].astype(np.float64), 1e-4)
+
+
 # ------------------------------------------------------------------------------------------- autograd / cache
 def test_packed_forward_input_gradient():
     """the reference's fake-quant nn.Linear is differentiable in x: dx = dy @ W through the packed path, for every regime"""

@@ -93,3 +93,32 @@ def test_modules_pack_on_the_gpu_like_on_the_host():
     ref = torch.nn.functional.linear(x, lin.weight.data, lin.bias.data)
     rel, ratio = O.parity_errors(pb(x).float().cpu().numpy(), ref.float().cpu().numpy().astype(np.float64))
     assert rel < 2e-3
+
+
+@pytest.mark.parametrize("N,K,lf,f16,gs", [(256, 1024, 0.9, True, -1), (100, 1536, 0.9, False, -1), (64, 1024, 0.9, True, 128), (4096, 4096, 0.95, True, -1)])
+def test_from_dense_on_the_gpu_is_byte_identical_to_the_host_route(N, K, lf, f16, gs):
+    """PBLinear.from_dense with a GPU weight, the PTQ low mask and the HighQuantizer state (what gptq_pb/run.py has in hand
+    after fasterquant, gptq.py:155,180-184): levels found on the device, blob from the device packer -- the bytes the host
+    route (numpy level inference + host packer) produces for the same tensors; a sign(0) value that is rarer than both levels
+    becomes an exception on both routes; a row where it is NOT rarer sends the whole layer through the host route."""
+    W = synth.llm_weight(N, K, seed=N + K + 1, heavy_tail=True)
+    W[1, 9] = 0.0
+    mask = O.ptq_low_mask(W, lf, "magnitude", None, gs)
+    r = O.ptq_rtn(W, mask, 8, gs)
+    Wd = torch.from_numpy(r["W_fq"])
+    Wd = Wd.half() if f16 else Wd
+    lm = torch.from_numpy(mask)
+    host = Q.PBLinear.from_dense(Wd, None, lm, gs, r["hscale"], r["hzero"])
+    dev = Q.PBLinear.from_dense(Wd.to(DEV), None, lm.to(DEV), gs, r["hscale"], r["hzero"])
+    assert dev.pbl_blob.is_cuda and not host.pbl_blob.is_cuda
+    assert np.array_equal(host.pbl_blob.numpy(), dev.pbl_blob.cpu().numpy())
+    if N == 64:       # a row-group holding ONE value at all binarized positions but two: three values, the middle one not rarer
+        Wb = r["W_fq"].copy()
+        g0 = np.nonzero(mask[5, :128])[0]
+        Wb[5, g0] = Wb[5, g0[0]]
+        Wb[5, g0[1]] += 0.5; Wb[5, g0[2]] += 1.0
+        Wt = torch.from_numpy(Wb).half() if f16 else torch.from_numpy(Wb)
+        assert Q._from_dense_dev(Wt.to(DEV), lm.to(DEV), gs, r["hscale"], r["hzero"]) is None
+        h2 = Q.PBLinear.from_dense(Wt, None, lm, gs, r["hscale"], r["hzero"])
+        d2 = Q.PBLinear.from_dense(Wt.to(DEV), None, lm.to(DEV), gs, r["hscale"], r["hzero"])
+        assert np.array_equal(h2.pbl_blob.numpy(), d2.pbl_blob.cpu().numpy())

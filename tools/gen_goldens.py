@@ -333,7 +333,52 @@ def g9(out):
     save(out, "g9_hessian_mask_module", **res)
 
 
-ALL = dict(G1=g1_g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9)
+def g10(out):
+    """A directory written by the reference's own save_bnn (utils.py:87-94: meta.json {module name -> class name},
+    weights.pth {name + "_weight": the module's weight as fp16, name + "_bias"}) for a two-layer model whose Linears were
+    swapped for quant.BinaryLinear / quant.XnorBinaryLinear the way utils.py:97-124 swaps them; plus the reference modules'
+    forwards after a load_bnn round trip (load_bnn rebuilds the modules from the fp16 weights)."""
+    import json
+    import utils as ref_utils                          # reference utils.py (save_bnn / load_bnn)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = nn.Linear(256, 128, bias=True)
+            self.blk = nn.Sequential(nn.Linear(128, 64, bias=False))
+
+        def forward(self, x):
+            return self.blk(self.fc1(x))
+
+    W1 = synth.llm_weight(128, 256, seed=10)
+    b1 = synth.normal((128,), 10, 3, 0.1)
+    W2 = synth.llm_weight(64, 128, seed=11)
+    W2[5, 7] = 0.0
+    x = synth.normal((4, 256), 10, 5, 1.0)
+    net = Net()
+    net.fc1 = quant.XnorBinaryLinear(T(W1), T(b1))
+    net.blk[0] = quant.BinaryLinear(T(W2), None)
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        with quiet():
+            ref_utils.save_bnn(net, td)
+        res["meta_json"] = np.array(open(os.path.join(td, "meta.json")).read())
+        wts = torch.load(os.path.join(td, "weights.pth"))
+        res["keys"] = np.array(json.dumps(sorted(wts)))
+        for k, v in wts.items():
+            res["w__" + k] = np.zeros(0, np.float16) if v is None else v.detach().numpy()
+            res["none__" + k] = np.array(v is None)
+        fresh = Net()
+        with quiet():
+            ref_utils.load_bnn(fresh, td)
+        assert isinstance(fresh.fc1, quant.XnorBinaryLinear) and isinstance(fresh.blk[0], quant.BinaryLinear)
+        with torch.no_grad():
+            res["y_loaded"] = fresh(T(x)).numpy()
+            res["y_fc1_loaded"] = fresh.fc1(T(x)).numpy()
+    save(out, "g10_save_bnn_directory", **res)
+
+
+ALL = dict(G1=g1_g2, G3=g3, G4=g4, G5=g5, G6=g6, G7=g7, G8=g8, G9=g9, G10=g10)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
