@@ -52,6 +52,10 @@ GEMM_THRESHOLD = 12
 #              same shapes (round 2: 120 / 344 / 327), forward 57 ms.  Use it where the dense copy must not exist.
 # fp32 / bf16 activations, an fp32 dense dtype, odd group sizes and K % 8 != 0 always take the library path.
 GEMM_BACKEND = os.environ.get("PBL_GEMM_BACKEND", "library")
+# bf16 activations at <= 32 rows run as ONE fp16 pass (bf16 -> fp16 is exact inside fp16's range); values beyond +-65504 are
+# saturated and NaN / inf do not survive the clamp.  True: check the range first (one device -> host sync per call, ~10 us) and
+# send such inputs through the dense path instead, so that overflow propagates exactly as in the reference's bf16 F.linear.
+BF16_RANGE_CHECK = os.environ.get("PBL_BF16_RANGE_CHECK", "0") == "1"
 
 
 def fused_gemm_ok(packed: PackedWeight) -> bool:
@@ -196,6 +200,12 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         # bf16 -> fp16 is exact (8 significand bits into 11) inside fp16's range: ONE pass, fp32 accumulation, bf16 result.
         # Out-of-range values are saturated to +-65504 (the two-term split below cannot represent them either); magnitudes
         # below 2^-24 round to fp16 subnormals (absolute error < 3e-8).
+        if BF16_RANGE_CHECK and not bool((x2.abs() <= 65504.0).all()):       # (NaN compares false: caught as well)
+            # out-of-range / non-finite bf16 activations: the dense path, which computes in the activation's own range like
+            # the reference's bf16 F.linear -- the same result whatever the token count (the GEMM regime never clamps)
+            W = unpack_on_device(packed, torch.float32)
+            y = torch.nn.functional.linear(x2.float(), W, bias_f32)
+            return (y if out_f32 else y.to(x.dtype)).reshape(*lead, packed.N)
         xc = x2.float().clamp_(-65504.0, 65504.0).half().contiguous()
         y = torch.empty(M, packed.N, dtype=torch.float32, device=x.device)
         run(layer, xc, y, M, True)
@@ -319,7 +329,12 @@ class PBLinear(nn.Module, BinaryInterface):
 
     @property
     def weight(self) -> torch.Tensor:
-        return self.packed.unpack().to(self.weight_dtype)
+        """the dense simulated weight, materialised on demand ON THE BLOB'S DEVICE (pbl_unpack_dev on the GPU: no host round trip;
+        the host unpacker for a CPU-resident module)"""
+        p = self.packed
+        if p.blob.is_cuda:
+            return unpack_on_device(p, torch.float32).to(self.weight_dtype)
+        return p.unpack().to(self.weight_dtype)
 
     @property
     def bias(self):
@@ -336,9 +351,10 @@ class PBLinear(nn.Module, BinaryInterface):
 
     def to_regular_linear(self) -> nn.Linear:
         lin = nn.Linear(self.in_features, self.out_features, bias=self.pbl_bias is not None)
-        lin.weight.data = self.weight
+        w = self.weight
+        lin.weight.data = w
         if self.pbl_bias is not None:
-            lin.bias.data = self.pbl_bias.to(self.weight_dtype).cpu()
+            lin.bias.data = self.pbl_bias.to(self.weight_dtype).to(w.device)
         return lin
 
     def extra_repr(self):

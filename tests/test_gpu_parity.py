@@ -519,3 +519,29 @@ def test_torch_compile_traces_pbllm_linear_op(llama7b_qproj):
         out2 = torch.compile(blk, backend="aot_eager", fullgraph=True)(x)
     assert any("pbllm.linear" in t for t in seen), seen
     assert torch.equal(out, eager) and torch.equal(out2, eager)
+
+
+def test_bf16_activations_out_of_fp16_range_with_the_range_check():
+    """bf16 activations beyond +-65504 (or non-finite): the one-pass fp16 route saturates them; with quant.BF16_RANGE_CHECK the
+    call is routed through the dense path and matches the float64 oracle on the true bf16 values, and NaN propagates."""
+    N, K = 64, 1024
+    W = synth.llm_weight(N, K, seed=2)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    layer = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+    x = torch.from_numpy(synth.activations((2, K), 4, 21)).float().to(DEV)
+    x[0, 7] = 3.0e5
+    xb = x.bfloat16()
+    ref = O.dense_linear(xb.float().cpu().numpy(), torch.from_numpy(r["W_fq"]).half().float().numpy())
+    old = Q.BF16_RANGE_CHECK
+    try:
+        Q.BF16_RANGE_CHECK = False
+        sat = layer(xb).float().cpu().numpy()
+        assert O.parity_errors(sat[1:], ref[1:])[0] < 1e-2 and O.parity_errors(sat[:1], ref[:1])[0] > 0.05     # row 0 saturated
+        Q.BF16_RANGE_CHECK = True
+        assert O.parity_errors(layer(xb).float().cpu().numpy(), ref)[0] < 1e-2
+        xb[1, 3] = float("nan")
+        y = layer(xb)
+        assert torch.isnan(y[1]).all() and not torch.isnan(y[0]).any()
+    finally:
+        Q.BF16_RANGE_CHECK = old

@@ -144,7 +144,7 @@ def test_g5_gptq_loop_on_gpu(metric, gs):
     assert e_gptq < np.linalg.norm(Xc @ rtn.T - ref)
     # ... and packs straight into the PB format: forward == dense F.linear on the same weights
     pb = q.to_pb().to(DEV)
-    np.testing.assert_array_equal(pb.weight.numpy(), Wq)
+    np.testing.assert_array_equal(pb.weight.cpu().numpy(), Wq)
     for x in (x1, x32):
         y = pb(T(x))
         rel, ratio = O.parity_errors(y.float().cpu().numpy(), O.dense_linear(x, Wq))
