@@ -76,12 +76,15 @@ __device__ __forceinline__ void class_consts(int ci, float& A, float& B) {
 // (w & M) | C in one VALU op.  hipcc splits it into v_and + v_or because VOP3 takes no
 // literal on gfx9; with M in an SGPR and C in a VGPR it is a single v_and_or_b32.
 template <int CI>
-__device__ __forceinline__ uint32_t unpack_pair(uint32_t w, uint32_t c_one) {
+__device__ __forceinline__ uint32_t unpack_pair(uint32_t w, uint32_t c_one, float order_after) {
     if constexpr (BitClass<CI>::C == 0u) {
         return w & BitClass<CI>::M;
     } else {
+        // `order_after` (an accumulator the previous class step wrote) is an unused input: it pins this instruction behind that
+        // step.  Without it hipcc schedules all 24 v_and_or of a tile first (to re-request the tile registers early), holds 24
+        // temporaries and the kernel drops from 8 to 6 waves per SIMD.
         uint32_t t;
-        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(t) : "v"(w), "s"(BitClass<CI>::M), "v"(c_one));
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(t) : "v"(w), "s"(BitClass<CI>::M), "v"(c_one), "v"(order_after));
         return t;
     }
 }
@@ -89,8 +92,9 @@ __device__ __forceinline__ uint32_t unpack_pair(uint32_t w, uint32_t c_one) {
 template <int MB, int CI>
 __device__ __forceinline__ void class_step(uint32_t w, uint32_t ws, uint32_t c_one, const uint32_t (&xr)[MB],
                                            float (&acc)[MB][16]) {
-    const uint32_t t0 = unpack_pair<CI>(w, c_one);
-    const uint32_t t1 = unpack_pair<CI>(ws, c_one);
+    const float dep = acc[0][(CI + 7) & 7];
+    const uint32_t t0 = unpack_pair<CI>(w, c_one, dep);
+    const uint32_t t1 = unpack_pair<CI>(ws, c_one, dep);
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
         acc[m][CI] = dot2(t0, xr[m], acc[m][CI]);
@@ -269,6 +273,12 @@ __device__ __forceinline__ void chunk_accumulate(uint32_t xbase, uint32_t tok_st
     }
 }
 
+#ifndef PBL_TILE_RING
+#define PBL_TILE_RING 2          // 2: rotating tile registers (63 VGPRs, 8 waves/SIMD; hipcc waits vmcnt(0) at the rotation, so
+                                 // the lookahead is one panel).  3: static three-set ring, a true two-panel lookahead at 74 VGPRs
+                                 // = 6 waves/SIMD.  Measured equal on the driver command (round 3, profiles/r03_gemv_ring.md):
+                                 // 0.669-0.688 of the HBM roofline for 3 vs 0.663-0.680 for 2 -- kept selectable, default unchanged.
+#endif
 #ifndef PBL_MIN_WAVES
 #define PBL_MIN_WAVES 1
 #endif
@@ -339,7 +349,11 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     const u32x4* codep = reinterpret_cast<const u32x4*>(sal + PBL_SAL_CODE_OFF(nchu));
     const uint8_t* tailcnt = sal + PBL_SAL_TAILCNT_OFF(nchu);
 
-    u32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0};
+    // Three tile registers sets, statically indexed: a set is re-requested for the panel three steps on right after its last
+    // use, so a request has two whole panels of arithmetic to land.  (Rounds 1-2 rotated t0 <- t1 <- t2: the copy touches the
+    // register of a load issued at the top of the same iteration, hipcc waits vmcnt(0) in front of it, and the "two panels
+    // ahead" prefetch was in fact one panel deep -- 1 KiB per wave in flight.)
+    u32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
     uint32_t s_c0 = 0;
     u32x4 s_d4 = {0, 0, 0, 0}, s_q4 = {0, 0, 0, 0};
     uint32_t abl = 0;
@@ -347,6 +361,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     if (active && PBL_ABLATE != 2) {
         if (wslot < P) t0 = __builtin_nontemporal_load(tiles + wslot * 64);
         if (wslot + WSTEP < P) t1 = __builtin_nontemporal_load(tiles + (wslot + WSTEP) * 64);
+        if (PBL_TILE_RING == 3 && wslot + 2 * WSTEP < P) t2 = __builtin_nontemporal_load(tiles + (wslot + 2 * WSTEP) * 64);
         if (nch > wslot * PBL_WAVE) {
             const int c_first = wslot * PBL_WAVE + lane;
             const int cc = c_first < nch ? c_first : nch - 1;
@@ -388,21 +403,42 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     // fp16x2 (1.0, 1.0) kept in a VGPR the compiler cannot constant-fold into a literal
     uint32_t c_one = 0x3C003C00u;
     asm volatile("" : "+v"(c_one));
-    for (int p = wslot; p < P; p += WSTEP) {
-        u32x4 t2 = t1;
-        if (p + 2 * WSTEP < P && PBL_ABLATE != 2) t2 = __builtin_nontemporal_load(tiles + (p + 2 * WSTEP) * 64);
+    auto panel = [&](const u32x4& t, int p) {
         const uint32_t* xw = reinterpret_cast<const uint32_t*>(xs + p * PBL_PANEL_COLS) + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             uint32_t xr[MB];
 #pragma unroll
             for (int m = 0; m < MB; ++m) xr[m] = xw[(m * xstride) / 2 + i * 64];
-            if (PBL_ABLATE == 1) { abl ^= t0[i] ^ xr[0]; continue; }
-            word_step<MB>(t0[i] ^ (PBL_ABLATE == 2 ? uint32_t(p * 4 + i + lane) : 0u), c_one, xr, acc, xl);
+            if (PBL_ABLATE == 1) { abl ^= t[i] ^ xr[0]; continue; }
+            word_step<MB>(t[i] ^ (PBL_ABLATE == 2 ? uint32_t(p * 4 + i + lane) : 0u), c_one, xr, acc, xl);
         }
-        t0 = t1;
-        t1 = t2;
+    };
+#if PBL_TILE_RING == 3
+    for (int p = wslot; p < P; p += 3 * WSTEP) {
+        panel(t0, p);
+        if (p + 3 * WSTEP < P && PBL_ABLATE != 2) t0 = __builtin_nontemporal_load(tiles + (p + 3 * WSTEP) * 64);
+        asm volatile("" ::: "memory");       // (keeps the next panel's LDS reads of x from being hoisted: 80 -> 64 VGPRs)
+        if (p + WSTEP < P) {
+            panel(t1, p + WSTEP);
+            if (p + 4 * WSTEP < P && PBL_ABLATE != 2) t1 = __builtin_nontemporal_load(tiles + (p + 4 * WSTEP) * 64);
+        }
+        asm volatile("" ::: "memory");
+        if (p + 2 * WSTEP < P) {
+            panel(t2, p + 2 * WSTEP);
+            if (p + 5 * WSTEP < P && PBL_ABLATE != 2) t2 = __builtin_nontemporal_load(tiles + (p + 5 * WSTEP) * 64);
+        }
+        asm volatile("" ::: "memory");
     }
+#else
+    for (int p = wslot; p < P; p += WSTEP) {              // the rotating form of rounds 1-2 (kept for A/B runs)
+        u32x4 tn = t1;
+        if (p + 2 * WSTEP < P && PBL_ABLATE != 2) tn = __builtin_nontemporal_load(tiles + (p + 2 * WSTEP) * 64);
+        panel(t0, p);
+        t0 = t1;
+        t1 = tn;
+    }
+#endif
 
     // reduce the 16 row accumulators now: from here on one register per token carries the
     // binary result (lane l holds row rho(l), see transpose_reduce16)

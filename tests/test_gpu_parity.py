@@ -116,7 +116,7 @@ def test_g5_ptq_from_dense_checkpoint_gpu(metric, gs, rtn, lf):
     mask = np.unpackbits(g["mask"])[:768 * 768].astype(bool).reshape(768, 768)
     layer = Q.PBLinear.from_dense(torch.from_numpy(g["W_fq"]), None, torch.from_numpy(mask), gs,
                                   g["hscale"], g["hzero"]).to(DEV)
-    np.testing.assert_array_equal(layer.weight.numpy(), g["W_fq"])   # exact repack of the checkpoint
+    np.testing.assert_array_equal(layer.weight.cpu().numpy(), g["W_fq"])   # exact repack of the checkpoint
     assert layer.packed.nexc <= 8, "fp16-rounded salients must stay 1-byte codes (PBL_FLAG_SAL_F16)"
     for x, key in ((x1, "y1"), (x32, "y32")):
         y = layer(T(x))
@@ -132,7 +132,7 @@ def test_g5_flattened_fp16_checkpoint_gpu(metric, gs):
     _, _, x1, x32 = g5_inputs()
     g = golden(g5_name(metric, gs, False, 0.9))
     layer = Q.PBLinear.from_dense(torch.from_numpy(g["W_fq"]), None, None, gs).to(DEV)
-    np.testing.assert_array_equal(layer.weight.numpy(), g["W_fq"])
+    np.testing.assert_array_equal(layer.weight.cpu().numpy(), g["W_fq"])
     assert layer.packed.nexc <= 0.02 * layer.packed.nnz   # off-grid leftovers only cost bytes
     assert_parity(layer(T(x32)), g["y32"])
     assert_parity(layer(T(x1)), O.dense_linear(x1, g["W_fq"]))
@@ -144,7 +144,7 @@ def test_g5_from_quantizers_matches_from_dense():
     mask = np.unpackbits(g["mask"])[:768 * 768].astype(bool).reshape(768, 768)
     a = Q.PBLinear.from_quantizers(torch.from_numpy(W16), torch.from_numpy(mask), g["mean"], g["scale"],
                                    g["hscale"], g["hzero"], dtype=torch.float16)
-    mism = np.count_nonzero(a.weight.numpy() != g["W_fq"])
+    mism = np.count_nonzero(a.weight.cpu().numpy() != g["W_fq"])
     assert mism <= 8
     assert_parity(a.to(DEV)(T(x1)), g["y1"])
 

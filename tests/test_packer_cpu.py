@@ -151,7 +151,7 @@ def test_fp16_checkpoint_packs_as_codes_not_exceptions():
     # flattened checkpoint, nothing but the fp16 matrix: structure re-inferred through the rounding
     from pb_llm_amd.quant import PBLinear
     layer = PBLinear.from_dense(torch.from_numpy(W16))
-    np.testing.assert_array_equal(layer.weight.numpy(), W16)
+    np.testing.assert_array_equal(layer.weight.cpu().numpy(), W16)
     assert layer.packed.nexc <= 0.05 * layer.packed.nnz
 
 

@@ -2,10 +2,12 @@
 # One gpurun call of round 3 (rewritten per call; results under gpurun_out/<tag>/).  Usage: tools/gpu_job.sh <tag>
 set -u
 export TMPDIR=/tmp
-O=gpurun_out/${1:-r3k}; mkdir -p $O
-timeout 1200 python -m pytest tests/test_gpu_pack.py tests/test_gpu_gemm.py tests/test_gpu_parity.py -q -x 2>&1 | tail -12 > $O/test_a.txt
-timeout 1200 python -m pytest tests/test_gpu_configs.py -q -x -k "g10 or g9 or fused_members or fused_decode or p2p" 2>&1 | tail -12 > $O/test_b.txt
-timeout 600 python tools/bench_host.py > $O/bench_host.json 2> $O/bench_host.err
-MODES=decode timeout 900 python tools/bench_llama7b.py > $O/llama7b_decode.json 2> $O/llama7b_decode.err
-PBL_NATIVE=0 MODES=decode timeout 900 python tools/bench_llama7b.py > $O/llama7b_decode_ctypes.json 2> $O/llama7b_decode_ctypes.err
-cat $O/test_a.txt $O/test_b.txt $O/bench_host.json $O/llama7b_decode.json $O/llama7b_decode_ctypes.json
+O=gpurun_out/${1:-r3l}; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -x 2>&1 | tail -5 > $O/test_gemv.txt
+for v in default ring2 ring3w7 ring3w8 default ring2; do
+  echo "== $v" >> $O/bench_gemv.txt
+  if [ $v = default ]; then L=""; else L="build/libpbl_$v.so"; fi
+  PBL_LIB=$L timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(round(d['value']), round(d['roofline']['frac'],4), round(d['roofline']['us_per_launch'],1))" >> $O/bench_gemv.txt
+done
+timeout 300 python tools/bench_p2p.py > $O/bench_p2p.json 2> $O/bench_p2p.err
+cat $O/test_gemv.txt $O/bench_gemv.txt $O/bench_p2p.json
