@@ -315,6 +315,16 @@ size_t pbl_gemm_workspace_bytes(const pbl_layer* layer, int M);
 int pbl_gemm_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* workspace, size_t workspace_bytes,
                     void* stream);
 int pbl_gemm_f16(const pbl_layer* layer, const void* x, void* y, int M, void* stream);   /* = pbl_gemm_f16_ex(.., 0, ..) */
+/* The two halves of pbl_gemm_f16_ws, for callers that build a layer's salient list once and use it many times, or build the
+ * NEXT layer's list on a second stream while this layer's GEMM runs (the perplexity loops call the same linears batch after
+ * batch: gptq_pb/eval_ppl_utils.py:55-64).  The list depends on the blob only -- never on x or M -- and stays valid until the
+ * blob changes.  pbl_gemm_list_bytes: its size (0: K > 16256, no list; use pbl_gemm_f16_ex).  pbl_gemm_prepare: one small
+ * kernel on `stream`.  pbl_gemm_f16_prepared: the GEMM over a prepared list, any M >= 1, results bit-identical to
+ * pbl_gemm_f16_ex / _ws.  The library keeps no reference to the workspace between calls. */
+size_t pbl_gemm_list_bytes(const pbl_layer* layer);
+int pbl_gemm_prepare(const pbl_layer* layer, void* workspace, size_t workspace_bytes, void* stream);
+int pbl_gemm_f16_prepared(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* Decode-time FUSED projections (q/k/v, gate/up: layers that read the same activation): L layers, ONE x [M, K] (fp16,
  * 16-B aligned rows are not required), ONE output matrix y [M, ldy] in which layer l owns the columns

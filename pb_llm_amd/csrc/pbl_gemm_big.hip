@@ -44,23 +44,25 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #define GW 64
 #ifndef NCONS
-#define NCONS 8                   // consumer (MFMA) waves: 256 / NCONS tokens each.  8 = two per SIMD: one's waits are the other's MFMAs
+#define NCONS 4                   // consumer (MFMA) waves, one per SIMD: 128 rows x 64 tokens each = 8 accumulator tiles of 32 x 32
 #endif
-#define GB_TPC (256 / NCONS)      // tokens per consumer wave (64 / 32)
-#define GB_TT (GB_TPC / 32)       // 32-token accumulator tiles per consumer (2 / 1)
-#define GB_PQ (GB_TPC / 8)        // 1 KiB DMA pieces per x slot (8 / 4)
-#define NPROD 4                   // producer (expand) waves: 2 records each
+#define GB_TPC (256 / NCONS)      // tokens per consumer wave
+#define GB_TT (GB_TPC / 32)       // 32-token accumulator tiles per consumer
+#define NPROD 4                   // producer (expand) waves of the in-kernel-decode build: 2 records each
+#ifndef NPROD_LIST
+#define NPROD_LIST 4              // ... of LIST mode (8 = one record each was measured equal: the producers are not the critical path)
+#endif
 #define NREC 8                    // records per workgroup tile
 #define GB_ROWS (NREC * 16)
 #define GB_TOK 256
 #define GB_HS 128                 // columns per A stage (half a slab)
-#define GB_XC 64                  // columns per x slot (sub-step)
-#define GB_XSLOTS 3
+#define GB_XC 64                  // columns per sub-step: 4 k-steps of 16; one lane's x of a sub-step is 64 contiguous bytes
 #define GB_AS_STAGE (GB_ROWS * GB_HS * 2)          // 32768 B
-#define GB_XSLOT_BYTES (GB_TPC * GB_XC * 2)         // 8192 / 4096 B: the consumer's tokens x 64 columns
-#define GB_XRING_BYTES (GB_XSLOTS * GB_XSLOT_BYTES)
-#define GB_X_OFF (2 * GB_AS_STAGE)
-#define GB_LDS (GB_X_OFF + NCONS * GB_XRING_BYTES)  // 163840 B
+#define GB_LDS (2 * GB_AS_STAGE)                   // 65536 B: the two A stages; x never enters LDS
+#define GB_EPI_BYTES (GB_LDS / NCONS)              // what a consumer's epilogue may use of it once the loop is over
+#ifndef GB_REFILL
+#define GB_REFILL 0               // x ring refill: 0 a whole sub-step at once (line-friendly), 1 piece by piece (longest lookahead)
+#endif
 // performance-analysis hook (tools/build_variant.sh): bit 0 no expansion in the loop, 1 no x staging in the loop, 2 no MFMA,
 // 3 no sign-plane expansion, 4 no salient overlay, 5 producers request nothing either (consumer loop alone), 6 no fragment
 // reads in the loop, 7 no barriers in the loop.  0 in every
@@ -435,6 +437,7 @@ struct RecL {
     const pbl_rowparams* params;
     const float2* ghl;
     uint32_t ofs0, ofs1;    // lane l: ofs[l], ofs[64 + l]  (entry ranges of all half slabs)
+    uint32_t cap_m1;        // last valid index of the record's entry words
     // even / odd stages keep their own registers: a stage's registers are re-requested for the stage after next right after
     // their last use, so a request has two stages to land and is never touched (copied) before it is needed
     uint32_t d[2];          // sign-plane dword
@@ -444,14 +447,33 @@ struct RecL {
 __device__ __forceinline__ uint32_t ofs_at(const RecL& R, int h) {          // wave uniform
     return h < 64 ? __builtin_amdgcn_readlane(R.ofs0, h) : __builtin_amdgcn_readlane(R.ofs1, h - 64);
 }
-__device__ __forceinline__ void request_list(const RecL& R, int h, int NH, int lane, uint32_t (&e)[GB_LPF]) {
+// The stage requests of LIST mode.  Two rules, both about `s_waitcnt vmcnt`:
+//  * UNCONDITIONAL (clamped addresses instead of predicates or branches): every stage issues exactly 1 + GB_LPF loads per
+//    record, so "the set requested two stages ago has landed" is `vmcnt(records per wave * (1 + GB_LPF))` -- the set requested ONE stage ago stays
+//    in flight.  Words beyond the stage's range are never stored (expand_list masks by the range).
+//  * issued from inline asm, waited for by wait_set(): hipcc's own bookkeeping gives up on this loop (it emitted ONE
+//    `vmcnt(0)` per two stages, right after the odd stage's requests: a full memory latency exposed per iteration, and the
+//    "two stages ahead" request was in effect zero to one stage ahead).  The registers are written by the asm load, named as
+//    read-write operands of the wait, and only used behind it; each set is re-requested after its last use, so no copy of an
+//    in-flight register is ever needed (checked in the ISA: no v_mov of d / e between request and wait).
+__device__ __forceinline__ void request_stage(const RecL& R, int h, int NH, int P, int lane, uint32_t& d, uint32_t (&e)[GB_LPF]) {
+    const uint32_t* pd = R.tile_dw + size_t(min(h >> 2, P - 1)) * 256 + (h & 3);      // dword (h & 3) of panel h >> 2
+    asm volatile("global_load_dword %0, %1, off nt" : "=&v"(d) : "v"(pd) : "memory");
+    const uint32_t lo = ofs_at(R, min(h, NH - 1));
 #pragma unroll
-    for (int k = 0; k < GB_LPF; ++k) e[k] = 0;
-    if (h >= NH) return;
-    const uint32_t lo = ofs_at(R, h), n = ofs_at(R, h + 1) - lo;
-#pragma unroll
-    for (int k = 0; k < GB_LPF; ++k)
-        if (uint32_t(lane) + 64u * k < n) e[k] = R.lst[lo + lane + 64 * k];
+    for (int k = 0; k < GB_LPF; ++k) {
+        const uint32_t* pe = R.lst + min(lo + uint32_t(lane) + 64u * k, R.cap_m1);
+        asm volatile("global_load_dword %0, %1, off" : "=&v"(e[k]) : "v"(pe) : "memory");
+    }
+}
+static_assert(GB_LPF == 4, "wait_set spells the operands out");
+__device__ __forceinline__ void wait_set(uint32_t& d0, uint32_t (&e0)[GB_LPF], uint32_t& d1, uint32_t (&e1)[GB_LPF]) {   // 2 records per wave
+    asm volatile("s_waitcnt vmcnt(10)"
+                 : "+v"(d0), "+v"(e0[0]), "+v"(e0[1]), "+v"(e0[2]), "+v"(e0[3]), "+v"(d1), "+v"(e1[0]), "+v"(e1[1]), "+v"(e1[2]), "+v"(e1[3])
+                 :: "memory");
+}
+__device__ __forceinline__ void wait_set(uint32_t& d0, uint32_t (&e0)[GB_LPF]) {                                           // 1 record per wave
+    asm volatile("s_waitcnt vmcnt(5)" : "+v"(d0), "+v"(e0[0]), "+v"(e0[1]), "+v"(e0[2]), "+v"(e0[3]) :: "memory");
 }
 __device__ __forceinline__ void store_entry(char* smem, uint32_t recaddr, uint32_t w) {
     *reinterpret_cast<uint16_t*>(smem + recaddr + (w >> 16)) = uint16_t(w & 0xFFFFu);
@@ -464,8 +486,14 @@ __device__ __forceinline__ void expand_list(const RecL& R, int h, const uint32_t
         if (__any(uint32_t(lane) + 64u * k < n)) {             // (wave uniform: most half slabs stop after one or two)
             if (uint32_t(lane) + 64u * k < n) store_entry(smem, recaddr, e[k]);
         }
-    for (uint32_t i = 64u * GB_LPF + uint32_t(lane); __any(i < n); i += 64u)
-        if (i < n) store_entry(smem, recaddr, R.lst[lo + i]);
+    // more than 64 * GB_LPF entries in one (record, half slab) -- rare: load and wait inside ONE asm block, invisible to the
+    // compiler's vmcnt bookkeeping (a compiler-visible load in a data-dependent loop makes every wait of the stage loop vmcnt(0))
+    for (uint32_t i = 64u * GB_LPF + uint32_t(lane); __any(i < n); i += 64u) {
+        uint32_t w;
+        const uint32_t* src = R.lst + min(lo + i, lo + n - 1u);
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(w) : "v"(src) : "memory");
+        if (i < n) store_entry(smem, recaddr, w);
+    }
     asm volatile("" ::: "memory");
 }
 template <typename REC>
@@ -478,6 +506,17 @@ __device__ __forceinline__ void load_levels_t(REC& R, uint32_t G, uint32_t g, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) R.hl[r] = __builtin_amdgcn_readlane(w, r);
 }
+// the same at a group boundary INSIDE the stage loop of LIST mode: load + wait in one asm block (see expand_list)
+__device__ __forceinline__ void load_levels_inloop(RecL& R, uint32_t G, uint32_t g, int lane) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 v;
+    const float2* src = R.ghl + size_t(lane & 15) * G + g;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+    const uint32_t hh = h16(v.x), ll = h16(v.y);
+    const uint32_t w = (((hh - ll) & 0xFFFFu) << 16) | ll;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) R.hl[r] = __builtin_amdgcn_readlane(w, r);
+}
 // start-up in two phases so that the requests of BOTH records of a wave are in flight together (a wave that finishes one
 // record's dependent chain before it starts the other's pays four memory round trips instead of two)
 __device__ __forceinline__ uint4 init_list_a(RecL& R, const GemmArgs& a, uint32_t rb, int NH, int lane) {
@@ -486,6 +525,7 @@ __device__ __forceinline__ uint4 init_list_a(RecL& R, const GemmArgs& a, uint32_
     R.ofs0 = lane <= NH ? ofs[lane] : 0u;
     R.ofs1 = lane + 64 <= NH ? ofs[lane + 64] : 0u;
     R.lst = a.lst + size_t(rb) * a.cap;
+    R.cap_m1 = a.cap - 1u;
     return reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[rb];
 }
 __device__ __forceinline__ void init_list_b(RecL& R, const GemmArgs& a, const uint4& info, int NH, int lane) {
@@ -494,25 +534,19 @@ __device__ __forceinline__ void init_list_b(RecL& R, const GemmArgs& a, const ui
     R.tile_dw = reinterpret_cast<const uint32_t*>(rec + PBL_TILES_OFF(L.G)) + lane * 4;
     R.params = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
     R.ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
-    R.d[0] = load_dw(R, 0, int(L.P));
-    R.d[1] = load_dw(R, 1, int(L.P));
-    request_list(R, 0, NH, lane, R.e[0]);
-    request_list(R, 1, NH, lane, R.e[1]);
 }
 
 // ---- consumer helpers -------------------------------------------------------------------------------------------------
-struct Frag { v8h a[4], b[GB_TT]; };
+struct Frag { v8h a[4]; };
 
-__device__ __forceinline__ void load_frag(Frag& f, const char* smem, uint32_t aaddr, uint32_t baddr, bool inloop = true) {
-    if ((PBL_GEMM_ABLATE & 64) && inloop) { asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0])); return; }
+__device__ __forceinline__ void load_frag(Frag& f, const char* smem, uint32_t aaddr, bool inloop = true) {
+    if ((PBL_GEMM_ABLATE & 64) && inloop) { asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3])); return; }
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) f.a[rt] = *reinterpret_cast<const v8h*>(smem + aaddr + rt * 8192);
-#pragma unroll
-    for (int tt = 0; tt < GB_TT; ++tt) f.b[tt] = *reinterpret_cast<const v8h*>(smem + baddr + tt * 4096);
 }
 
 template <bool Y32, bool LIST>
-__global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs a) {
+__global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pbl_gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -537,32 +571,39 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
 #endif
         if constexpr (LIST) {
             // the salient entries come ready to store from the per-call workspace (pbl_gemm_prep_kernel)
-            RecL R[2];
-            uint4 info[2];
+            constexpr int RPP = NREC / NPROD_LIST;                // records per producer wave
+            static_assert(RPP == 1 || RPP == 2, "wait_set exists for one and two records per wave");
+            RecL R[RPP];
+            uint4 info[RPP];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) info[i] = init_list_a(R[i], a, min(rowblk * NREC + 2 * p + i, L.NRB - 1), NH, lane);
+            for (int i = 0; i < RPP; ++i) info[i] = init_list_a(R[i], a, min(rowblk * NREC + RPP * p + i, L.NRB - 1), NH, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) init_list_b(R[i], a, info[i], NH, lane);
+            for (int i = 0; i < RPP; ++i) init_list_b(R[i], a, info[i], NH, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) load_levels_t(R[i], L.G, 0, lane);
+            for (int i = 0; i < RPP; ++i) load_levels_t(R[i], L.G, 0, lane);
+            // stages 0 and 1 requested set by set: from here on exactly RPP * (1 + GB_LPF) younger loads follow a set's requests
+#pragma unroll
+            for (int i = 0; i < RPP; ++i) request_stage(R[i], 0, NH, int(L.P), lane, R[i].d[0], R[i].e[0]);
+#pragma unroll
+            for (int i = 0; i < RPP; ++i) request_stage(R[i], 1, NH, int(L.P), lane, R[i].d[1], R[i].e[1]);
             auto produce = [&](int h, auto par_tag) {             // stage h from register set PAR = h & 1
                 constexpr int PAR = decltype(par_tag)::value;
                 const uint32_t stage = uint32_t(PAR) * GB_AS_STAGE;
                 const int kpairs = min(GB_HS, K - h * GB_HS) >> 1;
                 const bool work = !(PBL_GEMM_ABLATE & 1) || h == 0;
+                // this set has landed; the other one stays in flight
+                if constexpr (RPP == 2) wait_set(R[0].d[PAR], R[0].e[PAR], R[RPP - 1].d[PAR], R[RPP - 1].e[PAR]);
+                else wait_set(R[0].d[PAR], R[0].e[PAR]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint32_t recaddr = stage + uint32_t(2 * p + i) * 4096u;
+                for (int i = 0; i < RPP; ++i) {
+                    const uint32_t recaddr = stage + uint32_t(RPP * p + i) * 4096u;
                     if (work && !(PBL_GEMM_ABLATE & 8)) {
                         if (kpairs < GB_HS / 2) expand_sign<true>(R[i], R[i].d[PAR], smem_b, recaddr, lane, kpairs);
                         else expand_sign<false>(R[i], R[i].d[PAR], smem_b, recaddr, lane, kpairs);
                     }
                     if (work && !(PBL_GEMM_ABLATE & 16)) expand_list(R[i], h, R[i].e[PAR], smem_b, recaddr, lane);
-                    if (!(PBL_GEMM_ABLATE & 32)) {            // this set's next use: stage h + 2
-                        R[i].d[PAR] = load_dw(R[i], h + 2, int(L.P));
-                        request_list(R[i], h + 2, NH, lane, R[i].e[PAR]);
-                    }
-                    if (L.G > 1 && h + 1 < NH && uint32_t((h + 1) * GB_HS) % gs == 0) load_levels_t(R[i], L.G, uint32_t((h + 1) * GB_HS) / gs, lane);
+                    request_stage(R[i], h + 2, NH, int(L.P), lane, R[i].d[PAR], R[i].e[PAR]);      // this set's next use: stage h + 2
+                    if (L.G > 1 && h + 1 < NH && uint32_t((h + 1) * GB_HS) % gs == 0) load_levels_inloop(R[i], L.G, uint32_t((h + 1) * GB_HS) / gs, lane);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the stage is in LDS
                 if (!(PBL_GEMM_ABLATE & 128) || h == 0) __builtin_amdgcn_s_barrier();
@@ -572,6 +613,7 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
                 produce(h, std::integral_constant<int, 0>{});
                 if (h + 1 < NH) produce(h + 1, std::integral_constant<int, 1>{});
             }
+            if (!(NU & 1) && !(PBL_GEMM_ABLATE & 128)) __builtin_amdgcn_s_barrier();       // the consumers' closing barrier (their loop has no branch)
             return;
         }
         Rec R[2];
@@ -608,45 +650,46 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
+        if (!(NU & 1)) __builtin_amdgcn_s_barrier();              // the consumers' closing barrier (their loop has no branch)
         return;
     }
 
     // =================================== consumer waves =============================================================
+    // Round 3, second rebuild.  The first one staged x in LDS by LDS-DMA; its component builds showed the kernel LDS bound:
+    // per 128-column half slab 320 KB of fragment reads + 64 KB of x DMA + 32 KB of tile writes at ~128 B/clk are 3 250
+    // cycles against 2 048 cycles of MFMAs.  Now x goes from L2 STRAIGHT INTO the MFMA operand registers (a B fragment is 16
+    // contiguous bytes of one token row per lane) and a consumer owns 128 rows x 64 tokens, so the only LDS traffic left is
+    // the A tile: 128 KB of fragment reads + 32 KB of writes per half slab.
+    //   k mapping: within a 64-column sub-step lane (token, g) owns the 64 contiguous bytes of columns 32 g .. 32 g + 31; k-step j
+    //   multiplies its j-th 16 bytes (columns 32 g + 8 j ..) -- so one token row segment is a whole 128-byte line per lane pair --
+    //   and the A fragment of k-step j is unit 4 g + j of the row's sub-step (the contraction index is ours to order).
+    //   x ring: 2 sub-steps x 4 k-steps x 2 token tiles = 16 fragments (64 registers); piece j of sub-step u + 2 is requested
+    //   right after k-step j of sub-step u has multiplied: two sub-steps = 2 048 MFMA cycles for a load to land.
     const int c = wave;
     const int i32 = lane & 31, g = lane >> 5;
-    const uint32_t xring = GB_X_OFF + uint32_t(c) * GB_XRING_BYTES;
     // x through a buffer descriptor that starts at this workgroup's first token: tokens >= M read zeros
     const char* xbase = reinterpret_cast<const char*>(a.x) + size_t(tok0) * size_t(K) * 2;
     const size_t xrem = size_t(min(M - tok0, GB_TOK)) * size_t(K) * 2;          // <= 256 * 32767 * 2 < 2^24
     __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, int(xrem), 0x00020000);
-    // DMA piece q (1 KiB) of a slot = tokens 8q .. 8q+7 x 128 B; lane l lands on unit l & 7 of token 8q + (l >> 3), which holds
-    // the LOGICAL unit (l & 7) ^ ((token >> 1) & 7)
-    uint32_t xvoff[GB_PQ];
+    uint32_t xv[GB_TT];
 #pragma unroll
-    for (int q = 0; q < GB_PQ; ++q) {
-        const uint32_t tl = uint32_t(8 * q + (lane >> 3));                           // token within the wave's own
-        xvoff[q] = (uint32_t(GB_TPC * c) + tl) * uint32_t(K) * 2u + ((uint32_t(lane & 7) ^ ((tl >> 1) & 7)) << 4);
-    }
-    // K % 64 != 0: the units of the LAST sub-step that lie beyond K would hold the next token row; their source offset is
-    // pushed out of the descriptor's range instead, so they read zeros (and the producers zero the weights there too).
-    // Piece q, lane l holds logical unit (l & 7) ^ (((l >> 4) | 4 (q & 1))): two lane masks, for even and odd q.
-    const uint32_t ktail_units = uint32_t(K & (GB_XC - 1)) >> 3;                 // valid units of the last sub-step (0: no tail)
-    uint32_t xbad[2];
-#pragma unroll
-    for (int o = 0; o < 2; ++o)
-        xbad[o] = (ktail_units && ((uint32_t(lane & 7) ^ (uint32_t(lane >> 4) | uint32_t(4 * o))) >= ktail_units)) ? 0x40000000u : 0u;
-    auto issue_x = [&](int u, int q) {       // piece q of sub-step u into ring slot u % 3
-        const uint32_t dst = xring + uint32_t(u % GB_XSLOTS) * GB_XSLOT_BYTES + uint32_t(q) * 1024u;
-        const uint32_t vo = xvoff[q] + uint32_t(u) * (GB_XC * 2) + (u == NU - 1 ? xbad[q & 1] : 0u);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_b + dst), 16, int(vo), 0, 0, 0);
+    for (int tt = 0; tt < GB_TT; ++tt) xv[tt] = (uint32_t(GB_TPC * c + 32 * tt + i32)) * uint32_t(K) * 2u + uint32_t(g) * 64u;
+    const int gcol = 32 * g;
+    // piece j of sub-step u (clamped to the last one: the request count per k-step stays static).  K % 64 != 0: pieces of the
+    // last sub-step that lie beyond K would hold the next token row; their offset is pushed out of the descriptor's range
+    // instead, so they read zeros (and the producers zero the weights there too).
+    typedef uint32_t xfrag_t __attribute__((ext_vector_type(4)));
+    auto load_x = [&](int u, int j, int tt) -> v8h {
+        const int uu = min(u, NU - 1);
+        const uint32_t bad = (gcol + 8 * j < K - uu * GB_XC) ? 0u : 0x40000000u;
+        const xfrag_t v = __builtin_amdgcn_raw_buffer_load_b128(xrs, int(xv[tt] + bad), uu * (GB_XC * 2) + j * 16, 0);
+        return __builtin_bit_cast(v8h, v);
     };
-    // fragment addresses: A unit (2 ks8 + g) ^ (i32 & 15) of row i32 (+ 32 rt), ks8 = 4 (u & 1) + k: the odd sub-step's units
-    // are the even one's with bit 3 flipped (byte 128); x unit (2 k + g) ^ ((i32 >> 1) & 7) of token i32 (+ 32 tt)
-    uint32_t aq[4], bq[4];
+    // A fragment addresses: unit (4 g + j) ^ (i32 & 15) of row i32 (+ 32 rt); the odd sub-step's units are the even one's with
+    // bit 3 flipped (byte 128)
+    uint32_t aq[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) aq[k] = uint32_t(i32) * 256u + ((uint32_t(2 * k + g) ^ uint32_t(i32 & 15)) << 4);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) bq[k] = xring + uint32_t(i32) * 128u + ((uint32_t(2 * k + g) ^ uint32_t((i32 >> 1) & 7)) << 4);
+    for (int j = 0; j < 4; ++j) aq[j] = uint32_t(i32) * 256u + ((uint32_t(4 * g + j) ^ uint32_t(i32 & 15)) << 4);
 
     v16f acc[4][GB_TT];
 #pragma unroll
@@ -656,78 +699,104 @@ __global__ __launch_bounds__((NCONS + NPROD) * GW) void pbl_gemm_kernel(GemmArgs
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[rt][tt][e] = 0.f;
 
-    // prologue: the first three sub-steps of x on their way, stage 0 of A behind barrier 0
+    v8h xr[2][4][GB_TT];
 #pragma unroll
-    for (int u = 0; u < GB_XSLOTS; ++u)
-        if (u < NU)
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int q = 0; q < GB_PQ; ++q) issue_x(u, q);
-    __builtin_amdgcn_s_barrier();
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int tt = 0; tt < GB_TT; ++tt) xr[s][j][tt] = (PBL_GEMM_ABLATE & 2) ? v8h{} : load_x(s, j, tt);
+    __builtin_amdgcn_s_barrier();               // barrier 0: stage 0 of A is complete
     asm volatile("" ::: "memory");
-    // slot 0 has landed when at most the pieces of sub-steps 1, 2 are outstanding
-    if (NU >= 3) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-    else if (NU == 2) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if PBL_GEMM_PRIO
     __builtin_amdgcn_s_setprio(PBL_GEMM_PRIO);
 #endif
     Frag f0, f1;
-    load_frag(f0, smem_b, aq[0], bq[0], false);      // (stage 0, first half: no offsets)
-    if (PBL_GEMM_ABLATE & 64) load_frag(f1, smem_b, aq[1], bq[1], false);
+    load_frag(f0, smem_b, aq[0], false);
 
-    // One 64-column sub-step = 4 k-steps of 16 columns; fragments of k-step kk+1 are read while k-step kk multiplies.
-    auto mma = [&](const Frag& f) {
+    auto mma = [&](const Frag& f, const v8h (&b)[GB_TT]) {
         if (!(PBL_GEMM_ABLATE & 4)) {
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                 for (int tt = 0; tt < GB_TT; ++tt)
-                    acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[rt], f.b[tt], acc[rt][tt], 0, 0, 0);
+                    acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[rt], b[tt], acc[rt][tt], 0, 0, 0);
         }
     };
-    for (int u = 0; u < NU; ++u) {
-        const uint32_t abuf = uint32_t((u >> 1) & 1) * GB_AS_STAGE, ahalf = uint32_t(u & 1) * 128u;
-        const uint32_t xslot = uint32_t(u % GB_XSLOTS) * GB_XSLOT_BYTES;
-        const bool last = u + 1 >= NU;
-        // pieces of sub-step u+2's x go out GB_PQ / 4 per k-step: its slot, (u+2) % 3 == (u-1) % 3, was last read in sub-step u-1
-        const bool stage_x = !(PBL_GEMM_ABLATE & 2) && u >= 1 && u + 2 < NU;
-        // k-step 0
-        load_frag(f1, smem_b, (aq[1] ^ ahalf) + abuf, bq[1] + xslot);
-        if (stage_x) { issue_x(u + 2, 0 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 0 * 2 + 1); }
-        mma(f0);
-        // k-step 1
-        load_frag(f0, smem_b, (aq[2] ^ ahalf) + abuf, bq[2] + xslot);
-        if (stage_x) { issue_x(u + 2, 1 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 1 * 2 + 1); }
-        mma(f1);
-        // k-step 2
-        load_frag(f1, smem_b, (aq[3] ^ ahalf) + abuf, bq[3] + xslot);
-        if (stage_x) { issue_x(u + 2, 2 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 2 * 2 + 1); }
-        mma(f0);
-        // k-step 3: every read of this sub-step's x slot -- and, in an odd sub-step, of the A stage -- has been issued
-        if (stage_x) { issue_x(u + 2, 3 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 3 * 2 + 1); }
-        if (!last) {
-            // x of sub-step u+1: its pieces were issued during sub-step u-1 (or in the prologue); younger: sub-step u+2's
-            if (u + 2 < NU) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if ((u & 1) && !(PBL_GEMM_ABLATE & 128)) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the stage have returned
-                __builtin_amdgcn_s_barrier();                            // ... the next stage is complete
-                asm volatile("" ::: "memory");
+    // one 64-column sub-step from ring slot S (= u & 1, static); A fragments of k-step j + 1 are read while k-step j multiplies.
+    // Straight-line code (no branch: the barrier of an odd sub-step is unconditional, the producers add a closing one when NU
+    // is even), with sched_group_barriers that keep every fragment read AHEAD of the k-step before its use: left alone hipcc
+    // sinks the ds_reads next to their MFMAs, and with one MFMA wave per SIMD nothing covers that LDS latency.
+    auto substep = [&](int u, auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
+        const uint32_t abuf = uint32_t((u >> 1) & 1) * GB_AS_STAGE, ahalf = uint32_t(S) * 128u;
+        // refill of the ring slot for sub-step u + 2.  GB_REFILL 0: all 8 pieces behind the LAST k-step, the four 16-byte pieces
+        // of a lane's 64 bytes back to back -- one L1 miss per 128-byte line and three hits; piece by piece (1: right behind the
+        // k-step that consumed it) the four touches of a line are a whole sub-step apart, 32 KB of other lines pass through the
+        // L1 in between and every line is fetched from L2 four times.
+        auto refill = [&](int j) {
+            if (PBL_GEMM_ABLATE & 2) return;
+            if (GB_REFILL == 1) {
+#pragma unroll
+                for (int tt = 0; tt < GB_TT; ++tt) xr[S][j][tt] = load_x(u + 2, j, tt);
+            } else if (j == 3) {
+#pragma unroll
+                for (int tt = 0; tt < GB_TT; ++tt)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) xr[S][jj][tt] = load_x(u + 2, jj, tt);
             }
-            const uint32_t nabuf = uint32_t(((u + 1) >> 1) & 1) * GB_AS_STAGE, nahalf = uint32_t((u + 1) & 1) * 128u;
-            load_frag(f0, smem_b, (aq[0] ^ nahalf) + nabuf, bq[0] + uint32_t((u + 1) % GB_XSLOTS) * GB_XSLOT_BYTES);
+        };
+        // schedule of one k-step: the 4 fragment reads of the NEXT k-step, the 8 MFMAs of this one, this k-step's x refill
+        auto order = [&](int j) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // DS read
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * GB_TT, 0);     // MFMA
+            if (GB_REFILL == 1) __builtin_amdgcn_sched_group_barrier(0x020, GB_TT, 0);     // VMEM read
+            else if (j == 3) __builtin_amdgcn_sched_group_barrier(0x020, 4 * GB_TT, 0);
+        };
+        load_frag(f1, smem_b, (aq[1] ^ ahalf) + abuf);
+        mma(f0, xr[S][0]);
+        refill(0);
+        order(0);
+        load_frag(f0, smem_b, (aq[2] ^ ahalf) + abuf);
+        mma(f1, xr[S][1]);
+        refill(1);
+        order(1);
+        load_frag(f1, smem_b, (aq[3] ^ ahalf) + abuf);
+        mma(f0, xr[S][2]);
+        refill(2);
+        order(2);
+        // k-step 3: every read of this sub-step -- and, in an odd sub-step, of the A stage -- has been issued
+        if (S == 1 && !(PBL_GEMM_ABLATE & 128)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the stage have returned
+            __builtin_amdgcn_s_barrier();                            // ... the next stage is complete (after the last one: a closing barrier)
+            asm volatile("" ::: "memory");
         }
-        mma(f1);
+        const uint32_t nabuf = uint32_t(((u + 1) >> 1) & 1) * GB_AS_STAGE, nahalf = uint32_t(S ^ 1) * 128u;
+        load_frag(f0, smem_b, (aq[0] ^ nahalf) + nabuf);           // (behind the last sub-step: an unused read of valid LDS)
+        mma(f1, xr[S][3]);
+        refill(3);
+        order(3);
+    };
+    {
+        int u = 0;
+        for (; u + 1 < NU; u += 2) {            // (no exit between the two: hipcc's vmcnt bookkeeping stays exact -- 14 loads in flight)
+            substep(u, std::integral_constant<int, 0>{});
+            substep(u + 1, std::integral_constant<int, 1>{});
+        }
+        if (u < NU) substep(u, std::integral_constant<int, 0>{});
     }
 #if PBL_GEMM_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
 
-    // ---- epilogue, per consumer wave: accumulators (+ bias) -> Ys[tokens][128 rows] in the wave's own ring -> 16-byte stores
+    // ---- epilogue, per consumer wave: accumulators (+ bias) -> Ys[tokens][128 rows] in LDS -> 16-byte stores
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // every consumer's last fragment read has returned (the producers have left: finished waves do not count)
+    asm volatile("" ::: "memory");
+    const uint32_t xring = uint32_t(c) * GB_EPI_BYTES;        // this wave's share of the (now idle) A stages
     typedef typename std::conditional<Y32, float, _Float16>::type yt;
     constexpr uint32_t YSTR = Y32 ? 528u : 272u;              // bytes per token row: 128 rows + 16 B (every 16-byte read-back stays aligned)
-    constexpr int EPT = (32u * YSTR <= GB_XRING_BYTES) ? 32 : 16;     // tokens per pass: what the ring holds (fp32 result of 8 consumers: 16)
+    constexpr int EPT = (32u * YSTR <= GB_EPI_BYTES) ? 32 : 16;       // tokens per pass: what the share holds (fp32 result: 16)
     const uint32_t row0 = rowblk * GB_ROWS;
     const bool vec = (L.N & (Y32 ? 3 : 7)) == 0 && row0 + GB_ROWS <= L.N;     // whole 16-byte units, all rows exist
 #pragma unroll
@@ -790,46 +859,91 @@ int check_layer(const pbl_layer* layer, const void* x, const void* y, int M) {
 }
 }  // namespace
 
-// Bytes of transient device workspace pbl_gemm_f16_ws wants for M rows of x: the per-(record, half slab) entry ranges and
-// 4-byte entry words of LIST mode.  0: the call decodes inside the GEMM kernel (a single token tile, or a layer too wide for
-// the range registers) and needs no workspace.
-extern "C" size_t pbl_gemm_workspace_bytes(const pbl_layer* layer, int M) {
-    if (!layer || M <= GB_TOK) return 0;
+// Bytes of the salient list of a layer (LIST mode): per-(record, half slab) entry ranges + one 4-byte word per salient entry
+// and exception.  It depends on the layer only, never on x: pbl_gemm_prepare builds it, pbl_gemm_f16_prepared consumes it any
+// number of times.  0: the layer is too wide for the range registers (more than 127 half slabs) -- no list, the GEMM kernel
+// decodes in place.
+extern "C" size_t pbl_gemm_list_bytes(const pbl_layer* layer) {
+    if (!layer) return 0;
     const uint32_t NH = (layer->K + GB_HS - 1) / GB_HS;
     if (NH > GB_LIST_MAX_NH) return 0;
     const size_t ofs_stride = (NH + 1 + 3) & ~size_t(3);
     return align16(size_t(layer->NRB) * ofs_stride * 4) + size_t(layer->NRB) * list_cap(layer) * 4;
 }
 
+// Bytes of transient device workspace pbl_gemm_f16_ws wants for M rows of x: the list above when the call spans more than one
+// 256-token tile (every tile would decode the same entries again), else 0 (decode inside the GEMM kernel).
+extern "C" size_t pbl_gemm_workspace_bytes(const pbl_layer* layer, int M) {
+    if (!layer || M <= GB_TOK) return 0;
+    return pbl_gemm_list_bytes(layer);
+}
+
+namespace {
+bool list_fits(const pbl_layer* layer, const void* workspace, size_t workspace_bytes) {
+    const size_t want = pbl_gemm_list_bytes(layer);
+    return workspace && want && workspace_bytes >= want && !(reinterpret_cast<uintptr_t>(workspace) & 15);
+}
+void list_views(const pbl_layer* layer, void* workspace, GemmArgs& a) {
+    const uint32_t NH = (layer->K + GB_HS - 1) / GB_HS;
+    a.ofs_stride = (NH + 1 + 3) & ~3u;
+    a.cap = list_cap(layer);
+    a.ofs = static_cast<uint32_t*>(workspace);
+    a.lst = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + align16(size_t(layer->NRB) * a.ofs_stride * 4));
+}
+int launch_gemm(GemmArgs& a, bool list, hipStream_t s) {
+    const void* k = list ? (a.y_f32 ? reinterpret_cast<const void*>(pbl_gemm_kernel<true, true>) : reinterpret_cast<const void*>(pbl_gemm_kernel<false, true>))
+                         : (a.y_f32 ? reinterpret_cast<const void*>(pbl_gemm_kernel<true, false>) : reinterpret_cast<const void*>(pbl_gemm_kernel<false, false>));
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(GB_LDS)) != hipSuccess) return PBL_ERR_LAUNCH;
+    void* argv[] = {&a};
+    const dim3 grid(((a.L.NRB + NREC - 1) / NREC) * uint32_t((a.M + GB_TOK - 1) / GB_TOK));
+    return hipLaunchKernel(k, grid, dim3((NCONS + (list ? NPROD_LIST : NPROD)) * GW), argv, GB_LDS, s) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+}  // namespace
+
+// Build the layer's salient list into `workspace` (>= pbl_gemm_list_bytes(layer), 16-byte aligned): one small kernel, no x.
+// The list stays valid as long as the blob is unchanged; a caller may keep it per layer (4 B per salient entry) or build it
+// for the NEXT layer on a second stream while this layer's GEMM runs.
+extern "C" int pbl_gemm_prepare(const pbl_layer* layer, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!layer || !layer->blob) return PBL_ERR_INVALID_ARG;
+    if ((layer->K & 7) || !(layer->flags & PBL_FLAG_SLABS) || !(layer->flags & PBL_FLAG_TAIL_REPEAT)) return PBL_ERR_UNSUPPORTED;
+    if (!pbl_gemm_list_bytes(layer)) return PBL_ERR_UNSUPPORTED;
+    if (!list_fits(layer, workspace, workspace_bytes)) return workspace && workspace_bytes >= pbl_gemm_list_bytes(layer) ? PBL_ERR_MISALIGNED : PBL_ERR_INVALID_ARG;
+    GemmArgs a;
+    list_views(layer, workspace, a);
+    pbl_layer lcopy = *layer;
+    uint32_t* ofs = const_cast<uint32_t*>(a.ofs);
+    uint32_t* lst = const_cast<uint32_t*>(a.lst);
+    void* pargv[] = {&lcopy, &ofs, &lst, &a.ofs_stride, &a.cap};
+    const size_t plds = size_t(2 * (GB_LIST_MAX_NH + 1)) * 4 + 32 * 4 + 16 * sizeof(pbl_rowinfo) + ((size_t(layer->max_nch) + 15) & ~size_t(15));
+    return hipLaunchKernel(reinterpret_cast<const void*>(pbl_gemm_prep_kernel), dim3(layer->NRB), dim3(GB_PREP_THREADS), pargv, plds,
+                           static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+// The GEMM over a list pbl_gemm_prepare built for THIS layer (any M >= 1).  Bit-identical to pbl_gemm_f16_ws / _ex.
+extern "C" int pbl_gemm_f16_prepared(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    const int st = check_layer(layer, x, y, M);
+    if (st != PBL_OK) return st;
+    if (!list_fits(layer, workspace, workspace_bytes)) return PBL_ERR_INVALID_ARG;
+    GemmArgs a;
+    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32;
+    list_views(layer, const_cast<void*>(workspace), a);
+    return launch_gemm(a, true, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int pbl_gemm_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* workspace, size_t workspace_bytes,
                                void* stream) {
     const int st = check_layer(layer, x, y, M);
     if (st != PBL_OK) return st;
+    if (pbl_gemm_workspace_bytes(layer, M) && list_fits(layer, workspace, workspace_bytes)) {
+        const int sp = pbl_gemm_prepare(layer, workspace, workspace_bytes, stream);
+        if (sp != PBL_OK) return sp;
+        return pbl_gemm_f16_prepared(layer, x, y, M, y_f32, workspace, workspace_bytes, stream);
+    }
     GemmArgs a;
     a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32;
     a.ofs = nullptr; a.lst = nullptr; a.ofs_stride = 0; a.cap = 0;
-    const size_t want = pbl_gemm_workspace_bytes(layer, M);
-    const bool list = workspace && want && workspace_bytes >= want && !(reinterpret_cast<uintptr_t>(workspace) & 15);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (list) {
-        const uint32_t NH = (layer->K + GB_HS - 1) / GB_HS;
-        a.ofs_stride = (NH + 1 + 3) & ~3u;
-        a.cap = list_cap(layer);
-        uint32_t* ofs = static_cast<uint32_t*>(workspace);
-        uint32_t* lst = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + align16(size_t(layer->NRB) * a.ofs_stride * 4));
-        a.ofs = ofs; a.lst = lst;
-        pbl_layer lcopy = *layer;
-        void* pargv[] = {&lcopy, &ofs, &lst, &a.ofs_stride, &a.cap};
-        const size_t plds = size_t(2 * (GB_LIST_MAX_NH + 1)) * 4 + 32 * 4 + 16 * sizeof(pbl_rowinfo) + ((size_t(layer->max_nch) + 15) & ~size_t(15));
-        if (hipLaunchKernel(reinterpret_cast<const void*>(pbl_gemm_prep_kernel), dim3(layer->NRB), dim3(GB_PREP_THREADS), pargv, plds, s) != hipSuccess)
-            return PBL_ERR_LAUNCH;
-    }
-    const void* k = list ? (y_f32 ? reinterpret_cast<const void*>(pbl_gemm_kernel<true, true>) : reinterpret_cast<const void*>(pbl_gemm_kernel<false, true>))
-                         : (y_f32 ? reinterpret_cast<const void*>(pbl_gemm_kernel<true, false>) : reinterpret_cast<const void*>(pbl_gemm_kernel<false, false>));
-    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(GB_LDS)) != hipSuccess) return PBL_ERR_LAUNCH;
-    void* argv[] = {&a};
-    const dim3 grid(((layer->NRB + NREC - 1) / NREC) * uint32_t((M + GB_TOK - 1) / GB_TOK));
-    return hipLaunchKernel(k, grid, dim3((NCONS + NPROD) * GW), argv, GB_LDS, s) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+    return launch_gemm(a, false, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int pbl_gemm_f16_ex(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* stream) {

@@ -55,6 +55,9 @@ GEMM_BACKEND = os.environ.get("PBL_GEMM_BACKEND", "library")
 # bf16 activations at <= 32 rows run as ONE fp16 pass (bf16 -> fp16 is exact inside fp16's range); values beyond +-65504 are
 # saturated and NaN / inf do not survive the clamp.  True: check the range first (one device -> host sync per call, ~10 us) and
 # send such inputs through the dense path instead, so that overflow propagates exactly as in the reference's bf16 F.linear.
+# The prefill pipeline, when one is installed (pb_llm_amd/prefill.py: PrefillPipeline(model).install()): the next layer's unpack /
+# salient list is issued on a second stream while this layer's GEMM runs.
+PREFILL = None
 BF16_RANGE_CHECK = os.environ.get("PBL_BF16_RANGE_CHECK", "0") == "1"
 
 
@@ -66,20 +69,41 @@ def fused_gemm_ok(packed: PackedWeight) -> bool:
     return packed.G == 1 or (packed.K % packed.G == 0 and (packed.K // packed.G) % 128 == 0)
 
 
-def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False, workspace: bool = True) -> torch.Tensor:
+def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False, workspace: bool = True,
+                       prepared: torch.Tensor | None = None) -> torch.Tensor:
     """pbl_gemm_f16_ws: x2 [M, K] fp16 contiguous -> [M, N] fp16 (fp32 with out_f32); raises PblError(UNSUPPORTED) for layers
     it does not take.  workspace: hand the kernel the transient scratch it asks for (more than one 256-token tile: the
     salient entries are decoded once per call by a small kernel ahead of the GEMM; 4 B per entry from the caching allocator,
-    stream ordered) -- False decodes inside the GEMM kernel; the results are identical bit for bit."""
+    stream ordered) -- False decodes inside the GEMM kernel; the results are identical bit for bit.
+    prepared: a salient list pbl_gemm_prepare already built for this layer (gemm_list / the prefill pipeline):
+    pbl_gemm_f16_prepared, no per-call preparation."""
     M = x2.shape[0]
     y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
     layer = packed.layer_struct(bias_f32)
     L = _lib.lib()
+    if prepared is not None:
+        _lib.check(L.pbl_gemm_f16_prepared(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), prepared.data_ptr(), prepared.numel(),
+                                           torch.cuda.current_stream(x2.device).cuda_stream), "gemm_f16_prepared")
+        return y
     nb = L.pbl_gemm_workspace_bytes(C.byref(layer), M) if workspace else 0
     ws = torch.empty(nb, dtype=torch.uint8, device=x2.device) if nb else None
     _lib.check(L.pbl_gemm_f16_ws(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), ws.data_ptr() if ws is not None else None, nb,
                                  torch.cuda.current_stream(x2.device).cuda_stream), "gemm_f16")
     return y
+
+
+def gemm_list(packed: PackedWeight) -> torch.Tensor | None:
+    """pbl_gemm_prepare: the layer's salient list for pbl_gemm_f16_prepared (uint8 tensor, 4 B per salient entry + ranges), or None
+    for a layer without one (K > 16256).  Valid until the blob changes; callers that run the same layers batch after batch
+    (perplexity loops) may keep it."""
+    layer = packed.layer_struct(None)
+    L = _lib.lib()
+    nb = int(L.pbl_gemm_list_bytes(C.byref(layer)))
+    if not nb:
+        return None
+    ws = torch.empty(nb, dtype=torch.uint8, device=packed.blob.device)
+    _lib.check(L.pbl_gemm_prepare(C.byref(layer), ws.data_ptr(), nb, torch.cuda.current_stream(packed.blob.device).cuda_stream), "gemm_prepare")
+    return ws
 
 
 def unpack_on_device(packed: PackedWeight, dtype=torch.float16, out: torch.Tensor | None = None) -> torch.Tensor:
@@ -134,6 +158,13 @@ class _PackedLinearFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+def _mfma_ok(packed: PackedWeight) -> bool:
+    """layers the matrix-core kernel (<= 32 rows) takes: K % 8 == 0, slab index, column groups of a power of two >= 128"""
+    gs = packed.K // packed.G
+    return ((packed.G == 1 or (gs >= 128 and gs & (gs - 1) == 0 and gs * packed.G == packed.K))
+            and packed.K % 8 == 0 and bool(packed.flags & _lib.PBL_FLAG_SLABS))
+
+
 def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: torch.Tensor,
                       out_f32: bool = False, dense_dtype=None) -> torch.Tensor:
     """y = F.linear(x, w_sim, bias) through libpbl (pbl_linear_f16).  x [..., K] on
@@ -144,7 +175,9 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
         return _PackedLinearFn.apply(x, (packed, bias_f32), out_f32, dense_dtype)
     if x.dtype == torch.float16 and x.is_cuda and 0 < x.numel() <= MFMA_MAX * packed.K:
         nat = _lib.native_linear()                   # decode regime: one native call (csrc/pbl_torch.cpp)
-        if nat is not None:
+        # (layers the matrix-core kernel does not take -- odd group sizes, K % 8 -- leave the GEMV for the dense path at
+        # GEMM_THRESHOLD rows: _pb_linear_forward decides)
+        if nat is not None and (x.numel() < GEMM_THRESHOLD * packed.K or _mfma_ok(packed)):
             return nat(packed.blob, bias_f32, x, packed.N, packed.K, packed.P, packed.G, packed.NRB, packed.flags,
                        packed.max_nch, packed.max_nexc, out_f32)
     with torch.no_grad():
@@ -166,9 +199,7 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
     L = _lib.lib()
     if M == 0:
         return x.new_zeros(*lead, packed.N)
-    gs = packed.K // packed.G      # column groups: the matrix-core kernel wants a power-of-two group of >= 128 columns
-    mfma_ok = ((packed.G == 1 or (gs >= 128 and gs & (gs - 1) == 0 and gs * packed.G == packed.K))
-               and packed.K % 8 == 0 and bool(packed.flags & _lib.PBL_FLAG_SLABS))
+    mfma_ok = _mfma_ok(packed)
 
     def run(layer_s, xin, yout, rows, f32):
         # the K-split scratch of the matrix-core kernel, when pbl_linear_f16_ws is going to route this call there
@@ -183,12 +214,22 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         # reference executes (F.linear over the dense fake-quant weight).  fp16 weights when
         # the layer is fp16-exact (packed from an fp16 checkpoint), else fp32.
         wdt = torch.float16 if (x.dtype == torch.float16 and dense_dtype in (None, torch.float16)) else torch.float32
+        pipe = PREFILL if wdt == torch.float16 else None           # (pb_llm_amd/prefill.py: next layer prepared on a second stream)
         if GEMM_BACKEND == "fused" and wdt == torch.float16 and fused_gemm_ok(packed):
             xc = x2.contiguous()
             if xc.data_ptr() % 16 == 0:
-                return fused_gemm_forward(packed, bias_f32, xc, out_f32).reshape(*lead, packed.N)
-        W = unpack_on_device(packed, wdt)
+                ws = pipe.acquire(packed, "list") if pipe is not None else None
+                y = fused_gemm_forward(packed, bias_f32, xc, out_f32, prepared=ws)
+                if ws is not None:
+                    pipe.release("list")
+                return y.reshape(*lead, packed.N)
+        W = pipe.acquire(packed, "dense") if pipe is not None else None
+        piped = W is not None
+        if not piped:
+            W = unpack_on_device(packed, wdt)
         y = torch.nn.functional.linear(x2.to(wdt), W, None if bias_f32 is None else bias_f32.to(wdt))
+        if piped:
+            pipe.release("dense")
         y = y.float() if out_f32 else y.to(x.dtype)
         return y.reshape(*lead, packed.N)
     if x.dtype == torch.float16:

@@ -85,7 +85,7 @@ def test_random_column_group_layer(seed):
     layer = Q.PBLinear.from_dense(torch.from_numpy(Wd).half() if fp16 else torch.from_numpy(Wd), None, torch.from_numpy(mask), gs,
                                   r["hscale"], r["hzero"]).to(DEV)
     assert layer.packed.G == K // gs
-    np.testing.assert_array_equal(layer.weight.float().numpy(), Wd)
+    np.testing.assert_array_equal(layer.weight.float().cpu().numpy(), Wd)
     for M in (1, 4, 7, 11, 12, 40):
         x = synth.activations((M, K), seed, M)
         y = layer(T(x))

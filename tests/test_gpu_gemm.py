@@ -105,6 +105,12 @@ def test_gemm_regime_kernel(N, K, M, gs, lf, fp16, exc, metric):
     assert (_lib.lib().pbl_gemm_workspace_bytes(C.byref(pd.layer_struct(None)), M) > 0) == (M > 256 and K <= 16256)
     assert torch.equal(y, Q.fused_gemm_forward(pd, T(b), xt, workspace=False))
     assert torch.equal(y32, Q.fused_gemm_forward(pd, None, xt, out_f32=True, workspace=False))
+    # the two halves of the call: a list built once (it does not depend on x or M), then the GEMM over it -- any M
+    lst = Q.gemm_list(pd)
+    assert (lst is not None) == (K <= 16256)
+    if lst is not None:
+        assert torch.equal(y, Q.fused_gemm_forward(pd, T(b), xt, prepared=lst))
+        assert torch.equal(y32[:33], Q.fused_gemm_forward(pd, None, xt[:33].contiguous(), out_f32=True, prepared=lst))
     # the library backend on the unpacked layer: same operands, different summation order
     Wdev = Q.unpack_on_device(pd, torch.float16)
     np.testing.assert_array_equal(Wdev.float().cpu().numpy()[rows], W16[rows])
@@ -154,3 +160,53 @@ def test_gemm_regime_properties_at_full_size():
     assert torch.equal(sub, y[700:1000])
     z = Q.fused_gemm_forward(pd, b, torch.zeros(64, K, dtype=torch.float16, device=DEV), out_f32=True)
     assert torch.equal(z, b.expand(64, N))
+
+
+def test_prefill_pipeline_is_invisible_in_the_results():
+    """PrefillPipeline (pb_llm_amd/prefill.py): the next layer's unpack / salient list is issued on a second stream while this
+    layer's GEMM runs.  Same results bit for bit as without it, for both backends, pass after pass, in the learned order, in
+    another order (wrong guesses: the layer prepares in line), for a layer outside the pipeline and after a blob was rewritten."""
+    from pb_llm_amd.prefill import PrefillPipeline
+    dims = [(768, 512), (1024, 768), (512, 1024), (640, 512), (512, 640)]          # (N, K), a chain
+    mods = []
+    for i, (N, K) in enumerate(dims):
+        p, _ = rtn_layer(N, K, -1, seed=70 + i, low_frac=0.9, fp16=True, exceptions=i % 2)
+        mods.append(Q.PBLinear(p.to(DEV), T(synth.normal((N,), 4 + i, 3, 0.1))))
+    model = torch.nn.Sequential(*mods)
+    outsider_p, _ = rtn_layer(256, 512, -1, seed=99, low_frac=0.9, fp16=True)
+    outsider = Q.PBLinear(outsider_p.to(DEV), None)
+    x = T(synth.activations((300, 512), 3, 21))
+
+    def chain(order=None):
+        if order is None:
+            return model(x)
+        return [mods[i](T(synth.activations((100 + i, dims[i][1]), i, 21))) for i in order]
+
+    old = Q.GEMM_BACKEND
+    try:
+        for backend in ("library", "fused"):
+            Q.GEMM_BACKEND = backend
+            ref = chain()
+            scr = [4, 1, 3, 0, 2, 2, 0]
+            ref_scr = chain(scr)
+            ref_out = outsider(x)
+            with PrefillPipeline(model) as pipe:
+                for _ in range(3):
+                    assert torch.equal(chain(), ref)
+                assert pipe.stats["hits"] >= 12 and pipe.stats["inline"] <= 2, pipe.stats      # only the very first layer prepares in line
+                for got, want in zip(chain(scr), ref_scr):
+                    assert torch.equal(got, want)
+                assert torch.equal(outsider(x), ref_out) and pipe.stats["bypassed"] >= 1
+                assert torch.equal(chain(), ref)
+                # a blob written in place (load_state_dict copies into the buffer): its version counter moves, the slot that
+                # holds the old preparation is not served, the layer is prepared again
+                before = dict(pipe.stats)
+                mods[1].pbl_blob.add_(0)
+                assert torch.equal(chain(), ref)
+                assert pipe.stats["inline"] + pipe.stats["prefetches"] > before["inline"] + before["prefetches"]
+                assert torch.equal(chain(), ref)
+            assert Q.PREFILL is None
+            torch.cuda.synchronize()
+    finally:
+        Q.GEMM_BACKEND = old
+        Q.PREFILL = None

@@ -67,18 +67,18 @@ def _worker(rank, world, port, results):
         out = {}
         # N-split: no reduction, all-gather of the outputs
         shard, rows = PPw.shard_linear(Wt, bt, mt, "n", rank, world, -1, r["hscale"], r["hzero"])
-        np.testing.assert_array_equal(shard.weight.float().numpy(), r["W_fq"][rows[0]:rows[1]].astype(np.float32))
+        np.testing.assert_array_equal(shard.weight.float().cpu().numpy(), r["W_fq"][rows[0]:rows[1]].astype(np.float32))
         y = PPw.PBLinearNSplit(shard, rows, Wt.shape[0])(xt)
         out["n"] = O.parity_errors(y.numpy(), ref)[0]
         # K-split with PTQ side information
         shard, cols = PPw.shard_linear(Wt, bt, mt, "k", rank, world, -1, r["hscale"], r["hzero"])
-        np.testing.assert_array_equal(shard.weight.float().numpy(), r["W_fq"][:, cols[0]:cols[1]])
+        np.testing.assert_array_equal(shard.weight.float().cpu().numpy(), r["W_fq"][:, cols[0]:cols[1]])
         assert (shard.bias is not None) == (rank == 0)
         y = PPw.PBLinearKSplit(shard, cols)(xt)
         out["k"] = O.parity_errors(y.numpy(), ref)[0]
         # K-split from a flattened checkpoint (levels inferred on full rows, shared by all shards)
         shard, cols = PPw.shard_linear(Wt, None, None, "k", rank, world)
-        np.testing.assert_array_equal(shard.weight.float().numpy(), r["W_fq"][:, cols[0]:cols[1]])
+        np.testing.assert_array_equal(shard.weight.float().cpu().numpy(), r["W_fq"][:, cols[0]:cols[1]])
         y = PPw.PBLinearKSplit(shard, cols)(xt)
         out["k_flat"] = O.parity_errors(y.numpy(), O.dense_linear(x, r["W_fq"]))[0]
         # pre-sharded input (output of an N-split layer feeding a K-split layer, Megatron style)

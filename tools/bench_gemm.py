@@ -43,6 +43,9 @@ for shp, lf in SHAPES:
     res = {}
     if ONLY in ("", "fused"):
         res["fused_us"] = round(timeit(lambda: Q.fused_gemm_forward(layer.packed, None, x)), 1)
+        lst = Q.gemm_list(layer.packed)              # the list kept per layer (pbl_gemm_prepare once, pbl_gemm_f16_prepared per call)
+        if lst is not None:
+            res["fused_prepared_us"] = round(timeit(lambda: Q.fused_gemm_forward(layer.packed, None, x, prepared=lst)), 1)
     if ONLY in ("", "library"):
         Q.GEMM_BACKEND = "library"
         res["unpack_plus_library_us"] = round(timeit(lambda: layer(x)), 1)

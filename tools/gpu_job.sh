@@ -2,12 +2,19 @@
 # One gpurun call of round 3 (rewritten per call; results under gpurun_out/<tag>/).  Usage: tools/gpu_job.sh <tag>
 set -u
 export TMPDIR=/tmp
-O=gpurun_out/${1:-r3l}; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -q -x 2>&1 | tail -5 > $O/test_gemv.txt
-for v in default ring2 ring3w7 ring3w8 default ring2; do
-  echo "== $v" >> $O/bench_gemv.txt
+O=gpurun_out/${1:-r3s}; mkdir -p $O
+python __graft_entry__.py > $O/build.txt 2>&1
+for v in default v3; do
   if [ $v = default ]; then L=""; else L="build/libpbl_$v.so"; fi
-  PBL_LIB=$L timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(round(d['value']), round(d['roofline']['frac'],4), round(d['roofline']['us_per_launch'],1))" >> $O/bench_gemv.txt
+  i=0
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_VMEM_RD" \
+             "SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_DATA_FIFO_FULL SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
+             "TA_BUSY_avr TA_TA_BUSY_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_BUFFER_TOTAL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
+             "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_CACHE_MISS TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN" ; do
+    i=$((i+1))
+    PBL_LIB=$L PBL_BENCH_ONLY=fused PBL_BENCH_SHAPES=4096x4096:0.95 PBL_BENCH_PREHEAT_S=0.2 timeout 300 rocprofv3 --pmc $set --kernel-trace -d $O/prof_$v/gemm_pmc$i -o pmc -- python tools/bench_gemm.py > $O/pmc_${v}_$i.log 2>&1
+  done
+  python tools/summarize_prof.py $O/prof_$v > $O/pmc_summary_$v.txt 2>&1
+  rm -rf $O/prof_$v
 done
-timeout 300 python tools/bench_p2p.py > $O/bench_p2p.json 2> $O/bench_p2p.err
-cat $O/test_gemv.txt $O/bench_gemv.txt $O/bench_p2p.json
+cat $O/pmc_summary_*.txt | cut -c1-1200
