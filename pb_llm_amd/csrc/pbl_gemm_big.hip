@@ -44,25 +44,26 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 #define GW 64
 #ifndef NCONS
-#define NCONS 4                   // consumer (MFMA) waves, one per SIMD: 128 rows x 64 tokens each = 8 accumulator tiles of 32 x 32
+#define NCONS 8                   // consumer (MFMA) waves: 256 / NCONS tokens each.  8 = two per SIMD: one's waits are the other's MFMAs
 #endif
-#define GB_TPC (256 / NCONS)      // tokens per consumer wave
-#define GB_TT (GB_TPC / 32)       // 32-token accumulator tiles per consumer
+#define GB_TPC (256 / NCONS)      // tokens per consumer wave (64 / 32)
+#define GB_TT (GB_TPC / 32)       // 32-token accumulator tiles per consumer (2 / 1)
+#define GB_PQ (GB_TPC / 8)        // 1 KiB DMA pieces per x slot (8 / 4)
 #define NPROD 4                   // producer (expand) waves of the in-kernel-decode build: 2 records each
 #ifndef NPROD_LIST
-#define NPROD_LIST 4              // ... of LIST mode (8 = one record each was measured equal: the producers are not the critical path)
+#define NPROD_LIST 4              // ... of LIST mode: 2 records each (8 x 1 record measured equal, r3p: the producers are not the critical path)
 #endif
 #define NREC 8                    // records per workgroup tile
 #define GB_ROWS (NREC * 16)
 #define GB_TOK 256
 #define GB_HS 128                 // columns per A stage (half a slab)
-#define GB_XC 64                  // columns per sub-step: 4 k-steps of 16; one lane's x of a sub-step is 64 contiguous bytes
+#define GB_XC 64                  // columns per x slot (sub-step)
+#define GB_XSLOTS 3
 #define GB_AS_STAGE (GB_ROWS * GB_HS * 2)          // 32768 B
-#define GB_LDS (2 * GB_AS_STAGE)                   // 65536 B: the two A stages; x never enters LDS
-#define GB_EPI_BYTES (GB_LDS / NCONS)              // what a consumer's epilogue may use of it once the loop is over
-#ifndef GB_REFILL
-#define GB_REFILL 0               // x ring refill: 0 a whole sub-step at once (line-friendly), 1 piece by piece (longest lookahead)
-#endif
+#define GB_XSLOT_BYTES (GB_TPC * GB_XC * 2)         // 8192 / 4096 B: the consumer's tokens x 64 columns
+#define GB_XRING_BYTES (GB_XSLOTS * GB_XSLOT_BYTES)
+#define GB_X_OFF (2 * GB_AS_STAGE)
+#define GB_LDS (GB_X_OFF + NCONS * GB_XRING_BYTES)  // 163840 B
 // performance-analysis hook (tools/build_variant.sh): bit 0 no expansion in the loop, 1 no x staging in the loop, 2 no MFMA,
 // 3 no sign-plane expansion, 4 no salient overlay, 5 producers request nothing either (consumer loop alone), 6 no fragment
 // reads in the loop, 7 no barriers in the loop.  0 in every
@@ -537,12 +538,14 @@ __device__ __forceinline__ void init_list_b(RecL& R, const GemmArgs& a, const ui
 }
 
 // ---- consumer helpers -------------------------------------------------------------------------------------------------
-struct Frag { v8h a[4]; };
+struct Frag { v8h a[4], b[GB_TT]; };
 
-__device__ __forceinline__ void load_frag(Frag& f, const char* smem, uint32_t aaddr, bool inloop = true) {
-    if ((PBL_GEMM_ABLATE & 64) && inloop) { asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3])); return; }
+__device__ __forceinline__ void load_frag(Frag& f, const char* smem, uint32_t aaddr, uint32_t baddr, bool inloop = true) {
+    if ((PBL_GEMM_ABLATE & 64) && inloop) { asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0])); return; }
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) f.a[rt] = *reinterpret_cast<const v8h*>(smem + aaddr + rt * 8192);
+#pragma unroll
+    for (int tt = 0; tt < GB_TT; ++tt) f.b[tt] = *reinterpret_cast<const v8h*>(smem + baddr + tt * 4096);
 }
 
 template <bool Y32, bool LIST>
@@ -613,7 +616,6 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
                 produce(h, std::integral_constant<int, 0>{});
                 if (h + 1 < NH) produce(h + 1, std::integral_constant<int, 1>{});
             }
-            if (!(NU & 1) && !(PBL_GEMM_ABLATE & 128)) __builtin_amdgcn_s_barrier();       // the consumers' closing barrier (their loop has no branch)
             return;
         }
         Rec R[2];
@@ -650,46 +652,45 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        if (!(NU & 1)) __builtin_amdgcn_s_barrier();              // the consumers' closing barrier (their loop has no branch)
         return;
     }
 
     // =================================== consumer waves =============================================================
-    // Round 3, second rebuild.  The first one staged x in LDS by LDS-DMA; its component builds showed the kernel LDS bound:
-    // per 128-column half slab 320 KB of fragment reads + 64 KB of x DMA + 32 KB of tile writes at ~128 B/clk are 3 250
-    // cycles against 2 048 cycles of MFMAs.  Now x goes from L2 STRAIGHT INTO the MFMA operand registers (a B fragment is 16
-    // contiguous bytes of one token row per lane) and a consumer owns 128 rows x 64 tokens, so the only LDS traffic left is
-    // the A tile: 128 KB of fragment reads + 32 KB of writes per half slab.
-    //   k mapping: within a 64-column sub-step lane (token, g) owns the 64 contiguous bytes of columns 32 g .. 32 g + 31; k-step j
-    //   multiplies its j-th 16 bytes (columns 32 g + 8 j ..) -- so one token row segment is a whole 128-byte line per lane pair --
-    //   and the A fragment of k-step j is unit 4 g + j of the row's sub-step (the contraction index is ours to order).
-    //   x ring: 2 sub-steps x 4 k-steps x 2 token tiles = 16 fragments (64 registers); piece j of sub-step u + 2 is requested
-    //   right after k-step j of sub-step u has multiplied: two sub-steps = 2 048 MFMA cycles for a load to land.
     const int c = wave;
     const int i32 = lane & 31, g = lane >> 5;
+    const uint32_t xring = GB_X_OFF + uint32_t(c) * GB_XRING_BYTES;
     // x through a buffer descriptor that starts at this workgroup's first token: tokens >= M read zeros
     const char* xbase = reinterpret_cast<const char*>(a.x) + size_t(tok0) * size_t(K) * 2;
     const size_t xrem = size_t(min(M - tok0, GB_TOK)) * size_t(K) * 2;          // <= 256 * 32767 * 2 < 2^24
     __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, int(xrem), 0x00020000);
-    uint32_t xv[GB_TT];
+    // DMA piece q (1 KiB) of a slot = tokens 8q .. 8q+7 x 128 B; lane l lands on unit l & 7 of token 8q + (l >> 3), which holds
+    // the LOGICAL unit (l & 7) ^ ((token >> 1) & 7)
+    uint32_t xvoff[GB_PQ];
 #pragma unroll
-    for (int tt = 0; tt < GB_TT; ++tt) xv[tt] = (uint32_t(GB_TPC * c + 32 * tt + i32)) * uint32_t(K) * 2u + uint32_t(g) * 64u;
-    const int gcol = 32 * g;
-    // piece j of sub-step u (clamped to the last one: the request count per k-step stays static).  K % 64 != 0: pieces of the
-    // last sub-step that lie beyond K would hold the next token row; their offset is pushed out of the descriptor's range
-    // instead, so they read zeros (and the producers zero the weights there too).
-    typedef uint32_t xfrag_t __attribute__((ext_vector_type(4)));
-    auto load_x = [&](int u, int j, int tt) -> v8h {
-        const int uu = min(u, NU - 1);
-        const uint32_t bad = (gcol + 8 * j < K - uu * GB_XC) ? 0u : 0x40000000u;
-        const xfrag_t v = __builtin_amdgcn_raw_buffer_load_b128(xrs, int(xv[tt] + bad), uu * (GB_XC * 2) + j * 16, 0);
-        return __builtin_bit_cast(v8h, v);
+    for (int q = 0; q < GB_PQ; ++q) {
+        const uint32_t tl = uint32_t(8 * q + (lane >> 3));                           // token within the wave's own
+        xvoff[q] = (uint32_t(GB_TPC * c) + tl) * uint32_t(K) * 2u + ((uint32_t(lane & 7) ^ ((tl >> 1) & 7)) << 4);
+    }
+    // K % 64 != 0: the units of the LAST sub-step that lie beyond K would hold the next token row; their source offset is
+    // pushed out of the descriptor's range instead, so they read zeros (and the producers zero the weights there too).
+    // Piece q, lane l holds logical unit (l & 7) ^ (((l >> 4) | 4 (q & 1))): two lane masks, for even and odd q.
+    const uint32_t ktail_units = uint32_t(K & (GB_XC - 1)) >> 3;                 // valid units of the last sub-step (0: no tail)
+    uint32_t xbad[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+        xbad[o] = (ktail_units && ((uint32_t(lane & 7) ^ (uint32_t(lane >> 4) | uint32_t(4 * o))) >= ktail_units)) ? 0x40000000u : 0u;
+    auto issue_x = [&](int u, int q) {       // piece q of sub-step u into ring slot u % 3
+        const uint32_t dst = xring + uint32_t(u % GB_XSLOTS) * GB_XSLOT_BYTES + uint32_t(q) * 1024u;
+        const uint32_t vo = xvoff[q] + uint32_t(u) * (GB_XC * 2) + (u == NU - 1 ? xbad[q & 1] : 0u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_b + dst), 16, int(vo), 0, 0, 0);
     };
-    // A fragment addresses: unit (4 g + j) ^ (i32 & 15) of row i32 (+ 32 rt); the odd sub-step's units are the even one's with
-    // bit 3 flipped (byte 128)
-    uint32_t aq[4];
+    // fragment addresses: A unit (2 ks8 + g) ^ (i32 & 15) of row i32 (+ 32 rt), ks8 = 4 (u & 1) + k: the odd sub-step's units
+    // are the even one's with bit 3 flipped (byte 128); x unit (2 k + g) ^ ((i32 >> 1) & 7) of token i32 (+ 32 tt)
+    uint32_t aq[4], bq[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) aq[j] = uint32_t(i32) * 256u + ((uint32_t(4 * g + j) ^ uint32_t(i32 & 15)) << 4);
+    for (int k = 0; k < 4; ++k) aq[k] = uint32_t(i32) * 256u + ((uint32_t(2 * k + g) ^ uint32_t(i32 & 15)) << 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bq[k] = xring + uint32_t(i32) * 128u + ((uint32_t(2 * k + g) ^ uint32_t((i32 >> 1) & 7)) << 4);
 
     v16f acc[4][GB_TT];
 #pragma unroll
@@ -699,104 +700,78 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[rt][tt][e] = 0.f;
 
-    v8h xr[2][4][GB_TT];
+    // prologue: the first three sub-steps of x on their way, stage 0 of A behind barrier 0
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int u = 0; u < GB_XSLOTS; ++u)
+        if (u < NU)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int tt = 0; tt < GB_TT; ++tt) xr[s][j][tt] = (PBL_GEMM_ABLATE & 2) ? v8h{} : load_x(s, j, tt);
-    __builtin_amdgcn_s_barrier();               // barrier 0: stage 0 of A is complete
+            for (int q = 0; q < GB_PQ; ++q) issue_x(u, q);
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    // slot 0 has landed when at most the pieces of sub-steps 1, 2 are outstanding
+    if (NU >= 3) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else if (NU == 2) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if PBL_GEMM_PRIO
     __builtin_amdgcn_s_setprio(PBL_GEMM_PRIO);
 #endif
     Frag f0, f1;
-    load_frag(f0, smem_b, aq[0], false);
+    load_frag(f0, smem_b, aq[0], bq[0], false);      // (stage 0, first half: no offsets)
+    if (PBL_GEMM_ABLATE & 64) load_frag(f1, smem_b, aq[1], bq[1], false);
 
-    auto mma = [&](const Frag& f, const v8h (&b)[GB_TT]) {
+    // One 64-column sub-step = 4 k-steps of 16 columns; fragments of k-step kk+1 are read while k-step kk multiplies.
+    auto mma = [&](const Frag& f) {
         if (!(PBL_GEMM_ABLATE & 4)) {
 #pragma unroll
             for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                 for (int tt = 0; tt < GB_TT; ++tt)
-                    acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[rt], b[tt], acc[rt][tt], 0, 0, 0);
+                    acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[rt], f.b[tt], acc[rt][tt], 0, 0, 0);
         }
     };
-    // one 64-column sub-step from ring slot S (= u & 1, static); A fragments of k-step j + 1 are read while k-step j multiplies.
-    // Straight-line code (no branch: the barrier of an odd sub-step is unconditional, the producers add a closing one when NU
-    // is even), with sched_group_barriers that keep every fragment read AHEAD of the k-step before its use: left alone hipcc
-    // sinks the ds_reads next to their MFMAs, and with one MFMA wave per SIMD nothing covers that LDS latency.
-    auto substep = [&](int u, auto slot_tag) {
-        constexpr int S = decltype(slot_tag)::value;
-        const uint32_t abuf = uint32_t((u >> 1) & 1) * GB_AS_STAGE, ahalf = uint32_t(S) * 128u;
-        // refill of the ring slot for sub-step u + 2.  GB_REFILL 0: all 8 pieces behind the LAST k-step, the four 16-byte pieces
-        // of a lane's 64 bytes back to back -- one L1 miss per 128-byte line and three hits; piece by piece (1: right behind the
-        // k-step that consumed it) the four touches of a line are a whole sub-step apart, 32 KB of other lines pass through the
-        // L1 in between and every line is fetched from L2 four times.
-        auto refill = [&](int j) {
-            if (PBL_GEMM_ABLATE & 2) return;
-            if (GB_REFILL == 1) {
-#pragma unroll
-                for (int tt = 0; tt < GB_TT; ++tt) xr[S][j][tt] = load_x(u + 2, j, tt);
-            } else if (j == 3) {
-#pragma unroll
-                for (int tt = 0; tt < GB_TT; ++tt)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) xr[S][jj][tt] = load_x(u + 2, jj, tt);
+    for (int u = 0; u < NU; ++u) {
+        const uint32_t abuf = uint32_t((u >> 1) & 1) * GB_AS_STAGE, ahalf = uint32_t(u & 1) * 128u;
+        const uint32_t xslot = uint32_t(u % GB_XSLOTS) * GB_XSLOT_BYTES;
+        const bool last = u + 1 >= NU;
+        // pieces of sub-step u+2's x go out GB_PQ / 4 per k-step: its slot, (u+2) % 3 == (u-1) % 3, was last read in sub-step u-1
+        const bool stage_x = !(PBL_GEMM_ABLATE & 2) && u >= 1 && u + 2 < NU;
+        // k-step 0
+        load_frag(f1, smem_b, (aq[1] ^ ahalf) + abuf, bq[1] + xslot);
+        if (stage_x) { issue_x(u + 2, 0 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 0 * 2 + 1); }
+        mma(f0);
+        // k-step 1
+        load_frag(f0, smem_b, (aq[2] ^ ahalf) + abuf, bq[2] + xslot);
+        if (stage_x) { issue_x(u + 2, 1 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 1 * 2 + 1); }
+        mma(f1);
+        // k-step 2
+        load_frag(f1, smem_b, (aq[3] ^ ahalf) + abuf, bq[3] + xslot);
+        if (stage_x) { issue_x(u + 2, 2 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 2 * 2 + 1); }
+        mma(f0);
+        // k-step 3: every read of this sub-step's x slot -- and, in an odd sub-step, of the A stage -- has been issued
+        if (stage_x) { issue_x(u + 2, 3 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 3 * 2 + 1); }
+        if (!last) {
+            // x of sub-step u+1: its pieces were issued during sub-step u-1 (or in the prologue); younger: sub-step u+2's
+            if (u + 2 < NU) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((u & 1) && !(PBL_GEMM_ABLATE & 128)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the stage have returned
+                __builtin_amdgcn_s_barrier();                            // ... the next stage is complete
+                asm volatile("" ::: "memory");
             }
-        };
-        // schedule of one k-step: the 4 fragment reads of the NEXT k-step, the 8 MFMAs of this one, this k-step's x refill
-        auto order = [&](int j) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * GB_TT, 0);     // MFMA
-            if (GB_REFILL == 1) __builtin_amdgcn_sched_group_barrier(0x020, GB_TT, 0);     // VMEM read
-            else if (j == 3) __builtin_amdgcn_sched_group_barrier(0x020, 4 * GB_TT, 0);
-        };
-        load_frag(f1, smem_b, (aq[1] ^ ahalf) + abuf);
-        mma(f0, xr[S][0]);
-        refill(0);
-        order(0);
-        load_frag(f0, smem_b, (aq[2] ^ ahalf) + abuf);
-        mma(f1, xr[S][1]);
-        refill(1);
-        order(1);
-        load_frag(f1, smem_b, (aq[3] ^ ahalf) + abuf);
-        mma(f0, xr[S][2]);
-        refill(2);
-        order(2);
-        // k-step 3: every read of this sub-step -- and, in an odd sub-step, of the A stage -- has been issued
-        if (S == 1 && !(PBL_GEMM_ABLATE & 128)) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the stage have returned
-            __builtin_amdgcn_s_barrier();                            // ... the next stage is complete (after the last one: a closing barrier)
-            asm volatile("" ::: "memory");
+            const uint32_t nabuf = uint32_t(((u + 1) >> 1) & 1) * GB_AS_STAGE, nahalf = uint32_t((u + 1) & 1) * 128u;
+            load_frag(f0, smem_b, (aq[0] ^ nahalf) + nabuf, bq[0] + uint32_t((u + 1) % GB_XSLOTS) * GB_XSLOT_BYTES);
         }
-        const uint32_t nabuf = uint32_t(((u + 1) >> 1) & 1) * GB_AS_STAGE, nahalf = uint32_t(S ^ 1) * 128u;
-        load_frag(f0, smem_b, (aq[0] ^ nahalf) + nabuf);           // (behind the last sub-step: an unused read of valid LDS)
-        mma(f1, xr[S][3]);
-        refill(3);
-        order(3);
-    };
-    {
-        int u = 0;
-        for (; u + 1 < NU; u += 2) {            // (no exit between the two: hipcc's vmcnt bookkeeping stays exact -- 14 loads in flight)
-            substep(u, std::integral_constant<int, 0>{});
-            substep(u + 1, std::integral_constant<int, 1>{});
-        }
-        if (u < NU) substep(u, std::integral_constant<int, 0>{});
+        mma(f1);
     }
 #if PBL_GEMM_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
 
-    // ---- epilogue, per consumer wave: accumulators (+ bias) -> Ys[tokens][128 rows] in LDS -> 16-byte stores
+    // ---- epilogue, per consumer wave: accumulators (+ bias) -> Ys[tokens][128 rows] in the wave's own ring -> 16-byte stores
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();       // every consumer's last fragment read has returned (the producers have left: finished waves do not count)
-    asm volatile("" ::: "memory");
-    const uint32_t xring = uint32_t(c) * GB_EPI_BYTES;        // this wave's share of the (now idle) A stages
     typedef typename std::conditional<Y32, float, _Float16>::type yt;
     constexpr uint32_t YSTR = Y32 ? 528u : 272u;              // bytes per token row: 128 rows + 16 B (every 16-byte read-back stays aligned)
-    constexpr int EPT = (32u * YSTR <= GB_EPI_BYTES) ? 32 : 16;       // tokens per pass: what the share holds (fp32 result: 16)
+    constexpr int EPT = (32u * YSTR <= GB_XRING_BYTES) ? 32 : 16;     // tokens per pass: what the ring holds (fp32 result of 8 consumers: 16)
     const uint32_t row0 = rowblk * GB_ROWS;
     const bool vec = (L.N & (Y32 ? 3 : 7)) == 0 && row0 + GB_ROWS <= L.N;     // whole 16-byte units, all rows exist
 #pragma unroll

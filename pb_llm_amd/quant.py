@@ -55,9 +55,10 @@ GEMM_BACKEND = os.environ.get("PBL_GEMM_BACKEND", "library")
 # bf16 activations at <= 32 rows run as ONE fp16 pass (bf16 -> fp16 is exact inside fp16's range); values beyond +-65504 are
 # saturated and NaN / inf do not survive the clamp.  True: check the range first (one device -> host sync per call, ~10 us) and
 # send such inputs through the dense path instead, so that overflow propagates exactly as in the reference's bf16 F.linear.
-# The prefill pipeline, when one is installed (pb_llm_amd/prefill.py: PrefillPipeline(model).install()): the next layer's unpack /
-# salient list is issued on a second stream while this layer's GEMM runs.
-PREFILL = None
+# fused backend: keep each layer's salient list (pbl_gemm_prepare, 4 B per salient entry -- a fifth of the dense weight at 5 %
+# salients, 2.6 GB for a 7B model at 10 %) next to its blob instead of rebuilding it on every call: the perplexity loops call the
+# same linears batch after batch (gptq_pb/eval_ppl_utils.py:55-64).  4096^2 x 2048: 81 us instead of 90 (profiles/r03_gemm.md).
+GEMM_KEEP_LIST = os.environ.get("PBL_GEMM_KEEP_LIST", "0") == "1"
 BF16_RANGE_CHECK = os.environ.get("PBL_BF16_RANGE_CHECK", "0") == "1"
 
 
@@ -75,8 +76,8 @@ def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32
     it does not take.  workspace: hand the kernel the transient scratch it asks for (more than one 256-token tile: the
     salient entries are decoded once per call by a small kernel ahead of the GEMM; 4 B per entry from the caching allocator,
     stream ordered) -- False decodes inside the GEMM kernel; the results are identical bit for bit.
-    prepared: a salient list pbl_gemm_prepare already built for this layer (gemm_list / the prefill pipeline):
-    pbl_gemm_f16_prepared, no per-call preparation."""
+    prepared: a salient list pbl_gemm_prepare already built for this layer (gemm_list): pbl_gemm_f16_prepared, no per-call
+    preparation."""
     M = x2.shape[0]
     y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
     layer = packed.layer_struct(bias_f32)
@@ -106,11 +107,21 @@ def gemm_list(packed: PackedWeight) -> torch.Tensor | None:
     return ws
 
 
+def _kept_list(packed: PackedWeight) -> torch.Tensor | None:
+    """the layer's salient list, built on first use and kept with the PackedWeight until its blob changes (GEMM_KEEP_LIST)"""
+    key = (packed.blob.data_ptr(), packed.blob._version)
+    kept = getattr(packed, "_gemm_list", None)
+    if kept is None or kept[0] != key:
+        kept = (key, gemm_list(packed))
+        packed._gemm_list = kept
+    return kept[1]
+
+
 def unpack_on_device(packed: PackedWeight, dtype=torch.float16, out: torch.Tensor | None = None) -> torch.Tensor:
     """Dense [N, K] copy of the packed layer (pbl_unpack_dev).  The buffer comes from torch's caching allocator
     per call (stream-ordered, so two streams never share it and a captured graph keeps its own block); it is
     released as soon as the caller drops it, so a model never holds more than the layers in flight unpacked.
-    `out`: write into a caller-owned [N, K] buffer instead (the prefill pipeline's double buffer)."""
+    `out`: write into a caller-owned [N, K] buffer instead."""
     W = out if out is not None else torch.empty(packed.N, packed.K, dtype=dtype, device=packed.blob.device)
     layer = packed.layer_struct(None)
     stream = torch.cuda.current_stream(packed.blob.device).cuda_stream
@@ -214,22 +225,12 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         # reference executes (F.linear over the dense fake-quant weight).  fp16 weights when
         # the layer is fp16-exact (packed from an fp16 checkpoint), else fp32.
         wdt = torch.float16 if (x.dtype == torch.float16 and dense_dtype in (None, torch.float16)) else torch.float32
-        pipe = PREFILL if wdt == torch.float16 else None           # (pb_llm_amd/prefill.py: next layer prepared on a second stream)
         if GEMM_BACKEND == "fused" and wdt == torch.float16 and fused_gemm_ok(packed):
             xc = x2.contiguous()
             if xc.data_ptr() % 16 == 0:
-                ws = pipe.acquire(packed, "list") if pipe is not None else None
-                y = fused_gemm_forward(packed, bias_f32, xc, out_f32, prepared=ws)
-                if ws is not None:
-                    pipe.release("list")
-                return y.reshape(*lead, packed.N)
-        W = pipe.acquire(packed, "dense") if pipe is not None else None
-        piped = W is not None
-        if not piped:
-            W = unpack_on_device(packed, wdt)
+                return fused_gemm_forward(packed, bias_f32, xc, out_f32, prepared=_kept_list(packed) if GEMM_KEEP_LIST else None).reshape(*lead, packed.N)
+        W = unpack_on_device(packed, wdt)
         y = torch.nn.functional.linear(x2.to(wdt), W, None if bias_f32 is None else bias_f32.to(wdt))
-        if piped:
-            pipe.release("dense")
         y = y.float() if out_f32 else y.to(x.dtype)
         return y.reshape(*lead, packed.N)
     if x.dtype == torch.float16:

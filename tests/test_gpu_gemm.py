@@ -162,51 +162,21 @@ def test_gemm_regime_properties_at_full_size():
     assert torch.equal(z, b.expand(64, N))
 
 
-def test_prefill_pipeline_is_invisible_in_the_results():
-    """PrefillPipeline (pb_llm_amd/prefill.py): the next layer's unpack / salient list is issued on a second stream while this
-    layer's GEMM runs.  Same results bit for bit as without it, for both backends, pass after pass, in the learned order, in
-    another order (wrong guesses: the layer prepares in line), for a layer outside the pipeline and after a blob was rewritten."""
-    from pb_llm_amd.prefill import PrefillPipeline
-    dims = [(768, 512), (1024, 768), (512, 1024), (640, 512), (512, 640)]          # (N, K), a chain
-    mods = []
-    for i, (N, K) in enumerate(dims):
-        p, _ = rtn_layer(N, K, -1, seed=70 + i, low_frac=0.9, fp16=True, exceptions=i % 2)
-        mods.append(Q.PBLinear(p.to(DEV), T(synth.normal((N,), 4 + i, 3, 0.1))))
-    model = torch.nn.Sequential(*mods)
-    outsider_p, _ = rtn_layer(256, 512, -1, seed=99, low_frac=0.9, fp16=True)
-    outsider = Q.PBLinear(outsider_p.to(DEV), None)
-    x = T(synth.activations((300, 512), 3, 21))
-
-    def chain(order=None):
-        if order is None:
-            return model(x)
-        return [mods[i](T(synth.activations((100 + i, dims[i][1]), i, 21))) for i in order]
-
-    old = Q.GEMM_BACKEND
+def test_kept_salient_list_follows_the_blob():
+    """quant.GEMM_KEEP_LIST: the fused backend keeps a layer's salient list between calls (perplexity loops); same results bit for
+    bit, built once, rebuilt when the blob is written in place (its version counter moves)."""
+    p, Wd = rtn_layer(512, 1024, -1, seed=7, low_frac=0.9, fp16=True, exceptions=1)
+    layer = Q.PBLinear(p.to(DEV), T(synth.normal((512,), 3, 3, 0.1)))
+    x = T(synth.activations((300, 1024), 8, 21))
+    old = (Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST)
     try:
-        for backend in ("library", "fused"):
-            Q.GEMM_BACKEND = backend
-            ref = chain()
-            scr = [4, 1, 3, 0, 2, 2, 0]
-            ref_scr = chain(scr)
-            ref_out = outsider(x)
-            with PrefillPipeline(model) as pipe:
-                for _ in range(3):
-                    assert torch.equal(chain(), ref)
-                assert pipe.stats["hits"] >= 12 and pipe.stats["inline"] <= 2, pipe.stats      # only the very first layer prepares in line
-                for got, want in zip(chain(scr), ref_scr):
-                    assert torch.equal(got, want)
-                assert torch.equal(outsider(x), ref_out) and pipe.stats["bypassed"] >= 1
-                assert torch.equal(chain(), ref)
-                # a blob written in place (load_state_dict copies into the buffer): its version counter moves, the slot that
-                # holds the old preparation is not served, the layer is prepared again
-                before = dict(pipe.stats)
-                mods[1].pbl_blob.add_(0)
-                assert torch.equal(chain(), ref)
-                assert pipe.stats["inline"] + pipe.stats["prefetches"] > before["inline"] + before["prefetches"]
-                assert torch.equal(chain(), ref)
-            assert Q.PREFILL is None
-            torch.cuda.synchronize()
+        Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST = "fused", False
+        ref = layer(x)
+        Q.GEMM_KEEP_LIST = True
+        assert torch.equal(layer(x), ref)
+        kept = layer.packed._gemm_list
+        assert torch.equal(layer(x[:40]), ref[:40]) and layer.packed._gemm_list is kept          # one list, any M
+        layer.pbl_blob.add_(0)                                                                     # written in place
+        assert torch.equal(layer(x), ref) and layer.packed._gemm_list[0] != kept[0]
     finally:
-        Q.GEMM_BACKEND = old
-        Q.PREFILL = None
+        Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST = old
