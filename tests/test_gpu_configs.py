@@ -43,16 +43,18 @@ def assert_parity(y, ref, tol=1e-3):
 _cache = {}
 
 
-def cfg3_layer(name):
-    """packed llama-7b linear `name` at low_frac 0.95 with hessian salients (fp16 checkpoint, as gptq_pb writes it)"""
-    if name not in _cache:
+def cfg3_layer(name, lf=0.95):
+    """packed llama-7b linear `name` at low_frac `lf` (0.95: configs[2]; 0.9: configs[4]) with hessian salients (fp16
+    checkpoint, as gptq_pb writes it)"""
+    key = name if lf == 0.95 else f"{name}@{lf}"
+    if key not in _cache:
         N, K = LLAMA7B[name]
-        W, mask, r = hessian_layer(N, K, 0.95, seed=300 + len(_cache) // 2)
+        W, mask, r = hessian_layer(N, K, lf, seed=300 + len(_cache) // 2)
         W16 = torch.from_numpy(r["W_fq"]).half()
         layer = Q.PBLinear.from_dense(W16, None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
-        _cache[name] = (layer, W16, mask)
-        _cache[name + "_rtn"] = r
-    return _cache[name]
+        _cache[key] = (layer, W16, mask)
+        _cache[key + "_rtn"] = r
+    return _cache[key]
 
 
 # ------------------------------------------------------------------------------------------- config 3
@@ -88,16 +90,17 @@ def test_config3_llama7b_linears_hessian_m2048(name):
 
 
 # ------------------------------------------------------------------------------------------- config 5
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_config5_ksplit_shards_on_one_gpu(world):
+@pytest.mark.parametrize("world,lf", [(2, 0.95), (4, 0.95), (8, 0.95), (2, 0.9), (8, 0.9)])
+def test_config5_ksplit_shards_on_one_gpu(world, lf):
     """configs[4], K split (o_proj / down_proj: "row-sharded ... all-reduce"): all P shards of llama-7b down_proj built
     on cuda:0, the HIP kernel run on each with fp32 partial outputs, partials summed in rank order = what the
-    all-reduce computes; equals the unsharded HIP result and the oracle.  K = 11008 = 86 x 128 does not divide evenly."""
-    layer, W16, mask = cfg3_layer("down_proj")
+    all-reduce computes; equals the unsharded HIP result and the oracle.  K = 11008 = 86 x 128 does not divide evenly.
+    low_frac 0.9 is the value BASELINE configs[4] names; 0.95 shares its layers with the config 3 tests."""
+    layer, W16, mask = cfg3_layer("down_proj", lf)
     N, K = LLAMA7B["down_proj"]
     pts = PP.split_points(K, world, PP.COL_ALIGN)
     assert pts[-1] == K and all(p % 128 == 0 for p in pts[:-1]) and len(set(np.diff(pts))) <= 2
-    rh = _cache["down_proj_rtn"]
+    rh = _cache["down_proj_rtn" if lf == 0.95 else f"down_proj@{lf}_rtn"]
     mods = []
     for rank in range(world):                                       # the P shards, built once (quantizer state handed through)
         shard, (c0, c1) = PP.shard_linear(W16, None, torch.from_numpy(mask), "k", rank, world, high_scale=rh["hscale"],
