@@ -9,6 +9,7 @@
 // gptq_pb/eval_ppl_utils.py:55-64).  Other regimes (rows > 32, fp32 / bf16 activations) stay in pb_llm_amd/quant.py.
 // Host code only: built with g++ against libtorch and libpbl.so (__graft_entry__.build()).
 #include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -22,6 +23,7 @@ at::Tensor pbl_native_linear(const at::Tensor& blob, const c10::optional<at::Ten
     TORCH_CHECK(x.scalar_type() == at::kHalf, "pbllm_native.linear: fp16 activations");
     TORCH_CHECK(x.dim() >= 1 && x.size(-1) == K, "pbllm_native.linear: in_features mismatch: x has ", x.size(-1), ", layer has ", K);
     TORCH_CHECK(blob.device() == x.device(), "pbllm_native.linear: packed weight and input are on different devices");
+    const c10::DeviceGuard guard(x.device());        // a process that drives several GPUs: launch where x lives
     const at::Tensor xc = x.reshape({-1, K}).contiguous();
     const int64_t M = xc.size(0);
     TORCH_CHECK(M >= 1 && M <= 32, "pbllm_native.linear: 1..32 rows (decode / small batch); larger batches go through pb_llm_amd.quant");
