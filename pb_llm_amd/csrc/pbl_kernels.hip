@@ -30,11 +30,21 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define PBL_WAVE 64
 // Ablation builds for performance analysis only (tools/ablate.sh): 1 = memory only
 // (loads kept live, math skipped), 2 = compute only (weight-stream loads skipped).
+// TIMING-ONLY probes for tools/build_variant.sh (results are wrong; 0 in every shipped build): bit 0 chunk partials at half size
+// (one more workgroup per CU), 1 no per-word sum of x, 2 classes 8 / 9 unpacked by a plain AND, 3 tile loads without nt,
+// 4 salient loads without nt
+#ifndef PBL_PROBE
+#define PBL_PROBE 0
+#endif
 #ifndef PBL_ABLATE
 #define PBL_ABLATE 0
 #endif
 
 namespace {
+
+typedef uint32_t probe_u32x4 __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ T load_tile(const T* p) { return (PBL_PROBE & 8) ? *p : __builtin_nontemporal_load(p); }
+template <typename T> __device__ __forceinline__ T load_sal(const T* p) { return (PBL_PROBE & 16) ? *p : __builtin_nontemporal_load(p); }
 
 __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, a), __builtin_bit_cast(h2, b), c, false);
@@ -77,7 +87,7 @@ __device__ __forceinline__ void class_consts(int ci, float& A, float& B) {
 // literal on gfx9; with M in an SGPR and C in a VGPR it is a single v_and_or_b32.
 template <int CI>
 __device__ __forceinline__ uint32_t unpack_pair(uint32_t w, uint32_t c_one, float order_after) {
-    if constexpr (BitClass<CI>::C == 0u) {
+    if constexpr (BitClass<CI>::C == 0u || ((PBL_PROBE & 4) && CI < 2)) {
         return w & BitClass<CI>::M;
     } else {
         // `order_after` (an accumulator the previous class step wrote) is an unused input: it pins this instruction behind that
@@ -106,8 +116,9 @@ template <int MB>
 __device__ __forceinline__ void word_step(uint32_t w, uint32_t c_one, const uint32_t (&xr)[MB],
                                           float (&acc)[MB][16], float (&xl)[MB]) {
     const uint32_t ws = w << 8;
+    if (!(PBL_PROBE & 2))
 #pragma unroll
-    for (int m = 0; m < MB; ++m) xl[m] = dot2(c_one, xr[m], xl[m]);
+        for (int m = 0; m < MB; ++m) xl[m] = dot2(c_one, xr[m], xl[m]);
     class_step<MB, 0>(w, ws, c_one, xr, acc);
     class_step<MB, 1>(w, ws, c_one, xr, acc);
     class_step<MB, 2>(w, ws, c_one, xr, acc);
@@ -359,15 +370,15 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     uint32_t abl = 0;
     (void)abl;
     if (active && PBL_ABLATE != 2) {
-        if (wslot < P) t0 = __builtin_nontemporal_load(tiles + wslot * 64);
-        if (wslot + WSTEP < P) t1 = __builtin_nontemporal_load(tiles + (wslot + WSTEP) * 64);
-        if (PBL_TILE_RING == 3 && wslot + 2 * WSTEP < P) t2 = __builtin_nontemporal_load(tiles + (wslot + 2 * WSTEP) * 64);
+        if (wslot < P) t0 = load_tile(tiles + wslot * 64);
+        if (wslot + WSTEP < P) t1 = load_tile(tiles + (wslot + WSTEP) * 64);
+        if (PBL_TILE_RING == 3 && wslot + 2 * WSTEP < P) t2 = load_tile(tiles + (wslot + 2 * WSTEP) * 64);
         if (nch > wslot * PBL_WAVE) {
             const int c_first = wslot * PBL_WAVE + lane;
             const int cc = c_first < nch ? c_first : nch - 1;
             s_c0 = col0p[cc];
-            s_d4 = __builtin_nontemporal_load(deltap + cc);
-            s_q4 = __builtin_nontemporal_load(codep + cc);
+            s_d4 = load_sal(deltap + cc);
+            s_q4 = load_sal(codep + cc);
         }
     }
 
@@ -417,23 +428,23 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
 #if PBL_TILE_RING == 3
     for (int p = wslot; p < P; p += 3 * WSTEP) {
         panel(t0, p);
-        if (p + 3 * WSTEP < P && PBL_ABLATE != 2) t0 = __builtin_nontemporal_load(tiles + (p + 3 * WSTEP) * 64);
+        if (p + 3 * WSTEP < P && PBL_ABLATE != 2) t0 = load_tile(tiles + (p + 3 * WSTEP) * 64);
         asm volatile("" ::: "memory");       // (keeps the next panel's LDS reads of x from being hoisted: 80 -> 64 VGPRs)
         if (p + WSTEP < P) {
             panel(t1, p + WSTEP);
-            if (p + 4 * WSTEP < P && PBL_ABLATE != 2) t1 = __builtin_nontemporal_load(tiles + (p + 4 * WSTEP) * 64);
+            if (p + 4 * WSTEP < P && PBL_ABLATE != 2) t1 = load_tile(tiles + (p + 4 * WSTEP) * 64);
         }
         asm volatile("" ::: "memory");
         if (p + 2 * WSTEP < P) {
             panel(t2, p + 2 * WSTEP);
-            if (p + 5 * WSTEP < P && PBL_ABLATE != 2) t2 = __builtin_nontemporal_load(tiles + (p + 5 * WSTEP) * 64);
+            if (p + 5 * WSTEP < P && PBL_ABLATE != 2) t2 = load_tile(tiles + (p + 5 * WSTEP) * 64);
         }
         asm volatile("" ::: "memory");
     }
 #else
     for (int p = wslot; p < P; p += WSTEP) {              // the rotating form of rounds 1-2 (kept for A/B runs)
         u32x4 tn = t1;
-        if (p + 2 * WSTEP < P && PBL_ABLATE != 2) tn = __builtin_nontemporal_load(tiles + (p + 2 * WSTEP) * 64);
+        if (p + 2 * WSTEP < P && PBL_ABLATE != 2) tn = load_tile(tiles + (p + 2 * WSTEP) * 64);
         panel(t0, p);
         t0 = t1;
         t1 = tn;
@@ -460,7 +471,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     const bool has_crow = L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16);
 
     // ---- phase 2: salient chunks (next round's loads issued before this round's math) ---
-    float2* part = part_all + (SPLIT > 1 ? size_t(0) : size_t(wave) * L.max_nch * MB);
+    float2* part = part_all + (SPLIT > 1 ? size_t(0) : size_t(wave) * ((PBL_PROBE & 1) ? (L.max_nch + 1) / 2 : L.max_nch) * MB);
     {
         const uint32_t xbase = uint32_t(reinterpret_cast<uintptr_t>(xs));      // LDS byte offset of x
         const uint32_t tok_stride = uint32_t(xstride) * 2u;
@@ -474,8 +485,8 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
             if (base + WSTEP * PBL_WAVE < nch && PBL_ABLATE != 2) {
                 const int cn = c + WSTEP * PBL_WAVE < nch ? c + WSTEP * PBL_WAVE : nch - 1;
                 s_c0 = col0p[cn];
-                s_d4 = __builtin_nontemporal_load(deltap + cn);
-                s_q4 = __builtin_nontemporal_load(codep + cn);
+                s_d4 = load_sal(deltap + cn);
+                s_q4 = load_sal(codep + cn);
             }
             float Q[MB], S[MB];
 #pragma unroll
@@ -504,7 +515,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
             if (valid) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m)   // code mode: undo the 1024 code bias here, once per chunk
-                    part[size_t(m) * L.max_nch + c] = make_float2((SF && sf) ? Q[m] : fmaf(-1024.f, S[m], Q[m]), S[m]);
+                    part[size_t(m) * L.max_nch + ((PBL_PROBE & 1) ? (c >> 1) : c)] = make_float2((SF && sf) ? Q[m] : fmaf(-1024.f, S[m], Q[m]), S[m]);
             }
         }
     }
@@ -545,11 +556,11 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
         float Q = 0.f, S = 0.f;
         const float2* pm = part + size_t(m) * L.max_nch;
         for (int k = sub; k < int(ri.nfull); k += 4) {
-            const float2 v = pm[ri.start + k];
+            const float2 v = pm[(PBL_PROBE & 1) ? ((ri.start + k) >> 1) : (ri.start + k)];
             Q += v.x; S += v.y;
         }
         for (int k = sub; k < int(ri.ntail); k += 4) {
-            const float2 v = pm[nfull + ri.tailidx + k];
+            const float2 v = pm[(PBL_PROBE & 1) ? ((nfull + ri.tailidx + k) >> 1) : (nfull + ri.tailidx + k)];
             Q += v.x; S += v.y;
         }
         Q = quad_sum(Q); S = quad_sum(S);
@@ -582,7 +593,7 @@ size_t lds_bytes(uint32_t P, uint32_t max_nch, int mb, int wpb, int split = 1) {
     const size_t xstride = size_t(P) * PBL_PANEL_COLS + 8;
     size_t s = (size_t(mb) * xstride * 2 + 15) & ~size_t(15);
     if (split > 1) s += (size_t(max_nch) + size_t(split) * PBL_WAVE) * mb * sizeof(float2);
-    else s += size_t(wpb) * max_nch * mb * sizeof(float2);
+    else s += size_t(wpb) * ((PBL_PROBE & 1) ? (max_nch + 1) / 2 : max_nch) * mb * sizeof(float2);
     return s + 16;
 }
 
