@@ -1,14 +1,14 @@
 #!/bin/bash
 # One gpurun call of round 3 (rewritten per call; results under gpurun_out/<tag>/).  Usage: tools/gpu_job.sh <tag>
-# Timing-only probes of the headline GEMV (PBL_PROBE builds: results wrong by construction, only the launch time is read).
+# Round-end validation of the committed state: full -m gpu suite, the driver's bench command, smoke, the side workloads.
 set -u
 export TMPDIR=/tmp
-O=gpurun_out/${1:-r3w}; mkdir -p $O
+O=gpurun_out/${1:-r3x}; mkdir -p $O
 timeout 120 python __graft_entry__.py > $O/build.txt 2>&1
-for rep in 1 2; do
-for v in default p1 p2 p4 p8 p16 p7; do
-  if [ $v = default ]; then L=""; else L="build/libpbl_$v.so"; fi
-  echo -n "$v " >> $O/bench_gemv.txt
-  PBL_LIB=$L timeout 60 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print(round(d['value']), round(d['roofline']['frac'],4), round(d['roofline']['us_per_launch'],1))" >> $O/bench_gemv.txt
-done; done
-cat $O/bench_gemv.txt
+timeout 600 python -m pytest tests -q -m gpu 2>&1 | tail -8 > $O/test_all.txt
+timeout 100 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err
+timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1
+for b in library fused; do timeout 100 python bench.py --workload cfg3 --gemm-backend $b --steps 20 --warmup 5 2>/dev/null | tail -1 >> $O/bench_side.jsonl; done
+timeout 100 python bench.py --workload cfg4 --steps 50 --warmup 10 2>/dev/null | tail -1 >> $O/bench_side.jsonl
+MODES=prefill timeout 300 python tools/bench_llama7b.py > $O/llama7b_prefill.json 2> $O/llama7b.err
+cat $O/test_all.txt; tail -1 $O/bench_driver.json | cut -c1-330; tail -2 $O/smoke.txt; cut -c1-420 $O/bench_side.jsonl; tail -1 $O/llama7b_prefill.json | cut -c1-900
