@@ -84,7 +84,6 @@ struct MfmaArgs {
     float* part;            // [KS][M][N] fp32 (KS > 1)
     int M, y_f32, KS, sps;  // sps: slabs per K split
     int gshift;             // log2(columns per group) (GRP kernels)
-    int tw;                 // two-slabs-ahead loop (17..32 tokens, G == 1): entries per row of the slab table kept in LDS (sps + 4)
 };
 
 constexpr size_t MFMA_WAVE_BYTES = 16 + size_t(16) * SSTR * 2 + 2 * 512 + 256;   // dump slot + St + Wp + Wp << 8 + row params
@@ -102,10 +101,8 @@ __host__ __device__ constexpr size_t mfma_lds_bytes(int ntb) {
 // GRP: the layer has column groups (G > 1, a power-of-two number of columns >= 128 each): the binarized part and the salient
 // mask are folded into per-row totals at every group boundary with that group's (hi, lo), exactly as the column-group GEMV does
 // (pbl_kernels.hip); X is then needed per 128-column half slab and goes through LDS (Xh).
-// (second launch bound = waves per SIMD the register allocation must leave room for: two resident workgroups per CU, three
-// for the single-x-tile layout of <= 16 tokens without column groups -- what the LDS footprint allows)
 template <int NTB, bool SF, bool Q4, bool GRP>
-__global__ __launch_bounds__(WPG * GW, (mfma_xbufs(NTB) == 1 && !GRP) ? 3 : 2) void pbl_mfma_kernel(MfmaArgs a) {
+__global__ __launch_bounds__(WPG * GW) void pbl_mfma_kernel(MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_g[];
     constexpr int XT = 16 * NTB;                   // token rows of the x tile
     constexpr int XB = mfma_xbufs(NTB);            // x tiles in LDS
@@ -366,161 +363,6 @@ __global__ __launch_bounds__(WPG * GW, (mfma_xbufs(NTB) == 1 && !GRP) ? 3 : 2) v
         const float4* wp = reinterpret_cast<const float4*>(blob + size_t(winfo.x) * 16 + PBL_REC_PARAMS_OFF);
         reinterpret_cast<float4*>(smem_g + size_t(XB) * XT * SSTR * 2 + size_t(tid >> 4) * MFMA_WAVE_BYTES + 16 + size_t(16) * SSTR * 2 + 1024)[tid & 15] = wp[tid & 15];
     }
-    if constexpr (!GRP && NTB == 2) {
-    // ======================== 17..32 tokens, G == 1: requests two slabs ahead (round 3) ======================================
-    // (<= 16 tokens keep the loop below: three resident workgroups per CU leave 168 registers per lane, and this loop's three
-    // request sets need ~215 -- a spilled register that an in-flight load is about to write is not an option)
-    // Rounds 1-2 requested slab s + 1 at the top of iteration s and moved it into the "current" registers at the bottom
-    // (cA = nA, ...): hipcc waits vmcnt(0) in front of such a copy, so the data had one iteration to land -- and with two
-    // resident workgroups per CU (8 waves) and ~9 KB of requests per workgroup and slab only ~4 MB were in flight on the whole
-    // chip: the loop waited on memory (chunk loads 8 us, x 3.5 us of a 46 us config-4 call).  Now what comes from HBM (chunk
-    // rounds, sign-plane dwords) is requested TWO slabs ahead into three static register sets (slab s lives in set s mod 3, the
-    // loop is unrolled by 3, nothing is ever copied), x (L2 resident) one slab ahead and in front of them, the slab index sits
-    // in LDS.  All of these loads are issued from inline asm and waited for with ONE counted vmcnt per iteration: x of this
-    // slab has landed when only the NDEEP younger requests are outstanding, and the in-order counter then implies that this
-    // slab's deep set -- two iterations old -- has landed too.  Every iteration issues exactly the same number of loads (clamped
-    // addresses; what lies beyond the range is masked afterwards), so the count never lies.
-    constexpr int R = Q4 ? 3 : 2;                    // chunk rounds requested ahead (more are fetched on demand, rarely)
-    constexpr int NDEEP = 3 * R + 1;                 // loads per deep request
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    struct Deep { u32x4 d4[R], q4[R]; uint32_t c0[R]; u32x2 w; uint32_t ok; Seq sq; };
-    Deep D0, D1, D2;
-    const int TW = a.tw;
-    uint32_t* tabL = reinterpret_cast<uint32_t*>(smem_g + mfma_lds_bytes(NTB)) + size_t(wave) * 16 * TW;
-    for (int i = lane; i < 16 * TW; i += GW) {       // slabs s0 - 1 .. s0 + TW - 2 of the record's 16 rows (0 outside the layer)
-        const int row = i / TW, sj = s0 - 1 + (i - row * TW);
-        tabL[i] = (sj >= 0 && sj < NS) ? slabtab[row * NS + sj] : 0u;
-    }
-    auto tabl = [&](int sj) -> uint32_t { return tabL[rho_s * TW + (sj - s0 + 1)]; };
-    // a record without salients has no chunk arrays: the clamped requests read the record's own first bytes instead
-    const u32x4* dsafe = nch ? deltap : reinterpret_cast<const u32x4*>(rec);
-    const u32x4* qsafe = nch ? codep : reinterpret_cast<const u32x4*>(rec);
-    const uint16_t* csafe = nch ? col0p : reinterpret_cast<const uint16_t*>(rec);
-    const int cmax = nch ? nch - 1 : 0;
-    auto request_deep = [&](Deep& D, int sreq) {
-        const int sc = min(sreq, s1 - 1);
-        const Seq q = seq_of(tabl(sc - 1), tabl(sc));
-        D.sq = q;
-        uint32_t ok = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int j = Q4 ? r : slot + 4 * r;
-            int c = -1;
-            if (j < q.fn) c = int(ri.start) + q.fb + j;
-            else if (j - q.fn < q.tn) c = nfull + int(ri.tailidx) + q.tb + (j - q.fn);
-            ok |= (c >= 0 && sreq < s1 && !(PBL_MFMA_ABLATE & 64)) ? (1u << r) : 0u;
-            const int cc = min(max(c, 0), cmax);
-            const u32x4* pd = dsafe + cc;
-            const u32x4* pq = qsafe + cc;
-            const uint16_t* pc = csafe + cc;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(D.d4[r]) : "v"(pd) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(D.q4[r]) : "v"(pq) : "memory");
-            asm volatile("global_load_ushort %0, %1, off" : "=&v"(D.c0[r]) : "v"(pc) : "memory");
-        }
-        D.ok = ok;
-        const char* pw = reinterpret_cast<const char*>(tiles + (sc >> 1) * 64) + (sc & 1) * 8;
-        asm volatile("global_load_dwordx2 %0, %1, off nt" : "=&v"(D.w) : "v"(pw) : "memory");
-    };
-    auto request_x = [&](int sreq) {
-        const int sc = min(sreq, s1 - 1);
-#pragma unroll
-        for (int j = 0; j < 2 * NTB; ++j) {
-            const int idx = tid + j * (WPG * GW), tok = min(idx >> 5, M - 1), col = min(sc * SLAB + (idx & 31) * 8, K - 8);
-            const _Float16* px = a.x + size_t(tok) * K + col;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(xr[j]) : "v"(px) : "memory");
-        }
-    };
-    auto mask_x = [&](int sx) {                      // what request_x clamped: tokens >= M, columns >= K
-#pragma unroll
-        for (int j = 0; j < 2 * NTB; ++j) {
-            const int idx = tid + j * (WPG * GW), tok = idx >> 5, col = sx * SLAB + (idx & 31) * 8;
-            if (!(tok < M && col < K) || (PBL_MFMA_ABLATE & 16)) xr[j] = u32x4{0, 0, 0, 0};
-        }
-    };
-    // x of this slab and this slab's deep set have landed; the NDEEP requests of the next slab stay in flight
-    auto wait_top = [&](Deep& D) {
-        static_assert(NDEEP == 7 || NDEEP == 10, "the counts below are spelled out");
-        if constexpr (NTB == 2 && R == 2)
-            asm volatile("s_waitcnt vmcnt(7)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(D.d4[0]), "+v"(D.d4[1]), "+v"(D.q4[0]),
-                         "+v"(D.q4[1]), "+v"(D.c0[0]), "+v"(D.c0[1]), "+v"(D.w) :: "memory");
-        else if constexpr (NTB == 1 && R == 2)
-            asm volatile("s_waitcnt vmcnt(7)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(D.d4[0]), "+v"(D.d4[1]), "+v"(D.q4[0]),
-                         "+v"(D.q4[1]), "+v"(D.c0[0]), "+v"(D.c0[1]), "+v"(D.w) :: "memory");
-        else if constexpr (NTB == 2)
-            asm volatile("s_waitcnt vmcnt(10)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]), "+v"(D.d4[0]), "+v"(D.d4[1]), "+v"(D.d4[R - 1]),
-                         "+v"(D.q4[0]), "+v"(D.q4[1]), "+v"(D.q4[R - 1]), "+v"(D.c0[0]), "+v"(D.c0[1]), "+v"(D.c0[R - 1]), "+v"(D.w) :: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(10)" : "+v"(xr[0]), "+v"(xr[1]), "+v"(D.d4[0]), "+v"(D.d4[1]), "+v"(D.d4[R - 1]),
-                         "+v"(D.q4[0]), "+v"(D.q4[1]), "+v"(D.q4[R - 1]), "+v"(D.c0[0]), "+v"(D.c0[1]), "+v"(D.c0[R - 1]), "+v"(D.w) :: "memory");
-    };
-    for (int i = lane; i < int(size_t(16) * SSTR * 2 / 16); i += GW) reinterpret_cast<u32x4*>(St)[i] = u32x4{0, 0, 0, 0};
-    request_deep(D0, s0);
-    request_x(s0);
-    request_deep(D1, s0 + 1);
-    // one slab: Dc holds it, Dq (the set of slab s - 1, free again) takes the requests of slab s + 2
-    auto slab_iter = [&](int s, Deep& Dc, Deep& Dq) {
-        const int buf = XB == 2 ? (s - s0) & 1 : 0, cb = s * SLAB;
-        wait_top(Dc);
-        if (XB == 1 && s > s0) __syncthreads();      // a single x tile: every wave must be done with the previous slab's fragments
-        mask_x(s);
-        store_x(buf);
-        request_x(s + 1);
-        request_deep(Dq, s + 2);
-        {   // this slab's two sign-plane dwords -> Wp[sub-block][lane], as is and << 8
-            const uint32_t w0 = Dc.w[0], w1 = Dc.w[1];
-            Wp[lane] = w0; Wp[64 + lane] = w1; Wp8[lane] = w0 << 8; Wp8[64 + lane] = w1 << 8;
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            ChunkRegs cr;
-            cr.d4 = Dc.d4[r]; cr.q4 = Dc.q4[r];
-            cr.col0 = ((Dc.ok >> r) & 1u) ? int(Dc.c0[r]) : PBL_NO_CHUNK;
-            scatter(cr, cb);
-        }
-        for (int rnd = R; rounds_left(rnd, Dc.sq); ++rnd) scatter(load_chunk(rnd, Dc.sq), cb);
-        __syncthreads();   // x tile `buf` complete; everybody is done reading tile buf ^ 1; St / Wp ordered
-        const _Float16* xt = Xs + size_t(buf) * XT * SSTR;
-        struct Frags { u32x4 sd, wd; v8h bx[NTB]; };
-        auto read_frags = [&](int k8) -> Frags {
-            Frags f;
-            f.sd = *reinterpret_cast<const u32x4*>(St + row_a * SSTR + k8 * 32 + kblk * 8);
-            f.wd = *reinterpret_cast<const u32x4*>(Wsel + (k8 >> 2) * 64 + (k8 & 3) * 16 + kblk * 4);
-#pragma unroll
-            for (int t = 0; t < NTB; ++t) f.bx[t] = *reinterpret_cast<const v8h*>(xt + (t * 16 + row_a) * SSTR + k8 * 32 + kblk * 8);
-            return f;
-        };
-        Frags fcur = read_frags(0);
-#pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-            Frags fnext = fcur;
-            if (k8 + 1 < 8) fnext = read_frags(k8 + 1);
-            const v8h aW = frag(fcur.wd);
-            const v8h aS = __builtin_bit_cast(v8h, fcur.sd);
-            const v8h aM = mfrag(fcur.sd);
-#pragma unroll
-            for (int t = 0; t < ((PBL_MFMA_ABLATE & 4) ? 0 : NTB); ++t) {
-                accW[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aW, fcur.bx[t], accW[t], 0, 0, 0);
-                accS[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aS, fcur.bx[t], accS[t], 0, 0, 0);
-                accM[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aM, fcur.bx[t], accM[t], 0, 0, 0);
-            }
-            fcur = fnext;
-        }
-        if (!(PBL_MFMA_ABLATE & 8)) {
-            for (int i = lane; i < int(size_t(16) * SSTR * 2 / 16); i += GW) reinterpret_cast<u32x4*>(St)[i] = u32x4{0, 0, 0, 0};
-        }
-        asm volatile("" ::: "memory");
-    };
-    for (int s = s0; s < s1; s += 3) {
-        slab_iter(s, D0, D2);
-        if (s + 1 >= s1) break;
-        slab_iter(s + 1, D1, D0);
-        if (s + 2 >= s1) break;
-        slab_iter(s + 2, D2, D1);
-    }
-    // requests beyond the last slab are still in flight and the registers they write are about to be reused
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-    // ======================== column groups, <= 16 tokens: the loop of round 2 (requests one slab ahead) ======================
     u32x4 t_cur = {0, 0, 0, 0}, t_next = {0, 0, 0, 0};
     ChunkRegs cA, cB, cC, nA, nB, nC;                  // rounds 0, 1, 2 of the current / next slab
     cA.col0 = cB.col0 = cC.col0 = nA.col0 = nB.col0 = nC.col0 = PBL_NO_CHUNK;
@@ -627,8 +469,6 @@ __global__ __launch_bounds__(WPG * GW, (mfma_xbufs(NTB) == 1 && !GRP) ? 3 : 2) v
         // the tile is written as halves / dwords and read as 16-byte vectors: keep the compiler from moving the next
         // slab's stores across this slab's (type-based alias analysis would allow it; the LDS itself is in order)
         asm volatile("" ::: "memory");
-    }
-
     }
 
     // ---- X (the plain sum of x over this split's columns): 32 consecutive lanes staged one token's columns ----
@@ -790,9 +630,7 @@ extern "C" int pbl_gemm_mfma_f16_ws(const pbl_layer* layer, const void* x, void*
     const void* k = ntb == 1 ? (sf ? PBL_PICK(1, true) : PBL_PICK(1, false)) : (sf ? PBL_PICK(2, true) : PBL_PICK(2, false));
 #undef PBL_PICK
 #undef PBL_PICK2
-    a.tw = a.sps + 4;
-    const size_t lds = mfma_lds_bytes(ntb) + ((grp || ntb != 2) ? 0 : size_t(WPG) * 16 * a.tw * 4);   // + the slab table of the two-slabs-ahead loop
-    if (lds > 160 * 1024) return PBL_ERR_UNSUPPORTED;
+    const size_t lds = mfma_lds_bytes(ntb);
     if (lds > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
         return PBL_ERR_LAUNCH;
     void* argv[] = {&a};
