@@ -1,15 +1,15 @@
 #!/bin/bash
 # One gpurun call of round 3 (rewritten per call; results under gpurun_out/<tag>/).  Usage: tools/gpu_job.sh <tag>
-# Small-batch matrix-core kernel with requests two slabs ahead: parity first, then timing against the previous build.
+# Plumbing run of the multi-rank bench path on a one-GPU box: 2 ranks share cuda:0, control tensors over gloo, the data-path
+# sums through the peer-to-peer all-reduce; per-layer (64 dependent reductions) and stacked.  Never a measurement.
 set -u
 export TMPDIR=/tmp
-O=gpurun_out/${1:-r3y}; mkdir -p $O
+O=gpurun_out/${1:-r3z}; mkdir -p $O
 timeout 120 python __graft_entry__.py > $O/build.txt 2>&1
-timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py tests/test_gpu_fuzz.py -q -m gpu -x -k "mfma or m32 or small_batch or random_layer or routing or shapes_and_batches" 2>&1 | tail -8 > $O/test_sel.txt
-cat $O/test_sel.txt
-for v in default oldm default oldm; do
-  if [ $v = default ]; then L=""; else L="build/libpbl_$v.so"; fi
-  echo -n "$v " >> $O/bench_mfma.txt
-  PBL_LIB=$L PBL_BENCH_M=32,24 timeout 200 python tools/bench_mfma.py 2>/dev/null | tail -1 >> $O/bench_mfma.txt
+for tc in per-layer stacked; do
+  PBL_BENCH_BACKEND=gloo timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+    bench.py --gpus 2 --steps 5 --warmup 2 --preheat-s 0.3 --collective p2p --tp-collectives $tc --no-cpu-baseline > $O/tp2_$tc.json 2> $O/tp2_$tc.err
+  echo "rc=$?" >> $O/tp2_$tc.json
+  tail -2 $O/tp2_$tc.json | cut -c1-900
 done
-cat $O/bench_mfma.txt
+tail -5 $O/tp2_per-layer.err | cut -c1-300
