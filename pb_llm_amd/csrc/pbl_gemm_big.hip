@@ -66,7 +66,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define GB_LDS (GB_X_OFF + NCONS * GB_XRING_BYTES)  // 163840 B
 // performance-analysis hook (tools/build_variant.sh): bit 0 no expansion in the loop, 1 no x staging in the loop, 2 no MFMA,
 // 3 no sign-plane expansion, 4 no salient overlay, 5 producers request nothing either (consumer loop alone), 6 no fragment
-// reads in the loop, 7 no barriers in the loop.  0 in every
+// reads in the loop, 7 no barriers in the loop, 8 no result stores, 9 no epilogue.  0 in every
 // shipped build (results are wrong otherwise).
 #ifndef PBL_GEMM_ABLATE
 #define PBL_GEMM_ABLATE 0
@@ -774,6 +774,13 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
     constexpr int EPT = (32u * YSTR <= GB_XRING_BYTES) ? 32 : 16;     // tokens per pass: what the ring holds (fp32 result of 8 consumers: 16)
     const uint32_t row0 = rowblk * GB_ROWS;
     const bool vec = (L.N & (Y32 ? 3 : 7)) == 0 && row0 + GB_ROWS <= L.N;     // whole 16-byte units, all rows exist
+    if (PBL_GEMM_ABLATE & 512) {          // (timing probe: no epilogue at all; the accumulators stay live)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int tt = 0; tt < GB_TT; ++tt) asm volatile("" :: "v"(acc[rt][tt]));
+        return;
+    }
 #pragma unroll
     for (int tt = 0; tt < GB_TT; ++tt) {
 #pragma unroll
@@ -809,7 +816,8 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
                 constexpr int EPU = 16 / int(sizeof(yt));            // elements per unit
                 yt* dstg = static_cast<yt*>(a.y) + size_t(tok) * L.N + row0 + un * EPU;
                 const yt* src = reinterpret_cast<const yt*>(smem_b + xring + uint32_t(t) * YSTR) + un * EPU;
-                if (vec) *reinterpret_cast<u32x4*>(dstg) = *reinterpret_cast<const u32x4*>(src);
+                if (PBL_GEMM_ABLATE & 256) { if (tok == 0x7FFFFFFF) *reinterpret_cast<u32x4*>(dstg) = *reinterpret_cast<const u32x4*>(src); }    // (timing probe: no result stores)
+                else if (vec) *reinterpret_cast<u32x4*>(dstg) = *reinterpret_cast<const u32x4*>(src);
                 else
                     for (int e = 0; e < EPU; ++e)
                         if (row0 + un * EPU + e < L.N) dstg[e] = src[e];
