@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from pb_llm_amd import _lib, io as pbio, quant as Q, synth
+from pb_llm_amd.packing import PackedWeight
 from conftest import golden
 
 
@@ -79,3 +80,35 @@ def test_round3_c_abi_symbols_and_gemm_workspace_sizing():
     assert L.pbl_p2p_buffer_bytes_world(4096, 2) < L.pbl_p2p_buffer_bytes(4096) // 4
     assert L.pbl_p2p_buffer_bytes_world(4096, 17) == 0
     assert _lib.native_linear() is not None                                   # the native dispatcher is built and registered
+
+
+def test_gemm_list_halves_of_the_c_abi_without_a_gpu():
+    """pbl_gemm_list_bytes / pbl_gemm_prepare / pbl_gemm_f16_prepared: sizing is a pure function of the layer (never of M), the
+    argument checks answer before any launch"""
+    import __graft_entry__ as ge
+    ge.build()
+    L = _lib.lib()
+    lay = _lib.PblLayer(blob=None, bias=None, N=4096, K=4096, P=8, G=1, NRB=256, flags=0xE, max_nch=500, max_nexc=3)
+    nb = L.pbl_gemm_list_bytes(C.byref(lay))
+    assert nb == L.pbl_gemm_workspace_bytes(C.byref(lay), 2048) == L.pbl_gemm_workspace_bytes(C.byref(lay), 257) > 0
+    lay.K, lay.P = 16512, 33
+    assert L.pbl_gemm_list_bytes(C.byref(lay)) == 0
+    lay.K, lay.P = 4096, 8
+    assert L.pbl_gemm_prepare(C.byref(lay), None, 0, None) == _lib.PBL_ERR_INVALID_ARG                    # no blob
+    assert L.pbl_gemm_f16_prepared(C.byref(lay), None, None, 64, 0, None, 0, None) == _lib.PBL_ERR_INVALID_ARG
+    assert L.pbl_gemm_list_bytes(None) == 0
+
+
+def test_decode_regime_routing_of_the_native_dispatcher():
+    """pb_linear_forward hands <= 32 fp16 rows to the native operator only where the C router has a kernel for them: layers
+    the matrix-core kernel refuses (group size not a power of two >= 128, K % 8) must keep the Python path from 12 rows on,
+    which sends them to the dense backend"""
+    def pw(K, G, flags=0xE):
+        return PackedWeight(torch.zeros(16, dtype=torch.uint8), 64, K, (K + 511) // 512, G, 4, flags, 8, 0, 0, 0)
+    assert Q._mfma_ok(pw(4096, 1))
+    assert Q._mfma_ok(pw(4096, 32)) and Q._mfma_ok(pw(4096, 16))          # groups of 128 / 256 columns
+    assert not Q._mfma_ok(pw(1152, 3))                                      # groups of 384 columns
+    assert not Q._mfma_ok(pw(4096, 64))                                     # groups of 64 columns
+    assert not Q._mfma_ok(pw(4100, 1))                                      # K % 8
+    assert not Q._mfma_ok(pw(4096, 1, flags=0x6))                           # no slab index (format version 1 blob)
+    assert Q.GEMM_THRESHOLD == 12 and Q.MFMA_MAX == 32
