@@ -112,3 +112,15 @@ def test_decode_regime_routing_of_the_native_dispatcher():
     assert not Q._mfma_ok(pw(4100, 1))                                      # K % 8
     assert not Q._mfma_ok(pw(4096, 1, flags=0x6))                           # no slab index (format version 1 blob)
     assert Q.GEMM_THRESHOLD == 12 and Q.MFMA_MAX == 32
+
+
+def test_asm_issued_loads_of_the_gemm_producers_are_never_touched_in_flight():
+    """csrc/pbl_gemm_big.hip issues the LIST producers' stage requests from inline asm and waits for them with a counted vmcnt
+    (hipcc's own bookkeeping degenerates to vmcnt(0) in that loop).  Nothing but register discipline keeps that correct: no
+    instruction may read or write a register between the load that will fill it and the wait that covers it.
+    tools/audit_asm_loads.py compiles the file and walks the generated ISA (prologue + two trips around the stage loop)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("audit_asm_loads", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "audit_asm_loads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.main() == 0
