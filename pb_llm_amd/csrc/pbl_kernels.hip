@@ -39,6 +39,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #ifndef PBL_ABLATE
 #define PBL_ABLATE 0
 #endif
+// pbl_unpack_dev: stream the dense rows out with non-temporal stores (A/B builds; the library GEMM that follows reads the
+// buffer right away, so bypassing the caches is not obviously right)
+#ifndef PBL_UNPACK_NT
+#define PBL_UNPACK_NT 0
+#endif
 
 namespace {
 
@@ -924,8 +929,11 @@ __global__ __launch_bounds__(4 * PBL_WAVE) void pbl_unpack_kernel(pbl_layer L, O
             const int ncol = int(c_lo + c_n) <= K ? int(c_n) : K - int(c_lo);
             if (vec_ok) {
                 constexpr int V = 16 / sizeof(OutT);
-                for (int j = lane * V; j < ncol; j += PBL_WAVE * V)
-                    *reinterpret_cast<u32x4*>(dst + j) = *reinterpret_cast<const u32x4*>(rowbuf + j);
+                for (int j = lane * V; j < ncol; j += PBL_WAVE * V) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(rowbuf + j);
+                    if (PBL_UNPACK_NT) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + j));
+                    else *reinterpret_cast<u32x4*>(dst + j) = v;
+                }
             } else {
                 for (int j = lane; j < ncol; j += PBL_WAVE) dst[j] = rowbuf[j];
             }
