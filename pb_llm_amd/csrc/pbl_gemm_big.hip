@@ -80,6 +80,32 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef PBL_GEMM_PPRIO
 #define PBL_GEMM_PPRIO 1
 #endif
+// experiments on the arbitration between the two MFMA waves of a SIMD (waves c and c + NCONS / 2; oldest first by default):
+// PBL_GEMM_CPRIO_YOUNG: static priority for the younger half; PBL_GEMM_ALT_PRIO: the priority flips every k-step
+#ifndef PBL_GEMM_CPRIO_YOUNG
+#define PBL_GEMM_CPRIO_YOUNG 0
+#endif
+#ifndef PBL_GEMM_ALT_PRIO
+#define PBL_GEMM_ALT_PRIO 0
+#endif
+
+// timeline probe (tools/trace_gemm.py, build/libpbl_trace.so only): every wave stamps s_memrealtime (100 MHz) and s_memtime
+// (shader clock) at entry / loop start / loop end / exit and adds up the shader cycles it spends parked at the workgroup
+// barrier and at counted vmcnt waits.  0 in the shipped build.
+#ifndef PBL_TRACE
+#define PBL_TRACE 0
+#endif
+#if PBL_TRACE
+static uint64_t* g_gemm_trace = nullptr;
+extern "C" void pbl_debug_trace_gemm(void* p) { g_gemm_trace = static_cast<uint64_t*>(p); }
+#define TR_STAMP(slot) do { if (tr && lane == 0) { tr[2 * (slot)] = __builtin_amdgcn_s_memrealtime(); tr[2 * (slot) + 1] = __builtin_readcyclecounter(); } } while (0)
+#define TR_T0() const uint64_t tr_t0 = __builtin_readcyclecounter()
+#define TR_ADD(acc) acc += __builtin_readcyclecounter() - tr_t0
+#else
+#define TR_STAMP(slot) do {} while (0)
+#define TR_T0() do {} while (0)
+#define TR_ADD(acc) do {} while (0)
+#endif
 
 namespace {
 
@@ -99,6 +125,9 @@ struct GemmArgs {
     const uint32_t* ofs;    // [NRB][ofs_stride]: entry ranges per half slab, ofs[rb][h] .. ofs[rb][h + 1]
     const uint32_t* lst;    // [NRB][cap]: (byte offset in the record's 16 x 256-byte stage image << 16) | fp16 value
     uint32_t ofs_stride, cap;
+#if PBL_TRACE
+    uint64_t* trace;        // [workgroup][16 waves][16] (timeline probe)
+#endif
 };
 
 struct Seq { int fb, fn, tb, tn; };            // the row's full / tail chunks that overlap a slab: first index, count
@@ -564,6 +593,12 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
     const uint32_t wg = (xcd < xr_ ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq) + xi;
     const uint32_t rowblk = wg % nrbk;
     const int tok0 = int(wg / nrbk) * GB_TOK;
+#if PBL_TRACE
+    uint64_t* tr = a.trace ? a.trace + (size_t(blockIdx.x) * 16 + wave) * 16 : nullptr;
+    uint64_t tr_bar = 0, tr_vm = 0;
+    TR_STAMP(0);
+    if (tr && lane == 0) { tr[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tr[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+#endif
 
     if (wave >= NCONS) {
         // =================================== producer waves =========================================================
@@ -595,8 +630,12 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
                 const int kpairs = min(GB_HS, K - h * GB_HS) >> 1;
                 const bool work = !(PBL_GEMM_ABLATE & 1) || h == 0;
                 // this set has landed; the other one stays in flight
-                if constexpr (RPP == 2) wait_set(R[0].d[PAR], R[0].e[PAR], R[RPP - 1].d[PAR], R[RPP - 1].e[PAR]);
-                else wait_set(R[0].d[PAR], R[0].e[PAR]);
+                {
+                    TR_T0();
+                    if constexpr (RPP == 2) wait_set(R[0].d[PAR], R[0].e[PAR], R[RPP - 1].d[PAR], R[RPP - 1].e[PAR]);
+                    else wait_set(R[0].d[PAR], R[0].e[PAR]);
+                    TR_ADD(tr_vm);
+                }
 #pragma unroll
                 for (int i = 0; i < RPP; ++i) {
                     const uint32_t recaddr = stage + uint32_t(RPP * p + i) * 4096u;
@@ -609,13 +648,23 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
                     if (L.G > 1 && h + 1 < NH && uint32_t((h + 1) * GB_HS) % gs == 0) load_levels_inloop(R[i], L.G, uint32_t((h + 1) * GB_HS) / gs, lane);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the stage is in LDS
-                if (!(PBL_GEMM_ABLATE & 128) || h == 0) __builtin_amdgcn_s_barrier();
+                if (h == 0) TR_STAMP(1);
+                {
+                    TR_T0();
+                    if (!(PBL_GEMM_ABLATE & 128) || h == 0) __builtin_amdgcn_s_barrier();
+                    TR_ADD(tr_bar);
+                }
                 asm volatile("" ::: "memory");
             };
             for (int h = 0; h < NH; h += 2) {
                 produce(h, std::integral_constant<int, 0>{});
                 if (h + 1 < NH) produce(h + 1, std::integral_constant<int, 1>{});
             }
+            TR_STAMP(2);
+            TR_STAMP(3);
+#if PBL_TRACE
+            if (tr && lane == 0) { tr[8] = tr_bar; tr[9] = tr_vm; }
+#endif
             return;
         }
         Rec R[2];
@@ -712,9 +761,19 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
     if (NU >= 3) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     else if (NU == 2) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR_STAMP(1);
 #if PBL_GEMM_PRIO
     __builtin_amdgcn_s_setprio(PBL_GEMM_PRIO);
 #endif
+#if PBL_GEMM_CPRIO_YOUNG
+    if (c >= NCONS / 2) __builtin_amdgcn_s_setprio(PBL_GEMM_CPRIO_YOUNG);
+#endif
+    auto alt_prio = [&](int k) {
+#if PBL_GEMM_ALT_PRIO
+        if (((k & 1) != 0) == (c >= NCONS / 2)) __builtin_amdgcn_s_setprio(PBL_GEMM_ALT_PRIO);
+        else __builtin_amdgcn_s_setprio(0);
+#endif
+    };
     Frag f0, f1;
     load_frag(f0, smem_b, aq[0], bq[0], false);      // (stage 0, first half: no offsets)
     if (PBL_GEMM_ABLATE & 64) load_frag(f1, smem_b, aq[1], bq[1], false);
@@ -736,26 +795,36 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
         // pieces of sub-step u+2's x go out GB_PQ / 4 per k-step: its slot, (u+2) % 3 == (u-1) % 3, was last read in sub-step u-1
         const bool stage_x = !(PBL_GEMM_ABLATE & 2) && u >= 1 && u + 2 < NU;
         // k-step 0
+        alt_prio(0);
         load_frag(f1, smem_b, (aq[1] ^ ahalf) + abuf, bq[1] + xslot);
         if (stage_x) { issue_x(u + 2, 0 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 0 * 2 + 1); }
         mma(f0);
         // k-step 1
+        alt_prio(1);
         load_frag(f0, smem_b, (aq[2] ^ ahalf) + abuf, bq[2] + xslot);
         if (stage_x) { issue_x(u + 2, 1 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 1 * 2 + 1); }
         mma(f1);
         // k-step 2
+        alt_prio(0);
         load_frag(f1, smem_b, (aq[3] ^ ahalf) + abuf, bq[3] + xslot);
         if (stage_x) { issue_x(u + 2, 2 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 2 * 2 + 1); }
         mma(f0);
         // k-step 3: every read of this sub-step's x slot -- and, in an odd sub-step, of the A stage -- has been issued
+        alt_prio(1);
         if (stage_x) { issue_x(u + 2, 3 * (GB_PQ / 4)); if (GB_PQ == 8) issue_x(u + 2, 3 * 2 + 1); }
         if (!last) {
             // x of sub-step u+1: its pieces were issued during sub-step u-1 (or in the prologue); younger: sub-step u+2's
-            if (u + 2 < NU) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            {
+                TR_T0();
+                if (u + 2 < NU) { if (GB_PQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                TR_ADD(tr_vm);
+            }
             if ((u & 1) && !(PBL_GEMM_ABLATE & 128)) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's reads of the stage have returned
+                TR_T0();
                 __builtin_amdgcn_s_barrier();                            // ... the next stage is complete
+                TR_ADD(tr_bar);
                 asm volatile("" ::: "memory");
             }
             const uint32_t nabuf = uint32_t(((u + 1) >> 1) & 1) * GB_AS_STAGE, nahalf = uint32_t((u + 1) & 1) * 128u;
@@ -769,6 +838,10 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
 
     // ---- epilogue, per consumer wave: accumulators (+ bias) -> Ys[tokens][128 rows] in the wave's own ring -> 16-byte stores
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    TR_STAMP(2);
+#if PBL_TRACE
+    if (tr && lane == 0) { tr[8] = tr_bar; tr[9] = tr_vm; }
+#endif
     typedef typename std::conditional<Y32, float, _Float16>::type yt;
     constexpr uint32_t YSTR = Y32 ? 528u : 272u;              // bytes per token row: 128 rows + 16 B (every 16-byte read-back stays aligned)
     constexpr int EPT = (32u * YSTR <= GB_XRING_BYTES) ? 32 : 16;     // tokens per pass: what the ring holds (fp32 result of 8 consumers: 16)
@@ -825,13 +898,19 @@ __global__ __launch_bounds__((NCONS + (LIST ? NPROD_LIST : NPROD)) * GW) void pb
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done before the next pass overwrites the buffer
         }
     }
+#if PBL_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the result stores have left the wave)
+    TR_STAMP(3);
+#endif
 }
 
 }  // namespace
 
 namespace {
 size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
-uint32_t list_cap(const pbl_layer* l) { return (16u * l->max_nch + l->max_nexc + 3u) & ~3u; }
+// entry words per record; never 0: the producers' unconditional requests clamp their index to cap - 1, so a layer without any
+// salient entry (fully binarized) still owns one 16-byte line per record
+uint32_t list_cap(const pbl_layer* l) { const uint32_t c = (16u * l->max_nch + l->max_nexc + 3u) & ~3u; return c ? c : 4u; }
 int check_layer(const pbl_layer* layer, const void* x, const void* y, int M) {
     if (!layer || !layer->blob || !x || !y || M < 1) return PBL_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(layer->blob) & 15) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
@@ -874,6 +953,9 @@ void list_views(const pbl_layer* layer, void* workspace, GemmArgs& a) {
     a.lst = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + align16(size_t(layer->NRB) * a.ofs_stride * 4));
 }
 int launch_gemm(GemmArgs& a, bool list, hipStream_t s) {
+#if PBL_TRACE
+    a.trace = g_gemm_trace;
+#endif
     const void* k = list ? (a.y_f32 ? reinterpret_cast<const void*>(pbl_gemm_kernel<true, true>) : reinterpret_cast<const void*>(pbl_gemm_kernel<false, true>))
                          : (a.y_f32 ? reinterpret_cast<const void*>(pbl_gemm_kernel<true, false>) : reinterpret_cast<const void*>(pbl_gemm_kernel<false, false>));
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(GB_LDS)) != hipSuccess) return PBL_ERR_LAUNCH;

@@ -90,16 +90,38 @@ def save_bnn(model: nn.Module, save_path: str) -> dict:
     return meta
 
 
-def load_bnn(model: nn.Module, load_path: str, device=None, **ctor_kwargs) -> nn.Module:
+def _load_weights_file(path: str, allow_pickle: bool):
+    """weights.pth of a save_bnn directory.  The reference stores biases as nn.Parameter objects (utils.py:78-83), which the
+    restricted unpickler only takes with the Parameter rebuild helpers allow-listed; anything else in the file needs
+    allow_pickle=True (a full unpickle runs arbitrary code from a foreign directory, as the reference's torch.load does)."""
+    import torch._utils as tu
+    safe = [nn.Parameter, tu._rebuild_parameter]
+    if hasattr(tu, "_rebuild_parameter_with_state"):
+        safe.append(tu._rebuild_parameter_with_state)
+    try:
+        with torch.serialization.safe_globals(safe):
+            return torch.load(path, weights_only=True)
+    except Exception as e:  # noqa: BLE001 -- whatever the restricted unpickler raises, the decision is the caller's
+        if not allow_pickle:
+            raise ValueError(f"{path}: not loadable with the restricted unpickler ({type(e).__name__}: {e}); "
+                             "pass allow_pickle=True to unpickle it fully (only for directories you trust)") from e
+    return torch.load(path, weights_only=False)
+
+
+def load_bnn(model: nn.Module, load_path: str, device=None, allow_pickle: bool = False, class_kwargs: dict | None = None,
+             **ctor_kwargs) -> nn.Module:
     """Read a directory written by the reference's save_bnn (utils.py:87-94) the way its load_bnn does (utils.py:97-124): every
     nn.Linear named in meta.json is replaced by the class of that name from pb_llm_amd.quant, built from the stored fp16 weight
     and bias -- here the MI355X-backed class, on `device` (default: the replaced module's).  The reference calls
     `Class(weight, bias)`; classes that need more (BinaryXnorExceptOutliersLinear: outlier_fraction, which the reference's
-    dead-code loader cannot supply) take it from ctor_kwargs."""
+    dead-code loader cannot supply) take it from ctor_kwargs -- each class only gets the keywords its constructor names -- or
+    from class_kwargs[class name].  A directory this package's save_bnn wrote from PBLinear modules (class "PBLinear": the dense
+    fp16 weight of a packed layer) is re-packed with PBLinear.from_dense, which is exact for any weight."""
+    import inspect
     from . import quant as Q
     with open(os.path.join(load_path, "meta.json")) as f:
         meta = json.load(f)
-    weights = torch.load(os.path.join(load_path, "weights.pth"), weights_only=False)
+    weights = _load_weights_file(os.path.join(load_path, "weights.pth"), allow_pickle)
     modules = dict(model.named_modules())
     for name, module in modules.items():
         if not isinstance(module, nn.Linear) or name not in meta:
@@ -112,7 +134,14 @@ def load_bnn(model: nn.Module, load_path: str, device=None, **ctor_kwargs) -> nn
             raise ValueError(f"{name}: stored weight is {tuple(w.shape)}, the model's Linear is {(module.out_features, module.in_features)}")
         dev = device if device is not None else module.weight.device
         b = b.data if isinstance(b, nn.Parameter) else b
-        new = cls(w.to(dev), None if b is None else b.to(dev), **ctor_kwargs) if ctor_kwargs else cls(w.to(dev), None if b is None else b.to(dev))
+        w = w.data if isinstance(w, nn.Parameter) else w
+        if cls is PBLinear:
+            new = PBLinear.from_dense(w.to(dev), None if b is None else b.to(dev))
+        else:
+            names = set(inspect.signature(cls.__init__).parameters)
+            kw = {k: v for k, v in ctor_kwargs.items() if k in names}
+            kw.update((class_kwargs or {}).get(meta[name], {}))
+            new = cls(w.to(dev), None if b is None else b.to(dev), **kw)
         new.global_name = name.replace(".", "/")
         ind = name.rfind(".")
         father = modules[""] if ind == -1 else modules[name[:ind]]

@@ -1,0 +1,76 @@
+"""CPU tests added in round 4 (no GPU): the reference-layout checkpoint directory round-trips for the packed layer class,
+per-class constructor keywords in load_bnn, the restricted unpickler."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import pb_oracle as O
+from pb_llm_amd import io as pbio, quant as Q, synth
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.fc1 = nn.Linear(256, 128, bias=True)
+        self.blk = nn.Sequential(nn.Linear(128, 64, bias=False))
+
+
+def _pb_layer(N, K, seed, bias):
+    W = synth.llm_weight(N, K, seed=seed)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    b = torch.from_numpy(synth.llm_weight(1, N, seed=seed + 1)[0]).float() if bias else None
+    return Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), b, torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
+
+
+def test_save_bnn_load_bnn_round_trip_for_packed_layers(tmp_path):
+    """save_bnn writes class "PBLinear" + the dense fp16 weight (get_save_weight_dict, quant/quantizer.py:70-72); load_bnn packs
+    it again (exact for any weight) -- round 3's loader called PBLinear(weight, bias) and failed"""
+    net = Net()
+    net.fc1 = _pb_layer(128, 256, 3, True)
+    net.blk[0] = _pb_layer(64, 128, 5, False)
+    meta = pbio.save_bnn(net, str(tmp_path / "ckpt"))
+    assert meta == {"fc1": "PBLinear", "blk.0": "PBLinear"}
+    back = pbio.load_bnn(Net(), str(tmp_path / "ckpt"))
+    for a, b in ((net.fc1, back.fc1), (net.blk[0], back.blk[0])):
+        assert isinstance(b, Q.PBLinear)
+        assert torch.equal(a.weight, b.weight)                 # the dense simulated weights agree bit for bit
+        assert (a.bias is None) == (b.bias is None)
+        if a.bias is not None:
+            assert torch.equal(a.bias, b.bias)
+    assert back.fc1.global_name == "fc1" and back.blk[0].global_name == "blk/0"
+
+
+def test_load_bnn_hands_every_class_only_its_own_keywords(tmp_path):
+    """a directory that mixes classes: outlier_fraction reaches BinaryXnorExceptOutliersLinear only (BinaryLinear's constructor
+    does not take it and used to raise TypeError)"""
+    w1 = torch.from_numpy(synth.llm_weight(128, 256, seed=7)).half()
+    w2 = torch.from_numpy(synth.llm_weight(64, 128, seed=8)).half()
+    os.makedirs(tmp_path / "mix")
+    with open(tmp_path / "mix" / "meta.json", "w") as f:
+        json.dump({"fc1": "BinaryXnorExceptOutliersLinear", "blk.0": "BinaryLinear"}, f)
+    torch.save({"fc1_weight": w1, "fc1_bias": nn.Parameter(torch.zeros(128)), "blk.0_weight": w2, "blk.0_bias": None},
+               str(tmp_path / "mix" / "weights.pth"))
+    net = pbio.load_bnn(Net(), str(tmp_path / "mix"), outlier_fraction=0.2)
+    assert isinstance(net.fc1, Q.BinaryXnorExceptOutliersLinear) and net.fc1.outlier_fraction == 0.2
+    assert isinstance(net.blk[0], Q.BinaryLinear)
+    net = pbio.load_bnn(Net(), str(tmp_path / "mix"), class_kwargs={"BinaryXnorExceptOutliersLinear": {"outlier_fraction": 0.1}})
+    assert net.fc1.outlier_fraction == 0.1
+
+
+class _Evil:
+    def __reduce__(self):
+        return (os.system, ("true",))
+
+
+def test_load_bnn_refuses_a_pickle_payload_unless_asked(tmp_path):
+    os.makedirs(tmp_path / "bad")
+    with open(tmp_path / "bad" / "meta.json", "w") as f:
+        json.dump({"fc1": "BinaryLinear"}, f)
+    torch.save({"fc1_weight": torch.zeros(128, 256).half(), "fc1_bias": None, "x": _Evil()}, str(tmp_path / "bad" / "weights.pth"))
+    with pytest.raises(ValueError, match="restricted unpickler"):
+        pbio.load_bnn(Net(), str(tmp_path / "bad"))
