@@ -175,8 +175,13 @@ def native_linear():
         if os.environ.get("PBL_NATIVE", "1") != "0" and os.path.exists(NATIVE_PATH) and not os.environ.get("PBL_LIB"):
             import torch
             lib()                                    # libpbl.so first: the dispatcher links against it
-            torch.ops.load_library(NATIVE_PATH)
-            _native = torch.ops.pbllm_native.linear
+            try:
+                torch.ops.load_library(NATIVE_PATH)
+                _native = torch.ops.pbllm_native.linear
+            except (OSError, RuntimeError, AttributeError) as e:   # stale / ABI-incompatible build (torch upgrade, missing libtorch_hip)
+                import warnings
+                warnings.warn(f"pb_llm_amd: native dispatcher {NATIVE_PATH} did not load ({e}); using the ctypes path "
+                              "(same kernels, ~6 us more host time per call).  Rebuild with __graft_entry__.build(force=True)")
     return _native or None
 
 

@@ -18,12 +18,14 @@ so every shard is an ordinary PBLinear and uses the same kernel.
 """
 from __future__ import annotations
 
+import ctypes as C
+import itertools
+import weakref
+
 import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn as nn
-
-import ctypes as C
 
 from . import _lib
 from .quant import PBLinear, pb_linear_forward
@@ -95,7 +97,8 @@ class P2PAllReduce:
     2 * world * max_numel floats per rank (the slots are strided by the world size), allocated at the first all-reduce with
     the largest message any layer registered -- a 7B model with 64 K-split layers used to allocate 64 buffers of 33 MB."""
 
-    _shared: dict = {}
+    _shared: dict = {}          # (device index, serial) -> (weakref to the process group | None for the default group, communicator)
+    _serial = itertools.count()
 
     def __init__(self, max_numel: int, device, group=None, lazy: bool = False):
         self.group, self.device = group, torch.device(device)
@@ -110,17 +113,25 @@ class P2PAllReduce:
     @classmethod
     def shared(cls, device, group=None, max_numel: int = 0) -> "P2PAllReduce":
         """the communicator of (device, group), created on first use; max_numel only ever grows until the first all-reduce"""
-        key = (torch.device(device).index, id(group))
-        c = cls._shared.get(key)
-        if c is None:
-            c = cls._shared[key] = cls(max_numel, device, group, lazy=True)
-        c.reserve(max_numel)
+        # keyed on the group OBJECT (held weakly): an id() can be recycled after a group is garbage collected and would then
+        # hand a communicator mapped for other ranks to a new group
+        dev_index = torch.device(device).index
+        for k, (gref, c) in list(cls._shared.items()):
+            g = gref() if gref is not None else None
+            if gref is not None and g is None:
+                del cls._shared[k]                      # the group is gone: its communicator can never be asked for again
+                continue
+            if k[0] == dev_index and g is group:
+                c.reserve(max_numel)
+                return c
+        c = cls(max_numel, device, group, lazy=True)
+        cls._shared[(dev_index, next(cls._serial))] = (weakref.ref(group) if group is not None else None, c)
         return c
 
     def reserve(self, numel: int):
-        if numel > self.max_numel:
-            if self._own is not None:
-                raise _lib.PblError(f"P2PAllReduce is already allocated for {self.max_numel} elements; {numel} requested")
+        """grow the capacity while the buffers are not allocated yet; afterwards the capacity is frozen and larger messages
+        take the caller's RCCL path (PBLinearKSplit.forward checks max_numel) -- a layer built after warm-up must not fail"""
+        if numel > self.max_numel and self._own is None:
             self.max_numel = int(numel)
 
     def _allocate(self):
@@ -184,7 +195,7 @@ class P2PAllReduce:
             L.pbl_comm_free(self._own)
             self._own, self._opened = None, []
         for k, v in list(P2PAllReduce._shared.items()):
-            if v is self:
+            if v[1] is self:
                 del P2PAllReduce._shared[k]
 
 
@@ -226,6 +237,9 @@ class PBLinearKSplit(nn.Module):
         if collective not in ("rccl", "p2p"):
             raise ValueError("collective must be 'rccl' or 'p2p'")
         self.comm, self.max_tokens = None, max_tokens
+        # a timed-out peer wait poisons the output with NaN and sets the communicator's status word; the word is polled
+        # (synchronously) every `check_every` eager forwards, so a dead peer surfaces as an exception, not only as NaN logits
+        self.check_every, self._calls = 256, 0
         if collective == "p2p":
             # ONE communicator per (device, group) for all K-split layers, sized to the largest message
             self.comm = P2PAllReduce.shared(shard.pbl_blob.device, group, max_tokens * shard.out_features)
@@ -238,6 +252,9 @@ class PBLinearKSplit(nn.Module):
         xl = x if self.input_is_sharded else x[..., self.cols[0]:self.cols[1]]
         y = self.local_forward(xl)               # fp32, contiguous: the kernels' own output
         if self.comm is not None and y.numel() <= self.comm.max_numel:
+            self._calls += 1
+            if self.check_every and self._calls % self.check_every == 0 and not torch.cuda.is_current_stream_capturing():
+                self.comm.check()
             if x.dtype == torch.float16:         # the all-reduce kernel writes the fp16 result itself: no cast launch
                 out = torch.empty(y.shape, dtype=torch.float16, device=y.device)
                 self.comm.all_reduce_(y, out)

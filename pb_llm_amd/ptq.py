@@ -45,6 +45,9 @@ def gptq_blocks_(W: torch.Tensor, U: torch.Tensor, low_mask: torch.Tensor, hscal
     return losses
 
 
+CHOL_DTYPE = torch.float64      # precision of the H -> chol -> inverse -> chol(upper) chain in fasterquant (see there)
+
+
 class LowHighGPTQ:
     """LowHighGPT(layer, low_quantizer("xnor", groupsize), high_quantizer(bits, perchannel, asym), salient_metric,
     disable_gptq) -- gptq_pb/gptq.py:15-33, with the two quantizers folded in."""
@@ -105,9 +108,15 @@ class LowHighGPTQ:
         damp = percdamp * torch.mean(torch.diag(H))                                    # :74-81
         idx = torch.arange(K, device=self.dev)
         H[idx, idx] += damp
+        # The reference runs this chain in fp32 on the CPU (LAPACK); an fp32 chain on the GPU (rocSOLVER, other blocking and
+        # summation order) lands ~1e-4 away from it, which moves hessian-metric masks and GPTQ roundings near their
+        # thresholds.  In fp64, rounded ONCE to fp32, the factor is within a few fp32 ulp of the true one -- and so is the
+        # reference's (measured on golden G5: 2.8e-7 of max|U| between its stored U and the fp64 chain) -- so that is what
+        # pins this step (CHOL_DTYPE = torch.float32 restores the single-precision chain).
+        H = H.to(CHOL_DTYPE)
         H = torch.linalg.cholesky(H)
         H = torch.cholesky_inverse(H)
-        U = torch.linalg.cholesky(H, upper=True).contiguous()
+        U = torch.linalg.cholesky(H, upper=True).to(torch.float32).contiguous()
         mask = torch.zeros_like(W, dtype=torch.bool)
         mean = torch.zeros(self.n_groups, N, 1, device=self.dev)
         scale = torch.zeros(self.n_groups, N, 1, device=self.dev)

@@ -52,14 +52,16 @@ GEMM_THRESHOLD = 12
 #              same shapes (round 2: 120 / 344 / 327), forward 57 ms.  Use it where the dense copy must not exist.
 # fp32 / bf16 activations, an fp32 dense dtype, odd group sizes and K % 8 != 0 always take the library path.
 GEMM_BACKEND = os.environ.get("PBL_GEMM_BACKEND", "library")
-# bf16 activations at <= 32 rows run as ONE fp16 pass (bf16 -> fp16 is exact inside fp16's range); values beyond +-65504 are
-# saturated and NaN / inf do not survive the clamp.  True: check the range first (one device -> host sync per call, ~10 us) and
-# send such inputs through the dense path instead, so that overflow propagates exactly as in the reference's bf16 F.linear.
+# bf16 activations at <= 32 rows run as ONE fp16 pass (bf16 -> fp16 is exact inside fp16's range).  BF16_RANGE_CHECK (default
+# since round 4): check the range first (one device -> host sync per call, ~10 us) and send out-of-range / non-finite inputs
+# through the dense path, so that large values and inf / NaN behave exactly as in the reference's bf16 F.linear at every token
+# count; off (or under stream capture): per-token power-of-two scaling on the device, exact for all finite inputs (see
+# _pb_linear_forward).
 # fused backend: keep each layer's salient list (pbl_gemm_prepare, 4 B per salient entry -- a fifth of the dense weight at 5 %
 # salients, 2.6 GB for a 7B model at 10 %) next to its blob instead of rebuilding it on every call: the perplexity loops call the
 # same linears batch after batch (gptq_pb/eval_ppl_utils.py:55-64).  4096^2 x 2048: 81 us instead of 90 (profiles/r03_gemm.md).
 GEMM_KEEP_LIST = os.environ.get("PBL_GEMM_KEEP_LIST", "0") == "1"
-BF16_RANGE_CHECK = os.environ.get("PBL_BF16_RANGE_CHECK", "0") == "1"
+BF16_RANGE_CHECK = os.environ.get("PBL_BF16_RANGE_CHECK", "1") == "1"
 
 
 def fused_gemm_ok(packed: PackedWeight) -> bool:
@@ -239,18 +241,34 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         run(layer, xc, y, M, out_f32)
         return y.reshape(*lead, packed.N)
     if x.dtype == torch.bfloat16:
-        # bf16 -> fp16 is exact (8 significand bits into 11) inside fp16's range: ONE pass, fp32 accumulation, bf16 result.
-        # Out-of-range values are saturated to +-65504 (the two-term split below cannot represent them either); magnitudes
-        # below 2^-24 round to fp16 subnormals (absolute error < 3e-8).
-        if BF16_RANGE_CHECK and not bool((x2.abs() <= 65504.0).all()):       # (NaN compares false: caught as well)
-            # out-of-range / non-finite bf16 activations: the dense path, which computes in the activation's own range like
-            # the reference's bf16 F.linear -- the same result whatever the token count (the GEMM regime never clamps)
-            W = unpack_on_device(packed, torch.float32)
+        # bf16 -> fp16 is exact (8 significand bits into 11) inside fp16's range: ONE pass, fp32 accumulation, bf16 result;
+        # magnitudes below 2^-24 round to fp16 subnormals (absolute error < 3e-8).  Outside fp16's range the reference's bf16
+        # F.linear keeps computing (finite values up to 3.4e38) and propagates inf / NaN, and the GEMM regime (33 rows and more)
+        # does the same, so the packed path must not silently saturate:
+        #  * BF16_RANGE_CHECK (default; one device -> host sync per call, ~10 us; impossible under stream capture): inputs with
+        #    an out-of-range or non-finite value take the dense path -- the reference's result whatever the token count;
+        #  * otherwise (PBL_BF16_RANGE_CHECK=0, or while a hipGraph is being captured): every token is scaled by a power of two
+        #    chosen ON THE DEVICE so that its largest magnitude fits fp16 (exact; what falls below fp16's subnormals after the
+        #    scaling is more than 2^-39 below the token's maximum -- under the fp32 accumulation's own resolution) and the result
+        #    is scaled back: all FINITE bf16 inputs are exact; a token holding inf / NaN yields NaN in its whole output row,
+        #    where the reference distinguishes +-inf from NaN by the weights' signs (documented deviation of the sync-free mode).
+        if BF16_RANGE_CHECK and not torch.cuda.is_current_stream_capturing() and not bool((x2.abs() <= 65504.0).all()):
+            W = unpack_on_device(packed, torch.float32)                       # (NaN compares false: caught as well)
             y = torch.nn.functional.linear(x2.float(), W, bias_f32)
             return (y if out_f32 else y.to(x.dtype)).reshape(*lead, packed.N)
-        xc = x2.float().clamp_(-65504.0, 65504.0).half().contiguous()
+        xf = x2.float()
+        amax = xf.abs().amax(dim=1, keepdim=True)
+        # 2^-e with e = max(0, exponent(amax) - 14): frexp-free, from the fp32 bit pattern (inf / NaN -> exponent 255 -> the
+        # row becomes NaN below)
+        e = ((amax.view(torch.int32) >> 23) & 0xFF) - 127 - 14
+        sc = torch.ldexp(torch.ones_like(amax), -e.clamp_(min=0))
+        xc = (xf * sc).half().contiguous()
         y = torch.empty(M, packed.N, dtype=torch.float32, device=x.device)
-        run(layer, xc, y, M, True)
+        run(packed.layer_struct(None), xc, y, M, True)
+        y = y / sc                                                              # exact (power of two); inf rows: 0 * inf = NaN
+        y = torch.where(torch.isfinite(amax), y, torch.full_like(y, float("nan")))
+        if bias_f32 is not None:
+            y = y + bias_f32
         return (y if out_f32 else y.to(x.dtype)).reshape(*lead, packed.N)
     # fp32 activations: x = x_hi + x_lo with both terms fp16; the kernel is
     # linear in x, so y = W x_hi + W x_lo accumulated in fp32 (bias added once).
@@ -327,30 +345,34 @@ class PBLinear(nn.Module, BinaryInterface):
         """From the PTQ quantizer state (LowQuantizer.mean/scale [G,N,1],
         HighQuantizer.scale/zero [N,1]) and the ORIGINAL weights: composes
         q = q_high*~mask + q_low*mask (gptq.py:119-127) and packs it."""
-        Wf = W.detach().cpu().float()
+        dev = W.device
+        Wf = W.detach().float()
         N, K = Wf.shape
         gs = K if groupsize == -1 else groupsize
         G = (K + gs - 1) // gs
-        mean = torch.as_tensor(mean).float().reshape(G, N, 1)
-        scale = torch.as_tensor(scale).float().reshape(G, N, 1)
-        hs = torch.as_tensor(hscale).float().reshape(N, 1)
-        hz = torch.as_tensor(hzero).float().reshape(N, 1)
-        lm = low_mask.cpu().bool()
-        out = torch.empty_like(Wf)
-        hi = torch.empty(N, G)
-        lo = torch.empty(N, G)
-        for g in range(G):
-            sl = slice(g * gs, min((g + 1) * gs, K))
-            w = Wf[:, sl]
-            q_high = hs * (torch.clamp(torch.round(w / hs) + hz, 0, maxq) - hz)
-            q_low = torch.sign(w - mean[g]) * scale[g] + mean[g]
-            out[:, sl] = q_high * ~lm[:, sl] + q_low * lm[:, sl]
-            hi[:, g] = (scale[g] + mean[g]).reshape(-1)
-            lo[:, g] = (-scale[g] + mean[g]).reshape(-1)
+        t = lambda v: torch.as_tensor(v, device=dev).float()          # noqa: E731
+        mean = t(mean).reshape(G, N).t().contiguous()                  # [N, G]
+        scale = t(scale).reshape(G, N).t().contiguous()
+        hs, hz = t(hscale).reshape(N, 1), t(hzero).reshape(N, 1)
+        lm = torch.as_tensor(low_mask, device=dev).bool()
+        # per-column views of the per-(row, group) levels; whole-matrix tensor ops on W's device (round 3 looped over the
+        # groups on the host)
+        meanc = mean.repeat_interleave(gs, dim=1)[:, :K]
+        scalec = scale.repeat_interleave(gs, dim=1)[:, :K]
+        # w / scale must be the IEEE fp32 quotient (the integer codes depend on it): torch's GPU division is not correctly
+        # rounded, the fp64 quotient rounded to fp32 is (53 >= 2 * 24 + 2 bits: the double rounding is innocuous)
+        quot = (Wf.double() / hs.double()).float() if dev.type == "cuda" else Wf / hs
+        q_high = hs * (torch.clamp(torch.round(quot) + hz, 0, maxq) - hz)
+        q_low = torch.sign(Wf - meanc) * scalec + meanc
+        out = q_high * ~lm + q_low * lm                               # gptq.py:126,155 (the reference's composition, as written)
+        hi, lo = scale + mean, -scale + mean
         if dtype == torch.float16:  # the reference stores the result in the checkpoint dtype
             out, hi, lo = out.half().float(), hi.half().float(), lo.half().float()
-        packed = pack_dense(out.numpy(), hi.numpy(), lo.numpy(), hs.reshape(-1).numpy(), hz.reshape(-1).numpy(),
-                            (~lm).numpy().astype(np.uint8), sal_f16=dtype == torch.float16)
+        if dev.type == "cuda":
+            packed = pack_dense_dev(out, hi, lo, hs.reshape(-1), hz.reshape(-1), ~lm, sal_f16=dtype == torch.float16)
+        else:
+            packed = pack_dense(out.numpy(), hi.numpy(), lo.numpy(), hs.reshape(-1).numpy(), hz.reshape(-1).numpy(),
+                                (~lm).numpy().astype(np.uint8), sal_f16=dtype == torch.float16)
         return cls(packed, bias, dtype)
 
     # -- nn.Linear surface ----------------------------------------------------------

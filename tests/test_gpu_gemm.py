@@ -180,3 +180,24 @@ def test_kept_salient_list_follows_the_blob():
         assert torch.equal(layer(x), ref) and layer.packed._gemm_list[0] != kept[0]
     finally:
         Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST = old
+
+
+def test_gemm_regime_fully_binarized_layer_in_list_mode():
+    """a layer without ANY salient entry or exception (BinaryLinear / XnorBinaryLinear: max_nch = max_nexc = 0) on more than one
+    token tile: the salient list has no words, and its capacity must still be a valid region for the producers' clamped,
+    unconditional requests (round 3 computed cap - 1 = 0xFFFFFFFF and read past the workspace)"""
+    N, K, M = 256, 1024, 600
+    rng = np.random.default_rng(5)
+    a = np.abs(synth.llm_weight(N, 1, seed=9)[:, 0]).astype(np.float32) + 0.01
+    a = a.astype(np.float16).astype(np.float32)
+    Wd = np.where(rng.random((N, K)) < 0.5, a[:, None], -a[:, None]).astype(np.float32)
+    p = pack_dense(Wd, a, -a, np.ones(N, np.float32), np.zeros(N, np.float32), None, sal_f16=True)
+    assert p.nnz == 0 and p.nexc == 0 and p.max_nch == 0 and Q.fused_gemm_ok(p)
+    pd = p.to(DEV)
+    x = synth.activations((M, K), 11, 21)
+    y = Q.fused_gemm_forward(pd, None, T(x))
+    assert_parity(y, O.dense_linear(x, Wd))
+    lst = Q.gemm_list(pd)
+    assert lst is not None and lst.numel() > 0
+    assert torch.equal(y, Q.fused_gemm_forward(pd, None, T(x), prepared=lst))
+    assert torch.equal(y, Q.fused_gemm_forward(pd, None, T(x), workspace=False))

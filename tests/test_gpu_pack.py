@@ -122,3 +122,23 @@ def test_from_dense_on_the_gpu_is_byte_identical_to_the_host_route(N, K, lf, f16
         h2 = Q.PBLinear.from_dense(Wt, None, lm, gs, r["hscale"], r["hzero"])
         d2 = Q.PBLinear.from_dense(Wt.to(DEV), None, lm.to(DEV), gs, r["hscale"], r["hzero"])
         assert np.array_equal(h2.pbl_blob.numpy(), d2.pbl_blob.cpu().numpy())
+
+
+@pytest.mark.parametrize("gs,f16", [(-1, True), (128, True), (-1, False)])
+def test_from_quantizers_on_the_gpu_is_byte_identical_to_the_host_route(gs, f16):
+    """PBLinear.from_quantizers (the PTQ API INTEGRATION.md shows) with GPU tensors: the composition q_high * ~mask + q_low * mask
+    (gptq_pb/gptq.py:119-127) and the packing both run on the device (round 3: .cpu(), a Python loop over the groups, the host
+    packer) and give the host route's blob byte for byte"""
+    N, K = 192, 1024
+    W = synth.llm_weight(N, K, seed=77, heavy_tail=True)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, gs)
+    r = O.ptq_rtn(W, mask, 8, gs)
+    G = 1 if gs == -1 else K // gs
+    mean, scale = r["mean"].reshape(G, N, 1), r["scale"].reshape(G, N, 1)
+    dt = torch.float16 if f16 else torch.float32
+    host = Q.PBLinear.from_quantizers(torch.from_numpy(W), torch.from_numpy(mask), mean, scale, r["hscale"], r["hzero"], groupsize=gs, dtype=dt)
+    dev = Q.PBLinear.from_quantizers(T(W), T(mask), T(mean), T(scale), T(r["hscale"]), T(r["hzero"]), groupsize=gs, dtype=dt)
+    assert dev.pbl_blob.is_cuda and not host.pbl_blob.is_cuda
+    assert np.array_equal(host.pbl_blob.numpy(), dev.pbl_blob.cpu().numpy())
+    ref = r["W_fq"].astype(np.float16).astype(np.float32) if f16 else r["W_fq"]
+    assert np.array_equal(dev.weight.float().cpu().numpy(), ref)

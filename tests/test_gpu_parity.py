@@ -521,27 +521,50 @@ def test_torch_compile_traces_pbllm_linear_op(llama7b_qproj):
     assert torch.equal(out, eager) and torch.equal(out2, eager)
 
 
-def test_bf16_activations_out_of_fp16_range_with_the_range_check():
-    """bf16 activations beyond +-65504 (or non-finite): the one-pass fp16 route saturates them; with quant.BF16_RANGE_CHECK the
-    call is routed through the dense path and matches the float64 oracle on the true bf16 values, and NaN propagates."""
+def test_bf16_activations_out_of_fp16_range():
+    """bf16 activations beyond +-65504 or non-finite at 1, 32 and 33 rows (packed kernels / GEMM regime): with the range check
+    (the default) the result is the reference's bf16 F.linear -- large finite values computed in range, inf giving +-inf or
+    NaN by the weights' signs, NaN poisoning its row -- at every token count; the sync-free mode (PBL_BF16_RANGE_CHECK=0,
+    also what runs under stream capture) scales every token by a power of two on the device: all finite inputs exact, a
+    non-finite token gives a NaN row."""
     N, K = 64, 1024
     W = synth.llm_weight(N, K, seed=2)
     mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
     r = O.ptq_rtn(W, mask, 8, -1)
-    layer = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
-    x = torch.from_numpy(synth.activations((2, K), 4, 21)).float().to(DEV)
-    x[0, 7] = 3.0e5
-    xb = x.bfloat16()
-    ref = O.dense_linear(xb.float().cpu().numpy(), torch.from_numpy(r["W_fq"]).half().float().numpy())
+    W16 = torch.from_numpy(r["W_fq"]).half()
+    layer = Q.PBLinear.from_dense(W16, None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
     old = Q.BF16_RANGE_CHECK
     try:
-        Q.BF16_RANGE_CHECK = False
-        sat = layer(xb).float().cpu().numpy()
-        assert O.parity_errors(sat[1:], ref[1:])[0] < 1e-2 and O.parity_errors(sat[:1], ref[:1])[0] > 0.05     # row 0 saturated
-        Q.BF16_RANGE_CHECK = True
-        assert O.parity_errors(layer(xb).float().cpu().numpy(), ref)[0] < 1e-2
-        xb[1, 3] = float("nan")
-        y = layer(xb)
-        assert torch.isnan(y[1]).all() and not torch.isnan(y[0]).any()
+        for M in (1, 2, 32, 33):
+            x = torch.from_numpy(synth.activations((M, K), 4 + M, 21)).float().to(DEV)
+            x[0, 7] = 3.0e5
+            if M > 1:
+                x[1, 100] = -2.0e30
+            xb = x.bfloat16()
+            ref = O.dense_linear(xb.float().cpu().numpy(), W16.float().numpy())
+            for chk in (True, False):
+                Q.BF16_RANGE_CHECK = chk
+                y = layer(xb)
+                assert y.dtype == torch.bfloat16
+                for t in range(M):       # per token: the scales differ by 25 orders of magnitude
+                    assert O.parity_errors(y[t:t + 1].float().cpu().numpy(), ref[t:t + 1])[0] < 1e-2, (M, chk, t)
+            # non-finite inputs
+            xi = xb.clone()
+            xi[0, 3] = float("inf")
+            if M > 1:
+                xi[1, 5] = float("nan")
+            want = torch.nn.functional.linear(xi.float(), W16.float().to(DEV)).bfloat16()       # the reference's arithmetic
+            Q.BF16_RANGE_CHECK = True
+            y = layer(xi)
+            assert torch.equal(torch.isnan(y), torch.isnan(want)) and torch.equal(torch.isposinf(y), torch.isposinf(want))
+            assert torch.equal(torch.isneginf(y), torch.isneginf(want))
+            assert torch.isinf(y[0]).any()                                   # the inf did propagate as inf
+            Q.BF16_RANGE_CHECK = False
+            y = layer(xi)
+            fin = torch.isfinite(xi.float()).all(dim=1)
+            if M <= 32:                                                       # sync-free packed path: NaN rows
+                assert torch.isnan(y[~fin]).all() and torch.isfinite(y[fin]).all()
+            else:                                                             # the GEMM regime never clamps
+                assert torch.equal(torch.isnan(y), torch.isnan(want))
     finally:
         Q.BF16_RANGE_CHECK = old

@@ -112,7 +112,7 @@ def test_g5_rtn_branch_on_gpu(metric, gs, lf):
     layer, q, _ = run_layer(W16, Xcal, lf, metric, gs, True)
     gm = np.unpackbits(g["mask"])[:768 * 768].astype(bool).reshape(768, 768)
     mism = np.count_nonzero(q.mask.cpu().numpy() != gm)
-    assert mism == 0 if metric == "magnitude" else mism <= 64          # hessian: LAPACK-level rounding near the threshold
+    assert mism == 0                                                    # (round 3 allowed 64 for the hessian metric: fp32 chain)
     np.testing.assert_array_equal(q.hscale.cpu().numpy().reshape(-1), g["hscale"].reshape(-1))
     np.testing.assert_array_equal(q.hzero.cpu().numpy().reshape(-1), g["hzero"].reshape(-1))
     if metric == "magnitude":
@@ -121,7 +121,7 @@ def test_g5_rtn_branch_on_gpu(metric, gs, lf):
         assert layer.weight.dtype == torch.float16
         assert np.count_nonzero(layer.weight.data.cpu().numpy() != g["W_fq"]) <= 8
     else:
-        assert np.mean(layer.weight.data.cpu().numpy() == g["W_fq"]) > 0.99
+        assert np.mean(layer.weight.data.cpu().numpy() == g["W_fq"]) >= 0.999
 
 
 @pytest.mark.parametrize("metric,gs", [("magnitude", -1), ("hessian", 128), ("magnitude", 128)])
@@ -130,12 +130,18 @@ def test_g5_gptq_loop_on_gpu(metric, gs):
     g = golden(g5_name(metric, gs, False, 0.9))
     layer, q, info = run_layer(W16, Xcal, 0.9, metric, gs, False)
     gm = np.unpackbits(g["mask"])[:768 * 768].astype(bool).reshape(768, 768)
-    assert np.count_nonzero(q.mask.cpu().numpy() != gm) <= 64
-    assert abs(info["error"] - float(g["loss"])) / float(g["loss"]) < 2e-2
-    np.testing.assert_allclose(q.hinv_diag.cpu().numpy(), g["hinv_diag"], rtol=2e-4)
+    # Round 4: the Cholesky chain runs in fp64 on the GPU and is rounded once (ptq.CHOL_DTYPE): its diagonal is within 2e-6
+    # of the reference's stored fp32 LAPACK factor (measured 3.6e-7, gpurun_out/r44/chol.txt; the reference's own factor is
+    # 2.8e-7 of max|U| away from the fp64 chain), which pins the whole layer: masks EXACT for both metrics, >= 99.9 % of the
+    # fp16 weights identical (measured 99.94 - 100 %; the rest are roundings at a grid boundary after block-wise fp32 GEMM
+    # updates whose summation order no library pins), loss to 1e-4 (measured <= 1e-5).  Round 3 allowed 64 mask entries,
+    # 3 % of the weights and 2 % of the loss.
+    assert np.count_nonzero(q.mask.cpu().numpy() != gm) == 0
+    assert abs(info["error"] - float(g["loss"])) / float(g["loss"]) < 1e-4
+    np.testing.assert_allclose(q.hinv_diag.cpu().numpy(), g["hinv_diag"], rtol=2e-6)
     np.testing.assert_allclose(q.scale.cpu().numpy(), g["scale"], rtol=1e-4)
     Wq = layer.weight.data.cpu().numpy()
-    assert np.mean(Wq == g["W_fq"]) > 0.97
+    assert np.mean(Wq == g["W_fq"]) >= 0.999
     # the quantised layer lowers the layer-output error on the calibration inputs relative to round-to-nearest
     Xc = Xcal.reshape(-1, 768).astype(np.float64)
     ref = Xc @ W16.astype(np.float64).T
@@ -198,3 +204,22 @@ def test_quant_sequential_tiny_llama_on_gpu():
         a = torch.cat([m_pack(i.to(DEV)).logits.float() for i in ids]).cpu().numpy()
         b = torch.cat([m_gptq(i.to(DEV)).logits.float() for i in ids]).cpu().numpy()
     assert O.parity_errors(a, b.astype(np.float64))[0] < 5e-3
+
+
+def test_cholesky_chain_on_the_gpu_against_the_references_stored_factor():
+    """H -> chol -> cholesky_inverse -> chol(upper) (gptq_pb/gptq.py:74-81) in fp64 on the GPU, rounded once, against the FULL
+    upper factor U the reference computed (golden G5, fp32 CPU LAPACK): within 2e-6 of max|U| everywhere (the reference's own
+    factor sits 2.8e-7 from the fp64 chain), i.e. a few fp32 ulp -- the bound the whole-layer test above rests on"""
+    W16, Xcal, _, _ = g5_inputs()
+    g = golden(g5_name("hessian", -1, False, 0.9))
+    layer = nn.Linear(768, 768, bias=False).to(DEV)
+    q = ptq.LowHighGPTQ(layer, salient_metric="hessian", groupsize=-1, high_bit=8)
+    for s in range(Xcal.shape[0]):
+        q.add_batch(T(Xcal[s:s + 1]), None)
+    H = q.H.clone()
+    idx = torch.arange(768, device=DEV)
+    H[idx, idx] += 0.01 * torch.mean(torch.diag(H))
+    U = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H.double())), upper=True).float().cpu().numpy()
+    Uref = g["U"].astype(np.float32)
+    assert np.abs(U - Uref).max() <= 2e-6 * np.abs(Uref).max()
+    assert ptq.CHOL_DTYPE == torch.float64

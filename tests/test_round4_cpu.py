@@ -74,3 +74,18 @@ def test_load_bnn_refuses_a_pickle_payload_unless_asked(tmp_path):
     torch.save({"fc1_weight": torch.zeros(128, 256).half(), "fc1_bias": None, "x": _Evil()}, str(tmp_path / "bad" / "weights.pth"))
     with pytest.raises(ValueError, match="restricted unpickler"):
         pbio.load_bnn(Net(), str(tmp_path / "bad"))
+
+
+@pytest.mark.parametrize("gs", [-1, 128])
+def test_from_quantizers_vectorised_host_path_against_the_reference_goldens(gs):
+    """PBLinear.from_quantizers composes q_high * ~mask + q_low * mask (gptq_pb/gptq.py:119-127) from the quantizer state with
+    whole-matrix tensor ops (round 3 looped over the column groups on the host): RTN goldens G5, with and without groups"""
+    from conftest import golden
+    from test_oracle_golden import g5_inputs, g5_name
+    W16, _, _, _ = g5_inputs()
+    g = golden(g5_name("magnitude", gs, True, 0.9))
+    mask = np.unpackbits(g["mask"])[:768 * 768].astype(bool).reshape(768, 768)
+    a = Q.PBLinear.from_quantizers(torch.from_numpy(W16), torch.from_numpy(mask), g["mean"], g["scale"], g["hscale"], g["hzero"],
+                                   groupsize=gs, dtype=torch.float16)
+    assert a.packed.G == (1 if gs == -1 else 6)
+    assert np.count_nonzero(a.weight.numpy() != g["W_fq"]) <= 8

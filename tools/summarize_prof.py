@@ -27,6 +27,33 @@ def kernel_stats(d):
     return out
 
 
+def window_stats(d, want, window):
+    """The dominant kernel's dispatches split in time: the last `window` dispatches of the process (= bench.py's W warm-up + K
+    timed steps, which run after the pre-heat loop's final synchronize) against everything before (the pre-heat phase), so
+    that the average the profile reports and the bench line's ms_per_step describe the SAME launches."""
+    out = []
+    for db in dbs(d):
+        cur = sqlite3.connect(db).cursor()
+        try:
+            rows = list(cur.execute("select start, duration from kernels where name like ? order by start", (f"%{want}%",)))
+        except sqlite3.Error:
+            try:
+                rows = list(cur.execute("select start_timestamp, duration from kernels where name like ? order by start_timestamp", (f"%{want}%",)))
+            except sqlite3.Error:
+                continue
+        if len(rows) <= window:
+            continue
+        durs = [r[1] for r in rows]
+        pre, win = durs[:-window], durs[-window:]
+        late = pre[len(pre) // 2:]
+        med = lambda v: sorted(v)[len(v) // 2]       # noqa: E731
+        out.append(dict(kernel=want, dispatches=len(durs), window=window,
+                        timed_window_avg_us=round(sum(win) / len(win) / 1e3, 2), timed_window_med_us=round(med(win) / 1e3, 2),
+                        preheat_avg_us=round(sum(pre) / len(pre) / 1e3, 2),
+                        preheat_second_half_avg_us=round(sum(late) / len(late) / 1e3, 2), preheat_second_half_med_us=round(med(late) / 1e3, 2)))
+    return out
+
+
 def pmc_stats(d, want="pbl_gemv"):
     res = {}
     for db in dbs(d):
@@ -56,6 +83,11 @@ def main():
         print("\n## kernel trace, un-instrumented timing (durations in us)")
         for s in kernel_stats(tr)[:6]:
             print(json.dumps(s))
+        window = int(os.environ.get("PBL_PROF_WINDOW", "0"))     # W + K of the profiled command (tools/profile.sh exports it)
+        if window:
+            print("\n## the same trace split in time: last W + K dispatches (the timed region) vs the pre-heat loop")
+            for s in window_stats(tr, "pbl_gemv", window):
+                print(json.dumps(s))
     for sub in sorted(os.listdir(root)):
         p = os.path.join(root, sub)
         if not os.path.isdir(p):
