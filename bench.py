@@ -195,9 +195,12 @@ def run_side_workload(a):
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
     dev_s = e0.elapsed_time(e1) * 1e-3 / a.steps
+    n_img = sum(1 for l in layers if getattr(l.packed, "_gemm_image", (None, None))[1] is not None)
     if a.workload == "cfg3":
         roof = {"bound": "mfma", "achieved": flops / dev_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "traffic": None,
-                "kernel": "pbl_gemm_kernel" if a.gemm_backend == "fused" else "pbl_unpack_kernel + library GEMM",
+                "kernel": ("pbl_unpack_kernel + library GEMM" if a.gemm_backend == "library" else
+                           f"pbl_gemm_img_kernel ({n_img} of {len(layers)} layers have a GEMM image; the rest: " +
+                           ("pbl_gemm_kernel)" if a.gemm_backend == "fused" else "pbl_unpack_kernel + library GEMM)")),
                 "us_per_step": 1e6 * dev_s}
         value, unit = M / (32 * wall / a.steps), "tokens/s (linears of a 32-layer stack)"
         work = "llama-7b decoder-layer linears (q,k,v,o 4096x4096; gate,up 11008x4096; down 4096x11008), low_frac 0.95 hessian, M=2048"
@@ -244,7 +247,9 @@ def main():
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
                     help="cfg2 = BASELINE configs[1], the headline GEMV stream (default, what the driver runs); cfg3 / cfg4: "
                          "configs[2] / configs[3] as side lines (see run_side_workload)")
-    ap.add_argument("--gemm-backend", choices=["library", "fused"], default="library")
+    ap.add_argument("--gemm-backend", choices=["auto", "library", "fused"], default="auto",
+                    help="cfg3: quant.GEMM_BACKEND -- auto (default): the hand-written kernel over each layer's GEMM image "
+                         "(pbl_gemm_f16_image), library for layers without one; library: pbl_unpack_dev + library GEMM")
     a = ap.parse_args()
     if a.workload != "cfg2":
         assert a.gpus == 1, "side workloads are single-GPU lines"

@@ -1,0 +1,730 @@
+// pbl_gemm_img.hip -- GEMM regime (prefill: more than 32 rows of x) over a per-layer GEMM IMAGE of the packed weight.
+// Replaces F.linear(x, W_fq, b) over the dense fp16 fake-quant weight (gptq_pb/eval_ppl_utils.py:55-64, evaluate.py:126-145:
+// the reference's perplexity loops call every nn.Linear with 2048 rows) without the dense weight ever existing in HBM.
+//
+// Round 4.  The round-3 kernel (pbl_gemm_big.hip) was measured from inside (tools/trace_gemm.py, profiles/r04_gemm.md): at
+// 4096^2 x 2048 its loop takes 68 us against 36 - 38 us for the bare MFMA stream at the package power cap (1.85 - 2.0 GHz),
+// and BOTH roles need that long -- the eight MFMA waves (fragment reads: +16 us over the bare stream; their own x staging
+// by LDS-DMA: +10 us) and the four expanding waves (~330 instructions per half slab and wave: request addressing, range
+// look-ups, masked stores, branches around every one of them).  What this kernel changes:
+//   * the layer is re-laid ONCE (pbl_gemm_image_build, kept with the layer like round 3's salient list) into fixed-size slots,
+//     one per (16-row record, 128-column half slab): per lane the sign-plane dword and EW - 1 ready-to-store salient words
+//     {LDS offset : fp16 value}, padded with idempotent repeats -- so an expanding wave issues ONE 16-byte load per lane
+//     and record from an address that only moves by a scalar add, and stores every word unconditionally: no ranges, no
+//     clamps, no exec masking, no branches; the row levels are 16 SGPRs read with one scalar load.  ~105 instructions per
+//     record and 64-column step instead of ~165 per record and half slab plus the request bookkeeping.
+//   * four MFMA waves of 128 rows x 64 tokens (eight 32 x 32 accumulator tiles, 6 fragment reads per 8 MFMAs: 192 KB of LDS
+//     reads per half slab instead of 320) that do NOTHING but read fragments and multiply;
+//   * x is staged by the expanding waves (LDS-DMA, 8 KiB each per 64-column step) into a ring shared by the workgroup, one
+//     workgroup barrier per 64-column step; the MFMA waves never issue a vector-memory instruction in the loop.
+// Every weight still enters v_mfma_f32_32x32x16_f16 as the fp16 number a dense fp16 copy of the layer holds, and every
+// accumulator sums its k-steps in the same order as pbl_gemm_big.hip: the two kernels agree bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+#include "../../include/pbl.h"
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define GW 64
+#define GI_NCONS 4
+#define GI_NPROD 4
+#define GI_ROWS 128
+#define GI_TOK 256
+#define GI_HS 128                 // columns per A stage
+#define GI_XC 64                  // columns per step (x slot)
+#define GI_AS_STAGE (GI_ROWS * GI_HS * 2)         // 32768 B
+#define GI_XSLOT (GI_TOK * GI_XC * 2)              // 32768 B
+#define GI_X_OFF (2 * GI_AS_STAGE)
+#define GI_LDS (GI_X_OFF + 3 * GI_XSLOT)           // 163840 B
+#define GI_MAX_NH 127
+#define GI_NVMAX 5                // 16-byte vectors per lane in the largest slot
+#define GI_IMG_MAGIC 0x31494250u                   // "PBI1"
+#define GI_PREP_THREADS 1024
+#ifndef PBL_GEMM_PPRIO
+#define PBL_GEMM_PPRIO 1
+#endif
+// performance-analysis hook (tools/build_variant.sh): bit 0 no expansion in the loop, bit 1 no x staging in the loop, bit 2 no
+// MFMA.  0 in every shipped build (results are wrong otherwise).
+#ifndef PBL_IMG_ABLATE
+#define PBL_IMG_ABLATE 0
+#endif
+
+// timeline probe, as in pbl_gemm_big.hip (tools/trace_gemm.py)
+#ifndef PBL_TRACE
+#define PBL_TRACE 0
+#endif
+#if PBL_TRACE
+static uint64_t* g_img_trace = nullptr;
+extern "C" void pbl_debug_trace_gemm_img(void* p) { g_img_trace = static_cast<uint64_t*>(p); }
+#define TR_STAMP(slot) do { if (tr && lane == 0) { tr[2 * (slot)] = __builtin_amdgcn_s_memrealtime(); tr[2 * (slot) + 1] = __builtin_readcyclecounter(); } } while (0)
+#define TR_T0() const uint64_t tr_t0 = __builtin_readcyclecounter()
+#define TR_ADD(acc) acc += __builtin_readcyclecounter() - tr_t0
+#else
+#define TR_STAMP(slot) do {} while (0)
+#define TR_T0() do {} while (0)
+#define TR_ADD(acc) do {} while (0)
+#endif
+
+namespace {
+
+// image header (64 bytes); the records' slot rows follow at slots_off (record stride = tab.t[NH] * 256 bytes, slot h of a record at
+// (tab.t[h] & 0xFFFF) * 256, [64 lanes][4 nv_h] u32), the level table [NRB][G][16] u32 at levels_off
+struct ImgHeader {
+    uint32_t magic, stride256, NH, NRB, G, K, N, flags;
+    uint64_t slots_off, levels_off, total;
+    uint32_t pad[2];
+};
+static_assert(sizeof(ImgHeader) == 64, "image header is 64 bytes");
+
+// Slot geometry per half-slab COLUMN h (the same for every record): t[h] = offset in the record's slot row (256-byte units) |
+// nv_h << 16, nv_h = 1 .. 5 sixteen-byte vectors per lane = 3, 7, 11, 15 or 19 entry words per lane = up to 192 / 448 / 704 / 960 /
+// 1216 entries;
+// t[NH] = the row's length.  Salient density varies mostly along the columns (the hessian metric concentrates salients in a few
+// input channels, gptq_pb/gptq.py:93-99): sizing every slot for the densest one would triple the image.  Passed by value in the
+// kernel arguments (512 B): a scalar load with a uniform index, tracked by the compiler.
+struct ImgTab { uint32_t t[128]; };
+
+__device__ __forceinline__ _Float16 round_f16_twice(float prod) {
+    asm volatile("" : "+v"(prod));   // keep the fp32 product: an fp16-checkpoint value is double rounded
+    return _Float16(prod);
+}
+__device__ __forceinline__ uint32_t h16(float v) { return uint32_t(__builtin_bit_cast(uint16_t, _Float16(v))); }
+
+// ---- building the image ---------------------------------------------------------------------------------------------------
+// One workgroup per record.  STATS: only count the entries of every (record, half slab) and fold the maximum into *maxn (the
+// caller sizes the slots with it).  Otherwise fill the record's NH slots and its level rows.
+template <bool STATS>
+__global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, uint8_t* __restrict__ img, ImgTab tab, uint32_t* __restrict__ colmax) {
+    extern __shared__ __attribute__((aligned(16))) char smem_p[];
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem_p);            // entries per half slab
+    uint32_t* s_first = s_cnt + (GI_MAX_NH + 1);                       // the first word written to a half slab (padding repeats it)
+    float* s_ss = reinterpret_cast<float*>(s_first + (GI_MAX_NH + 1));
+    float* s_sz = s_ss + 16;
+    pbl_rowinfo* s_ri = reinterpret_cast<pbl_rowinfo*>(s_sz + 16);
+    uint8_t* s_crow = reinterpret_cast<uint8_t*>(s_ri + 16);
+    const uint32_t rb = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int NH = int((L.K + GI_HS - 1) / GI_HS);
+    const uint8_t* blob = static_cast<const uint8_t*>(L.blob);
+    const uint4 info = reinterpret_cast<const uint4*>(blob + sizeof(pbl_blob_header))[rb];
+    const uint8_t* rec = blob + size_t(info.x) * 16;
+    const int nfull = int(info.y), ntail = int(info.z), nexc = int(info.w), nch = nfull + ntail;
+    const uint32_t nchu = uint32_t(nch);
+    const bool has_crow = (L.flags & (PBL_FLAG_HAS_GROUPS | PBL_FLAG_SAL_F16)) != 0;
+    const uint32_t tiles_off = PBL_TILES_OFF(L.G);
+    const uint8_t* sal = rec + tiles_off + L.P * 1024u;
+    const uint16_t* col0p = reinterpret_cast<const uint16_t*>(sal);
+    const u32x4* deltap = reinterpret_cast<const u32x4*>(sal + PBL_SAL_DELTA_OFF(nchu));
+    const uint32_t* codew = reinterpret_cast<const uint32_t*>(sal + PBL_SAL_CODE_OFF(nchu));
+    const uint2* exc = reinterpret_cast<const uint2*>(sal + PBL_SAL_EXC_OFF(nchu, uint32_t(ntail), has_crow));
+    const pbl_rowparams* params = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
+    const float2* ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
+    const uint32_t* tile_dw = reinterpret_cast<const uint32_t*>(rec + tiles_off);
+    const uint32_t stride256 = tab.t[NH];
+    uint8_t* slotrow = STATS ? nullptr : img + sizeof(ImgHeader) + size_t(rb) * stride256 * 256;
+    auto slot_of = [&](uint32_t h) -> uint32_t* { return reinterpret_cast<uint32_t*>(slotrow + size_t(tab.t[h] & 0xFFFFu) * 256); };
+    if (tid < 16) {
+        s_ri[tid] = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF)[tid];
+        s_ss[tid] = params[tid].sscale; s_sz[tid] = params[tid].szero;
+    }
+    for (int h = tid; h <= NH; h += GI_PREP_THREADS) { s_cnt[h] = 0; s_first[h] = 0; }
+    __syncthreads();
+    for (int r = 0; r < 16; ++r) {                           // chunk -> row (rowinfo: full chunks [start, +nfull), tails [tailidx, +ntail))
+        const pbl_rowinfo ri = s_ri[r];
+        for (int k = tid; k < int(ri.nfull) + int(ri.ntail); k += GI_PREP_THREADS)
+            s_crow[k < int(ri.nfull) ? int(ri.start) + k : nfull + int(ri.tailidx) + (k - int(ri.nfull))] = uint8_t(r);
+    }
+    __syncthreads();
+    auto put = [&](uint32_t h, uint32_t j, uint32_t word) {   // entry j of half slab h: lane j & 63, word 1 + (j >> 6)
+        if (j == 0) s_first[h] = word;
+        const uint32_t EW = 4u * (tab.t[h] >> 16);
+        if (j < 64u * (EW - 1u)) slot_of(h)[(j & 63u) * EW + 1u + (j >> 6)] = word;
+    };
+    // a quarter of a chunk per thread
+    for (int u = tid; u < 4 * nch; u += GI_PREP_THREADS) {
+        const int c = u >> 2, sub = u & 3;
+        const u32x4 dv = deltap[c];
+        const uint32_t q = codew[u], cc = col0p[c];
+        const uint32_t row = s_crow[c];
+        uint32_t pre = 0;
+        pre = sub > 0 ? __builtin_amdgcn_sad_u8(dv[0], 0u, pre) : pre;
+        pre = sub > 1 ? __builtin_amdgcn_sad_u8(dv[1], 0u, pre) : pre;
+        pre = sub > 2 ? __builtin_amdgcn_sad_u8(dv[2], 0u, pre) : pre;
+        const uint32_t dd = sub == 0 ? dv[0] : (sub == 1 ? dv[1] : (sub == 2 ? dv[2] : dv[3]));
+        uint32_t off[4];
+        off[0] = 2u * cc + pre + (dd & 0xFFu);               // byte offsets in the fp16 row
+        off[1] = off[0] + ((dd >> 8) & 0xFFu); off[2] = off[1] + ((dd >> 16) & 0xFFu); off[3] = off[2] + (dd >> 24);
+        const float ss = s_ss[row], sz = s_sz[row];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // the padding of a tail chunk repeats its last entry with step 0 (PBL_FLAG_TAIL_REPEAT): not an entry of its own (real
+            // columns rise strictly; only a chunk's FIRST entry may have step 0) -- counting it would size the slots of layers with
+            // many short chunks (hessian salients) for up to 16 x their content
+            if ((4 * sub + e) > 0 && ((dd >> (8 * e)) & 0xFFu) == 0u) continue;
+            const uint32_t h = off[e] >> 8;
+            const uint32_t pos = atomicAdd(&s_cnt[h], 1u);
+            if (!STATS) {
+                const float qf = float((q >> (8 * e)) & 0xFFu);
+                const uint32_t v = uint32_t(__builtin_bit_cast(uint16_t, round_f16_twice(ss * (qf - sz))));
+                put(h, pos, ((row * 256u + ((off[e] & 0xFFu) ^ (row << 4))) << 16) | v);
+            }
+        }
+    }
+    for (int k = tid; k < nexc; k += GI_PREP_THREADS) {
+        const uint2 ex = exc[k];
+        const uint32_t col = ex.x & 0xFFFFu, row = ex.x >> 16, h = col >> 7, o = (2u * col) & 0xFFu;
+        const uint32_t pos = atomicAdd(&s_cnt[h], 1u);
+        if (!STATS) {
+            const uint32_t v = uint32_t(__builtin_bit_cast(uint16_t, _Float16(__builtin_bit_cast(float, ex.y))));
+            put(h, pos, ((row * 256u + (o ^ (row << 4))) << 16) | v);
+        }
+    }
+    __syncthreads();
+    if (STATS) {
+        for (int h = tid; h < NH; h += GI_PREP_THREADS)
+            if (s_cnt[h]) atomicMax(colmax + h, s_cnt[h]);
+        return;
+    }
+    // the plane dword of every (half slab, lane) and the padding: unused words repeat the half slab's first entry (the same
+    // value to the same place: idempotent); a half slab without any entry rewrites position (row 0, column 0) with the value
+    // the plane gives it
+    for (int it = tid; it < NH * 64; it += GI_PREP_THREADS) {
+        const int h = it >> 6, l = it & 63;
+        const uint32_t d = uint32_t(h >> 2) < L.P ? tile_dw[size_t(h >> 2) * 256 + l * 4 + (h & 3)] : 0u;
+        const uint32_t EW = 4u * (tab.t[h] >> 16);
+        uint32_t* sl = slot_of(uint32_t(h)) + size_t(l) * EW;
+        sl[0] = d;
+        const uint32_t n = s_cnt[h];
+        uint32_t padw = s_first[h];
+        if (n == 0) {
+            const uint32_t d0 = uint32_t(h >> 2) < L.P ? tile_dw[size_t(h >> 2) * 256 + (h & 3)] : 0u;   // lane 0: columns 0, 1 of the half slab
+            float hi, lo;
+            if (L.G > 1) { const float2 v = ghl[(uint32_t(h) * GI_HS) / (L.K / L.G)]; hi = v.x; lo = v.y; }   // row 0's levels of that group
+            else { hi = params[0].hi; lo = params[0].lo; }
+            padw = ((d0 >> 8) & 1u) ? h16(hi) : h16(lo);                                                    // row 0 <-> bit 8 (pbl.h), offset 0
+        }
+        for (uint32_t k = 1; k < EW; ++k)
+            if ((k - 1u) * 64u + uint32_t(l) >= n) sl[k] = padw;
+    }
+    // level rows: (hi - lo) mod 2^16 : lo as fp16 bit patterns, 16 per (record, group)
+    uint32_t* lev = reinterpret_cast<uint32_t*>(img + sizeof(ImgHeader) + size_t(L.NRB) * stride256 * 256) + size_t(rb) * L.G * 16;
+    for (uint32_t it = tid; it < 16u * L.G; it += GI_PREP_THREADS) {
+        const uint32_t g = it >> 4, r = it & 15u;
+        float hi, lo;
+        if (L.G > 1) { const float2 v = ghl[size_t(r) * L.G + g]; hi = v.x; lo = v.y; }
+        else { hi = params[r].hi; lo = params[r].lo; }
+        const uint32_t hh = h16(hi), ll = h16(lo);
+        lev[it] = (((hh - ll) & 0xFFFFu) << 16) | ll;
+    }
+    if (rb == 0 && tid == 0) {
+        ImgHeader* w = reinterpret_cast<ImgHeader*>(img);
+        w->magic = GI_IMG_MAGIC; w->stride256 = stride256; w->NH = uint32_t(NH); w->NRB = L.NRB; w->G = L.G; w->K = L.K; w->N = L.N; w->flags = L.flags;
+        w->slots_off = sizeof(ImgHeader);
+        w->levels_off = sizeof(ImgHeader) + uint64_t(L.NRB) * stride256 * 256;
+        w->total = w->levels_off + uint64_t(L.NRB) * L.G * 64;
+        w->pad[0] = w->pad[1] = 0;
+    }
+}
+
+// ---- the GEMM ---------------------------------------------------------------------------------------------------------------
+struct ImgArgs {
+    pbl_layer L;
+    const _Float16* x;      // [M, K]
+    void* y;                // [M, N] fp16 / fp32
+    int M, y_f32;
+    const uint8_t* img;
+    ImgTab tab;
+#if PBL_TRACE
+    uint64_t* trace;
+#endif
+};
+
+struct Frag { v8h a[4], b[2]; };
+
+template <bool Y32, bool KT>
+__global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kernel(ImgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_i[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const pbl_layer& L = a.L;
+    const int K = int(L.K), M = a.M;
+    const int NH = (K + GI_HS - 1) / GI_HS, NU = (K + GI_XC - 1) / GI_XC;
+    // XCD-aware work order (speed only): workgroup b runs on XCD b % 8; every XCD gets a CONTIGUOUS range of the token-tile-major
+    // work list, so the workgroups resident on an XCD share one 256-token slab of x in its L2
+    const uint32_t nrbk = (L.NRB + 7) / 8, nwg = gridDim.x;
+    const uint32_t xq = nwg >> 3, xr_ = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const uint32_t wg = (xcd < xr_ ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq) + xi;
+    const uint32_t rowblk = wg % nrbk;
+    const int tok0 = int(wg / nrbk) * GI_TOK;
+    // ---- the result tile: Ys[256 tokens][128 rows] over the (then idle) ring and stages; the MFMA waves fill it, ALL eight waves
+    // store it (32 tokens each, contiguous 16-byte units): with four storing waves the tail of the kernel was 6.4 us, with eight 3.4
+    typedef typename std::conditional<Y32, float, _Float16>::type yt;
+    constexpr uint32_t YSTR = Y32 ? 528u : 272u;              // bytes per token row: 128 rows + 16 B (every 16-byte read-back stays aligned)
+    constexpr uint32_t YBIAS = GI_TOK * YSTR;                 // 128 floats of bias behind the tile (fp32 tile: 135168 + 512 <= 163840)
+    static_assert(YBIAS + 512 <= GI_LDS, "tile + bias fit the workgroup's LDS");
+    const uint32_t row0 = rowblk * GI_ROWS;
+    auto store_tile = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // the tile is complete
+        asm volatile("" ::: "memory");
+        const bool vec = (L.N & (Y32 ? 3 : 7)) == 0 && row0 + GI_ROWS <= L.N;     // whole 16-byte units, all rows exist
+        constexpr int UPR = GI_ROWS * int(sizeof(yt)) / 16;      // 16-byte units per token row: 16 (fp16) / 32 (fp32)
+        constexpr int EPU = 16 / int(sizeof(yt));                // elements per unit
+        for (int idx = lane; idx < 32 * UPR; idx += GW) {
+            const int t = 32 * wave + idx / UPR, un = idx % UPR, tok = tok0 + t;
+            if (tok >= M) continue;
+            yt* dstg = static_cast<yt*>(a.y) + size_t(tok) * L.N + row0 + un * EPU;
+            const yt* src = reinterpret_cast<const yt*>(smem_i + uint32_t(t) * YSTR) + un * EPU;
+            if (vec) *reinterpret_cast<u32x4*>(dstg) = *reinterpret_cast<const u32x4*>(src);
+            else
+                for (int e_ = 0; e_ < EPU; ++e_)
+                    if (row0 + un * EPU + e_ < L.N) dstg[e_] = src[e_];
+        }
+    };
+#if PBL_TRACE
+    uint64_t* tr = a.trace ? a.trace + (size_t(blockIdx.x) * 16 + wave) * 16 : nullptr;
+    uint64_t tr_bar = 0, tr_vm = 0;
+    TR_STAMP(0);
+    if (tr && lane == 0) { tr[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4); tr[11] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+#endif
+
+    if (wave >= GI_NCONS) {
+        // =================================== expanding + staging waves ==============================================
+        const int p = wave - GI_NCONS;
+#if PBL_GEMM_PPRIO
+        __builtin_amdgcn_s_setprio(PBL_GEMM_PPRIO);
+#endif
+        const uint32_t stride256 = a.tab.t[NH];
+        const uint8_t* slots = a.img + sizeof(ImgHeader);
+        const uint32_t* levels = reinterpret_cast<const uint32_t*>(slots + size_t(L.NRB) * stride256 * 256);
+        const uint32_t gs = L.K / L.G;                          // columns per group (a multiple of 128)
+        uint32_t rbv[2];
+        const uint8_t* sbase[2];                                // the record's slot row (wave uniform)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            rbv[i] = min(rowblk * 8 + 2 * uint32_t(p) + uint32_t(i), L.NRB - 1);      // (a record beyond the layer mirrors the last one; its rows are never stored)
+            sbase[i] = slots + size_t(rbv[i]) * stride256 * 256;
+        }
+        const uint32_t lane16 = uint32_t(lane) * 16u;
+        uint32_t hl[2][16];                                     // (hi - lo : lo) of the 16 rows, current column group: SGPRs
+        auto load_levels = [&](int i, uint32_t g) {
+            const uint32_t* lp = levels + (size_t(rbv[i]) * L.G + g) * 16;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hl[i][r] = __builtin_amdgcn_readfirstlane(lp[r]);
+        };
+        // slot registers: set s = (half slab & 1), record i, up to five 16-byte vectors.  A set is re-requested (for the half slab
+        // after next) right after its last use and lands two half slabs later; nothing touches it in between (asm loads, counted
+        // waits: see wait_all).  nvs: how many vectors the slot a set holds has (wave uniform).
+        u32x4 e[2][2][GI_NVMAX];
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int v = 0; v < GI_NVMAX; ++v) e[s_][i][v] = u32x4{0, 0, 0, 0};
+        int nvs[2][2];
+        // ONE asm block names all three vectors as read-write operands and skips the loads a smaller slot does not have with a
+        // scalar branch INSIDE the block: with the loads under C++ branches the compiler merges the paths with register copies
+        // (v_mov of registers whose load is in flight -- found by tools/audit_asm_loads.py in the first per-column build).
+        auto request = [&](int i, int hh, u32x4 (&dst)[GI_NVMAX], int& nv_out) {
+            const uint32_t t = a.tab.t[min(hh, NH - 1)];
+            const uint32_t nv = t >> 16;
+            const uint8_t* sp = sbase[i] + size_t(t & 0xFFFFu) * 256;
+            const uint32_t lo = lane16 * nv;                    // the lane's bytes in a slot of nv vectors
+            static_assert(GI_NVMAX == 5, "the request block spells five loads out");
+            asm volatile("global_load_dwordx4 %0, %5, %6\n\t"
+                         "s_cmp_lt_u32 %7, 2\n\t"
+                         "s_cbranch_scc1 1f\n\t"
+                         "global_load_dwordx4 %1, %5, %6 offset:16\n\t"
+                         "s_cmp_lt_u32 %7, 3\n\t"
+                         "s_cbranch_scc1 1f\n\t"
+                         "global_load_dwordx4 %2, %5, %6 offset:32\n\t"
+                         "s_cmp_lt_u32 %7, 4\n\t"
+                         "s_cbranch_scc1 1f\n\t"
+                         "global_load_dwordx4 %3, %5, %6 offset:48\n\t"
+                         "s_cmp_lt_u32 %7, 5\n\t"
+                         "s_cbranch_scc1 1f\n\t"
+                         "global_load_dwordx4 %4, %5, %6 offset:64\n"
+                         "1:"
+                         : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]) : "v"(lo), "s"(sp), "s"(nv) : "memory", "scc");
+            nv_out = int(nv);
+        };
+        // x through a buffer descriptor that starts at this workgroup's first token: tokens >= M read zeros
+        const char* xbase = reinterpret_cast<const char*>(a.x) + size_t(tok0) * size_t(K) * 2;
+        const size_t xrem = size_t(min(M - tok0, GI_TOK)) * size_t(K) * 2;          // <= 256 * 32767 * 2 < 2^24
+        __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xbase), 0, int(xrem), 0x00020000);
+        // DMA piece q (1 KiB) of this wave: tokens 64 p + 8 q .. + 7, 128 B each; lane l lands on unit l & 7 of token (l >> 3),
+        // which holds the LOGICAL unit (l & 7) ^ ((token >> 1) & 7)
+        uint32_t xvoff[8], xvlast[KT ? 8 : 1];
+        const uint32_t ktail_units = uint32_t(K & (GI_XC - 1)) >> 3;               // valid 16-byte units of the last step (0: no tail)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t tl = uint32_t(64 * p + 8 * q + (lane >> 3));
+            const uint32_t lu = uint32_t(lane & 7) ^ ((tl >> 1) & 7);
+            xvoff[q] = tl * uint32_t(K) * 2u + (lu << 4);
+            // K % 64 != 0: the units of the LAST step beyond K would hold the next token row; their source offset is pushed out of
+            // the descriptor's range instead, so they read zeros (the weights there are finite, the products vanish)
+            if constexpr (KT) xvlast[q] = xvoff[q] + ((ktail_units && lu >= ktail_units) ? 0x40000000u : 0u);
+        }
+        auto stage_x = [&](int u, uint32_t slot_off) {           // the wave's 8 pieces of step u into the ring slot at slot_off
+            const uint32_t so = uint32_t(u) * (GI_XC * 2);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t dst = GI_X_OFF + slot_off + uint32_t(8 * p + q) * 1024u;
+                uint32_t vo = xvoff[q];
+                if constexpr (KT) vo = (u == NU - 1) ? xvlast[q] : vo;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_i + dst), 16, int(vo), int(so), 0, 0);
+            }
+        };
+        // store addresses of the sign plane: lane l holds columns 2l, 2l+1 of all 16 rows in ONE dword (include/pbl.h: bit 16 e + pos);
+        // row r's dword goes to  record + 256 r + (((l >> 2) ^ r) << 4) + 4 (l & 3)
+        const uint32_t v0 = uint32_t(p) * 8192u + (uint32_t(lane >> 2) << 4) + (uint32_t(lane & 3) << 2);
+        const uint32_t pb = uint32_t(p) * 8192u;
+        auto expand = [&](int i, const u32x4 (&s)[GI_NVMAX], int nv, uint32_t stage) {
+            const uint32_t base = stage * GI_AS_STAGE + uint32_t(i) * 4096u;       // (compile-time where the caller unrolls)
+            const uint32_t d = s[0][0];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pos = r < 8 ? r + 8 : r - 8;
+                const uint32_t m = (d >> pos) & 0x00010001u;
+                uint32_t val;
+                // per half: lo + bit * (hi - lo)  (mod 2^16): src1 = the pair's high half, src2 = its low half, for both lanes
+                asm("v_pk_mad_u16 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(val) : "v"(m), "s"(hl[i][r]));
+                *reinterpret_cast<uint32_t*>(smem_i + base + (v0 ^ uint32_t(0x110 * r))) = val;
+            }
+            asm volatile("" ::: "memory");                       // (the overlay comes after the plane: LDS keeps a wave's accesses in order)
+            auto put_word = [&](uint32_t w) { *reinterpret_cast<uint16_t*>(smem_i + base + pb + (w >> 16)) = uint16_t(w & 0xFFFFu); };
+            put_word(s[0][1]); put_word(s[0][2]); put_word(s[0][3]);
+            if (nv >= 2) { put_word(s[1][0]); put_word(s[1][1]); put_word(s[1][2]); put_word(s[1][3]); }
+            if (nv >= 3) { put_word(s[2][0]); put_word(s[2][1]); put_word(s[2][2]); put_word(s[2][3]); }
+            if (nv >= 4) { put_word(s[3][0]); put_word(s[3][1]); put_word(s[3][2]); put_word(s[3][3]); }
+            if (nv >= 5) { put_word(s[4][0]); put_word(s[4][1]); put_word(s[4][2]); put_word(s[4][3]); }
+            asm volatile("" ::: "memory");
+        };
+        // `s_waitcnt vmcnt(10)` at the end of a step.  Issue order per step: 8 x pieces (D), then the slot request (R, 1 - 5 loads).
+        // The barrier that follows publishes the x pieces of the PREVIOUS step, D(q-1); behind them came R(q-1) (>= 1), D(q) (8),
+        // R(q) (>= 1): with at most 10 operations in flight D(q-1) has landed whatever the slot sizes are (in-order return) -- and
+        // with it every slot set requested two or more steps ago.  (13 = 8 + the largest request looked right and let up to three
+        // pieces of D(q-1) stay in flight when the slots are small: a race the config-3 test found on 2 of 256 workgroups.)  For
+        // larger slots the constant is stricter than necessary (it then also covers part of R(q-1) / D(q)): those were issued a
+        // whole step earlier.  ONE constant wait: a count that follows the slot sizes needs one asm statement per value under C++
+        // branches, and the compiler merges those paths with register copies of slots still in flight
+        // (tools/audit_asm_loads.py).  The slot registers are named as read-write operands, so no use can move above the wait and
+        // no request below it.
+#define GI_ESET(s_, i_) "+v"(e[s_][i_][0]), "+v"(e[s_][i_][1]), "+v"(e[s_][i_][2]), "+v"(e[s_][i_][3]), "+v"(e[s_][i_][4])
+#define GI_EREGS GI_ESET(0, 0), GI_ESET(0, 1), GI_ESET(1, 0), GI_ESET(1, 1)
+        auto wait_all = [&]() {
+            TR_T0();
+            asm volatile("s_waitcnt vmcnt(10)" : GI_EREGS :: "memory");
+            TR_ADD(tr_vm);
+        };
+        auto barrier = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's LDS stores are done
+            TR_T0();
+            __builtin_amdgcn_s_barrier();
+            TR_ADD(tr_bar);
+            asm volatile("" ::: "memory");
+        };
+
+        // ---- prologue: half slab 0 of A, steps 0 and 1 of x, the requests that follow
+#pragma unroll
+        for (int i = 0; i < 2; ++i) load_levels(i, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) request(i, 0, e[0][i], nvs[0][i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) request(i, 1, e[1][i], nvs[1][i]);
+        stage_x(0, 0);
+        stage_x(1, GI_XSLOT);
+        asm volatile("s_waitcnt vmcnt(0)" : GI_EREGS :: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { expand(i, e[0][i], nvs[0][i], 0); request(i, 2, e[0][i], nvs[0][i]); }
+        TR_STAMP(1);
+        barrier();                                               // barrier 0: stage 0 of A, steps 0 and 1 of x are in LDS
+
+        // ---- step q (between barriers q and q + 1): x of step q + 2 into the slot step q - 1 used; record q & 1 of half slab
+        // (q >> 1) + 1 into the stage half slab (q >> 1) - 1 used; that record's slot of half slab (q >> 1) + 3 requested
+        uint32_t xs_free = 2 * GI_XSLOT, xs_a = 0, xs_b = GI_XSLOT;                 // ring slots: free now, then the two in use
+        auto step = [&](int q, auto qm_tag) {
+            constexpr int QM = decltype(qm_tag)::value;           // q & 3
+            constexpr int i = QM & 1, st = ((QM >> 1) + 1) & 1;   // record; stage == register set == parity of the target half slab
+            const int hh = (q >> 1) + 1;
+            if (!(PBL_IMG_ABLATE & 2)) stage_x(q + 2, xs_free);
+            { const uint32_t t = xs_free; xs_free = xs_a; xs_a = xs_b; xs_b = t; }
+            if (L.G > 1 && (uint32_t(hh) * GI_HS) % gs == 0 && hh < NH) load_levels(i, (uint32_t(hh) * GI_HS) / gs);
+            if (!(PBL_IMG_ABLATE & 1)) expand(i, e[st][i], nvs[st][i], uint32_t(st));
+            request(i, hh + 2, e[st][i], nvs[st][i]);
+            wait_all();
+            barrier();
+        };
+        int q = 0;
+        for (; q + 4 <= NU - 1; q += 4) {
+            step(q, std::integral_constant<int, 0>{});
+            step(q + 1, std::integral_constant<int, 1>{});
+            step(q + 2, std::integral_constant<int, 2>{});
+            step(q + 3, std::integral_constant<int, 3>{});
+        }
+        if (q < NU - 1) {                                          // (nested: the control-flow graph then only has feasible paths, which is what
+            step(q, std::integral_constant<int, 0>{});               // tools/audit_asm_loads.py walks)
+            if (q + 1 < NU - 1) {
+                step(q + 1, std::integral_constant<int, 1>{});
+                if (q + 2 < NU - 1) step(q + 2, std::integral_constant<int, 2>{});
+            }
+        }
+        TR_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (requests and x pieces past the end: nothing may land after the ring is reused)
+        barrier();                                               // the MFMA waves are done with the ring: the result tile goes there
+#undef GI_EREGS
+#undef GI_ESET
+#if PBL_TRACE
+        if (tr && lane == 0) { tr[8] = tr_bar; tr[9] = tr_vm; }
+#endif
+        store_tile();                                            // (second barrier inside: the tile is complete) this wave's 32 tokens
+        return;
+    }
+
+    // =================================== MFMA waves ==================================================================
+    const int c = wave;
+    const int i32 = lane & 31, g = lane >> 5;
+    // fragment addresses: A unit (2 ks8 + g) ^ (i32 & 15) of row i32 (+ 32 rt), ks8 = 4 (u & 1) + k: the odd step's units are the
+    // even one's with bit 3 flipped (byte 128); x unit (2 k + g) ^ ((i32 >> 1) & 7) of token 64 c + i32 (+ 32 tt)
+    uint32_t aq[4], bq[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) aq[k] = uint32_t(i32) * 256u + ((uint32_t(2 * k + g) ^ uint32_t(i32 & 15)) << 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bq[k] = GI_X_OFF + uint32_t(64 * c + i32) * 128u + ((uint32_t(2 * k + g) ^ uint32_t((i32 >> 1) & 7)) << 4);
+
+    v16f acc[4][2];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int e_ = 0; e_ < 16; ++e_) acc[rt][tt][e_] = 0.f;
+
+    float bias_lo = 0.f, bias_hi = 0.f;                           // bias of rows row0 + lane, row0 + 64 + lane (used in the epilogue)
+    if (L.bias) {
+        if (row0 + uint32_t(lane) < L.N) bias_lo = L.bias[row0 + lane];
+        if (row0 + 64u + uint32_t(lane) < L.N) bias_hi = L.bias[row0 + 64 + lane];
+    }
+    // Fragment reads are issued from inline asm and waited for with counted lgkmcnt: left to itself hipcc sinks every ds_read to
+    // just in front of the MFMA that needs it and waits lgkmcnt(0) there (seen in the ISA of the first build of this kernel: the
+    // whole LDS latency in front of every k-step).  Here the six reads of k-step kk + 1 go out BEFORE the eight MFMAs of k-step kk;
+    // the wait in front of those MFMAs leaves exactly the six younger reads outstanding (LDS returns in order).
+    auto load_frag = [&](Frag& f, uint32_t aaddr, uint32_t baddr, auto aoff_tag) {
+        constexpr int AO = decltype(aoff_tag)::value;              // stage offset of A (immediate)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a[0]) : "v"(aaddr), "n"(AO) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=&v"(f.b[0]) : "v"(baddr) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:4096" : "=&v"(f.b[1]) : "v"(baddr) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a[1]) : "v"(aaddr), "n"(AO + 8192) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a[2]) : "v"(aaddr), "n"(AO + 16384) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a[3]) : "v"(aaddr), "n"(AO + 24576) : "memory");
+    };
+    auto wait_frag = [&](Frag& f, auto n_tag) {                    // f has landed; n younger reads stay in flight
+        constexpr int NOUT = decltype(n_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]) : "n"(NOUT) : "memory");
+    };
+    auto mma = [&](const Frag& f) {
+        if (!(PBL_IMG_ABLATE & 4)) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+                    acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[rt], f.b[tt], acc[rt][tt], 0, 0, 0);
+        }
+        // nothing moves across: without it the scheduler sinks a k-step's MFMAs below the NEXT wait and even below the workgroup
+        // barrier (seen in the ISA), and the matrix pipe idles exactly while the wave is parked
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+        TR_T0();
+        __builtin_amdgcn_s_barrier();                             // barrier 0
+        TR_ADD(tr_bar);
+        asm volatile("" ::: "memory");
+    }
+    TR_STAMP(1);
+    Frag f0, f1;
+    uint32_t xs0 = 0, xs1 = GI_XSLOT, xs2 = 2 * GI_XSLOT;         // ring slot of this step, the next, the one after
+    load_frag(f0, aq[0], bq[0], std::integral_constant<int, 0>{});
+    // One 64-column step = 4 k-steps of 16 columns.  The barrier that opens step u + 1 sits in front of the step's LAST eight MFMAs:
+    // they cover the first fragment reads of step u + 1.  Every step has it -- the last one's is the barrier behind which the
+    // result tile may overwrite the ring (its prefetch then reads LDS nobody needs any more) -- so a step is branch free.
+    auto substep = [&](auto um_tag) {
+        constexpr int UM = decltype(um_tag)::value;               // u & 3
+        constexpr int abuf = ((UM >> 1) & 1) * GI_AS_STAGE, nabuf = (((UM + 1) >> 1) & 1) * GI_AS_STAGE;
+        constexpr uint32_t ahalf = uint32_t(UM & 1) * 128u, nahalf = uint32_t((UM + 1) & 1) * 128u;
+        load_frag(f1, aq[1] ^ ahalf, bq[1] + xs0, std::integral_constant<int, abuf>{});
+        wait_frag(f0, std::integral_constant<int, 6>{});
+        mma(f0);
+        load_frag(f0, aq[2] ^ ahalf, bq[2] + xs0, std::integral_constant<int, abuf>{});
+        wait_frag(f1, std::integral_constant<int, 6>{});
+        mma(f1);
+        load_frag(f1, aq[3] ^ ahalf, bq[3] + xs0, std::integral_constant<int, abuf>{});
+        wait_frag(f0, std::integral_constant<int, 6>{});
+        mma(f0);
+        wait_frag(f1, std::integral_constant<int, 0>{});          // every read of this step has returned
+        {
+            TR_T0();
+            __builtin_amdgcn_s_barrier();                         // barrier u + 1: step u + 1 of x (and, after an odd step, the next stage of A) is complete
+            TR_ADD(tr_bar);
+            asm volatile("" ::: "memory");
+        }
+        load_frag(f0, aq[0] ^ nahalf, bq[0] + xs1, std::integral_constant<int, nabuf>{});
+        mma(f1);
+        { const uint32_t t = xs0; xs0 = xs1; xs1 = xs2; xs2 = t; }
+    };
+    int u = 0;
+    for (; u + 4 <= NU; u += 4) {
+        substep(std::integral_constant<int, 0>{});
+        substep(std::integral_constant<int, 1>{});
+        substep(std::integral_constant<int, 2>{});
+        substep(std::integral_constant<int, 3>{});
+    }
+    if (u < NU) { substep(std::integral_constant<int, 0>{}); ++u; }
+    if (u < NU) { substep(std::integral_constant<int, 1>{}); ++u; }
+    if (u < NU) { substep(std::integral_constant<int, 2>{}); ++u; }
+    wait_frag(f0, std::integral_constant<int, 0>{});              // (the last prefetch: nothing may land in the registers later)
+    TR_STAMP(2);
+#if PBL_TRACE
+    if (tr && lane == 0) { tr[8] = tr_bar; tr[9] = tr_vm; }
+#endif
+
+    // ---- epilogue: accumulators (+ bias) -> the tile; the bias of the 128 rows goes through LDS (two coalesced loads per lane,
+    // requested before the loop) instead of 64 predicated loads per lane
+    if (L.bias) {
+        reinterpret_cast<float*>(smem_i + YBIAS)[lane] = bias_lo;
+        reinterpret_cast<float*>(smem_i + YBIAS)[64 + lane] = bias_hi;     // (every MFMA wave writes the same 128 values)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int rloc = rt * 32 + 8 * q4 + 4 * g;        // 4 consecutive rows held by this lane: D row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+                v4f b4 = {0.f, 0.f, 0.f, 0.f};
+                if (L.bias) b4 = *reinterpret_cast<const v4f*>(smem_i + YBIAS + uint32_t(rloc) * 4u);
+                yt h[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = yt(acc[rt][tt][4 * q4 + r] + b4[r]);
+                char* dst = smem_i + uint32_t(64 * c + 32 * tt + i32) * YSTR + uint32_t(rloc) * sizeof(yt);
+                if (Y32) *reinterpret_cast<v4f*>(dst) = v4f{float(h[0]), float(h[1]), float(h[2]), float(h[3])};
+                else {
+                    uint2 pk;
+                    pk.x = uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[0]))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[1]))) << 16);
+                    pk.y = uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[2]))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[3]))) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                }
+            }
+    }
+    store_tile();
+#if PBL_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR_STAMP(3);
+#endif
+}
+
+size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
+bool layer_ok(const pbl_layer* layer) {
+    if (!layer || (layer->K & 7) || !(layer->flags & PBL_FLAG_SLABS) || !(layer->flags & PBL_FLAG_TAIL_REPEAT)) return false;
+    if (layer->G < 1 || (layer->G > 1 && (layer->K % layer->G || (layer->K / layer->G) % GI_HS))) return false;
+    return (layer->K + GI_HS - 1) / GI_HS <= GI_MAX_NH;
+}
+// slot geometry from the per-column maxima (pbl_gemm_image_stats): false when a column needs more than 1216 entries in a slot
+bool make_tab(const pbl_layer* layer, const uint32_t* colmax, ImgTab& tab) {
+    const uint32_t NH = (layer->K + GI_HS - 1) / GI_HS;
+    uint32_t off = 0;
+    for (uint32_t h = 0; h < 128; ++h) tab.t[h] = 0;
+    for (uint32_t h = 0; h < NH; ++h) {
+        const uint32_t m = colmax[h];
+        const uint32_t nv = m <= 192u ? 1u : (m <= 448u ? 2u : (m <= 704u ? 3u : (m <= 960u ? 4u : (m <= 1216u ? 5u : 0u))));
+        if (!nv) return false;
+        tab.t[h] = off | (nv << 16);
+        off += 4u * nv;                                    // 1 KiB = four 256-byte units per vector
+    }
+    tab.t[NH] = off;
+    return off <= 0xFFFFu;
+}
+size_t image_bytes_of(const pbl_layer* layer, const ImgTab& tab) {
+    const uint32_t NH = (layer->K + GI_HS - 1) / GI_HS;
+    return align16(sizeof(ImgHeader) + size_t(layer->NRB) * tab.t[NH] * 256 + size_t(layer->NRB) * layer->G * 64);
+}
+size_t prep_lds(const pbl_layer* layer) {
+    return size_t(2 * (GI_MAX_NH + 1)) * 4 + 32 * 4 + 16 * sizeof(pbl_rowinfo) + ((size_t(layer->max_nch) + 15) & ~size_t(15));
+}
+
+}  // namespace
+
+// For every 128-column half slab h of the layer: the largest number of salient entries + exceptions any 16-row record holds there,
+// folded into the device words colmax_dev[0 .. ceil(K / 128)) (uint32, zeroed by the caller): what sizes the image's slots.  One
+// small kernel, no x.
+extern "C" int pbl_gemm_image_stats(const pbl_layer* layer, void* colmax_dev, void* stream) {
+    if (!layer || !layer->blob || !colmax_dev) return PBL_ERR_INVALID_ARG;
+    if (!layer_ok(layer)) return PBL_ERR_UNSUPPORTED;
+    pbl_layer lcopy = *layer;
+    uint8_t* img = nullptr;
+    ImgTab tab;
+    for (uint32_t h = 0; h < 128; ++h) tab.t[h] = 0;
+    uint32_t* mx = static_cast<uint32_t*>(colmax_dev);
+    void* argv[] = {&lcopy, &img, &tab, &mx};
+    return hipLaunchKernel(reinterpret_cast<const void*>(img_prep_kernel<true>), dim3(layer->NRB), dim3(GI_PREP_THREADS), argv, prep_lds(layer),
+                           static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+// Bytes of the layer's GEMM image for the per-column maxima colmax[0 .. ceil(K / 128)) (HOST array, read back from
+// pbl_gemm_image_stats): per record and column a slot of 1 KiB (up to 192 entries), 2 KiB (448) ... 5 KiB (1216), + 64 B of levels per
+// (record, group).  0: no image for this layer (K % 8, more than 127 half slabs, an odd group size, or more than 1216 entries in
+// one slot) -- pbl_gemm_f16_ws serves it.
+extern "C" size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* colmax) {
+    if (!layer_ok(layer) || !colmax) return 0;
+    ImgTab tab;
+    if (!make_tab(layer, colmax, tab)) return 0;
+    return image_bytes_of(layer, tab);
+}
+
+// Build the image into `image` (>= pbl_gemm_image_bytes(layer, colmax), 16-byte aligned): one small kernel.  It depends on the blob
+// only and stays valid as long as the blob is unchanged.
+extern "C" int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* colmax, void* image, size_t image_bytes, void* stream) {
+    if (!layer || !layer->blob || !image || !colmax) return PBL_ERR_INVALID_ARG;
+    if (!layer_ok(layer)) return PBL_ERR_UNSUPPORTED;
+    ImgTab tab;
+    if (!make_tab(layer, colmax, tab)) return PBL_ERR_UNSUPPORTED;
+    if (image_bytes < image_bytes_of(layer, tab)) return PBL_ERR_CAPACITY;
+    if (reinterpret_cast<uintptr_t>(image) & 15) return PBL_ERR_MISALIGNED;
+    pbl_layer lcopy = *layer;
+    uint8_t* img = static_cast<uint8_t*>(image);
+    uint32_t* mx = nullptr;
+    void* argv[] = {&lcopy, &img, &tab, &mx};
+    return hipLaunchKernel(reinterpret_cast<const void*>(img_prep_kernel<false>), dim3(layer->NRB), dim3(GI_PREP_THREADS), argv, prep_lds(layer),
+                           static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+// y[M, N] = x[M, K] . W^T (+ bias) over an image pbl_gemm_image_build made for THIS layer with the same colmax (any M >= 1).
+// Bit-identical to pbl_gemm_f16_ws / _prepared.
+extern "C" int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
+                                  const uint32_t* colmax, void* stream) {
+    if (!layer || !layer->blob || !x || !y || !image || !colmax || M < 1) return PBL_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return PBL_ERR_MISALIGNED;
+    if (!layer_ok(layer)) return PBL_ERR_UNSUPPORTED;
+    ImgArgs a;
+    if (!make_tab(layer, colmax, a.tab)) return PBL_ERR_UNSUPPORTED;
+    if (image_bytes < image_bytes_of(layer, a.tab)) return PBL_ERR_CAPACITY;
+    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32; a.img = static_cast<const uint8_t*>(image);
+#if PBL_TRACE
+    a.trace = g_img_trace;
+#endif
+    const bool kt = (layer->K & (GI_XC - 1)) != 0;
+    const void* k = y_f32 ? (kt ? reinterpret_cast<const void*>(pbl_gemm_img_kernel<true, true>) : reinterpret_cast<const void*>(pbl_gemm_img_kernel<true, false>))
+                          : (kt ? reinterpret_cast<const void*>(pbl_gemm_img_kernel<false, true>) : reinterpret_cast<const void*>(pbl_gemm_img_kernel<false, false>));
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(GI_LDS)) != hipSuccess) return PBL_ERR_LAUNCH;
+    void* argv[] = {&a};
+    const dim3 grid(((layer->NRB + 7) / 8) * uint32_t((M + GI_TOK - 1) / GI_TOK));
+    return hipLaunchKernel(k, grid, dim3((GI_NCONS + GI_NPROD) * GW), argv, GI_LDS, static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}

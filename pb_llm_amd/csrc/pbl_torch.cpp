@@ -1,56 +1,223 @@
-// pbl_torch.cpp -- native dispatcher of the packed forward: `torch.ops.pbllm_native.linear`.
+// pbl_torch.cpp -- the packed forward as a native torch operator: `torch.ops.pbllm_native.linear`.
 //
-// north_star asks for "a PyTorch-ROCm C++/HIP extension with the same nn.Linear-compatible signature"; rounds 1-2 reached the
-// C ABI (include/pbl.h) through ctypes from Python, which costs ~25-30 us of interpreter work per eager call (descriptor
-// struct, workspace query, two allocations, stream lookup, the ctypes marshalling) -- next to a 1-6 us kernel.  This file is
-// the whole decode-regime forward (rows <= 32, fp16 activations) as ONE native call: checks, output and workspace
-// allocation through ATen's caching allocator (stream ordered, graph safe), the current HIP stream, pbl_linear_f16_ws.
-// The callers it serves: every `module(x)` of the reference's eval loops (qat/run_qat.py:45-66, utils.py:103-123,
-// gptq_pb/eval_ppl_utils.py:55-64).  Other regimes (rows > 32, fp32 / bf16 activations) stay in pb_llm_amd/quant.py.
-// Host code only: built with g++ against libtorch and libpbl.so (__graft_entry__.build()).
+// north_star asks for "a PyTorch-ROCm C++/HIP extension with the same nn.Linear-compatible signature".  The boundary stays the
+// C ABI (include/pbl.h); this file is the torch side of it in C++: ONE operator that does everything `module(x)` needs for any
+// row count and activation dtype --
+//   * decode / small batch (<= 32 rows): pbl_linear_f16_ws (GEMV passes or the matrix-core kernel, routed by the library);
+//     bf16 activations as one fp16 pass (exact inside fp16's range; per-token power-of-two scaling outside it, or the dense
+//     path when the range check finds out-of-range / non-finite values), fp32 activations as two fp16 terms;
+//   * GEMM regime (> 32 rows: prefill, the reference's perplexity loops gptq_pb/eval_ppl_utils.py:55-64): the hand-written
+//     kernel over the layer's GEMM image (pbl_gemm_f16_image) when the caller hands one over, pbl_gemm_f16_ws for
+//     backend "fused", else pbl_unpack_dev + a library GEMM on the transient dense weight;
+//   * a Meta kernel (shapes and dtypes without touching a GPU: torch.compile, fake tensors) and an Autograd kernel (the packed
+//     weight is frozen, dx = dy @ W with W re-unpacked in the backward -- what the reference's fake-quant nn.Linear gives
+//     prompt tuning / input-gradient analysis).
+// Round 3 had the <= 32-row fp16 case only (7.7 us per eager call instead of 13.7 through ctypes); everything else went through
+// Python (pb_llm_amd/quant.py), which now only keeps the ctypes route as the fallback for variant libraries (PBL_LIB) and
+// PBL_NATIVE=0.  The callers it serves: every `module(x)` of the reference's loops (qat/run_qat.py:45-66, utils.py:103-123,
+// gptq_pb/eval_ppl_utils.py:55-64).  Host code only: built with g++ against libtorch and libpbl.so (__graft_entry__.build()).
 #include <ATen/ATen.h>
 #include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPGraphsC10Utils.h>
 #include <c10/hip/HIPStream.h>
+#include <torch/autograd.h>
 #include <torch/library.h>
+
+#include <string>
+#include <vector>
 
 #include "../../include/pbl.h"
 
 namespace {
 
-at::Tensor pbl_native_linear(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K,
-                             int64_t P, int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32) {
-    TORCH_CHECK(x.is_cuda() && blob.is_cuda(), "pbllm_native.linear: GPU tensors only (the HIP kernels are the only compute path)");
-    TORCH_CHECK(x.scalar_type() == at::kHalf, "pbllm_native.linear: fp16 activations");
-    TORCH_CHECK(x.dim() >= 1 && x.size(-1) == K, "pbllm_native.linear: in_features mismatch: x has ", x.size(-1), ", layer has ", K);
-    TORCH_CHECK(blob.device() == x.device(), "pbllm_native.linear: packed weight and input are on different devices");
-    const c10::DeviceGuard guard(x.device());        // a process that drives several GPUs: launch where x lives
-    const at::Tensor xc = x.reshape({-1, K}).contiguous();
-    const int64_t M = xc.size(0);
-    TORCH_CHECK(M >= 1 && M <= 32, "pbllm_native.linear: 1..32 rows (decode / small batch); larger batches go through pb_llm_amd.quant");
+constexpr int64_t MFMA_MAX = 32;        // rows the packed small-batch kernels take (pb_llm_amd/quant.py: MFMA_MAX)
+constexpr int64_t GEMM_THRESHOLD = 12;  // ... and where layers the matrix-core kernel refuses switch to the dense path
+
+pbl_layer make_layer(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, int64_t N, int64_t K, int64_t P, int64_t G,
+                     int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool with_bias) {
     pbl_layer L;
     L.blob = blob.data_ptr();
     L.bias = nullptr;
-    if (bias.has_value() && bias->defined()) {
+    if (with_bias && bias.has_value() && bias->defined()) {
         TORCH_CHECK(bias->scalar_type() == at::kFloat && bias->is_contiguous() && bias->numel() == N, "pbllm_native.linear: fp32 bias [N]");
         L.bias = bias->data_ptr<float>();
     }
     L.N = uint32_t(N); L.K = uint32_t(K); L.P = uint32_t(P); L.G = uint32_t(G); L.NRB = uint32_t(NRB);
     L.flags = uint32_t(flags); L.max_nch = uint32_t(max_nch); L.max_nexc = uint32_t(max_nexc);
-    std::vector<int64_t> shape(x.sizes().begin(), x.sizes().end());
-    shape.back() = N;
-    at::Tensor y = at::empty(shape, x.options().dtype(out_f32 ? at::kFloat : at::kHalf));
+    return L;
+}
+
+// layers the matrix-core kernel (<= 32 rows) takes: K % 8 == 0, slab index, column groups of a power of two >= 128
+bool mfma_ok(int64_t K, int64_t G, int64_t flags) {
+    const int64_t gs = K / G;
+    return (G == 1 || (gs >= 128 && (gs & (gs - 1)) == 0 && gs * G == K)) && K % 8 == 0 && (flags & PBL_FLAG_SLABS);
+}
+// layers pbl_gemm_f16_* take: K % 8 == 0, slab index + repeat-padded tails, groups of k * 128 columns
+bool fused_ok(int64_t K, int64_t G, int64_t flags) {
+    const int64_t need = PBL_FLAG_SLABS | PBL_FLAG_TAIL_REPEAT;
+    if (K % 8 || (flags & need) != need) return false;
+    return G == 1 || (K % G == 0 && (K / G) % 128 == 0);
+}
+
+void check(int rc, const char* what) { TORCH_CHECK(rc == PBL_OK, "libpbl ", what, ": ", pbl_status_string(rc), " (", rc, ")"); }
+
+hipStream_t stream_of(const at::Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// <= 32 rows of fp16 x [M, K] -> y [M, N] (fp16 / fp32); scratch from the caching allocator (stream ordered, graph safe)
+at::Tensor run_small(const pbl_layer& L, const at::Tensor& xc, int64_t M, bool f32) {
+    at::Tensor y = at::empty({M, int64_t(L.N)}, xc.options().dtype(f32 ? at::kFloat : at::kHalf));
     const size_t nb = M > 1 ? pbl_linear_workspace_bytes(&L, int(M)) : 0;      // one token is always one GEMV pass
     at::Tensor ws;
-    if (nb) ws = at::empty({int64_t(nb)}, x.options().dtype(at::kByte));
-    hipStream_t st = c10::hip::getCurrentHIPStream(x.device().index()).stream();
-    const int rc = pbl_linear_f16_ws(&L, xc.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, nb ? ws.data_ptr() : nullptr, nb, st);
-    TORCH_CHECK(rc == PBL_OK, "libpbl linear: ", pbl_status_string(rc), " (", rc, ")");
+    if (nb) ws = at::empty({int64_t(nb)}, xc.options().dtype(at::kByte));
+    check(pbl_linear_f16_ws(&L, xc.data_ptr(), y.data_ptr(), int(M), f32 ? 1 : 0, nb ? ws.data_ptr() : nullptr, nb, stream_of(xc)), "linear");
     return y;
+}
+
+at::Tensor unpack(const pbl_layer& L, const at::Tensor& like, at::ScalarType dt) {
+    at::Tensor W = at::empty({int64_t(L.N), int64_t(L.K)}, like.options().dtype(dt));
+    pbl_layer nb = L;
+    nb.bias = nullptr;
+    check(pbl_unpack_dev(&nb, W.data_ptr(), dt == at::kFloat ? 1 : 0, stream_of(like)), "unpack_dev");
+    return W;
+}
+
+at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
+                       int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
+                       const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> colmax, c10::string_view backend,
+                       bool bf16_range_check) {
+    TORCH_CHECK(x.is_cuda() && blob.is_cuda(), "pbllm_native.linear: GPU tensors only (the HIP kernels are the only compute path)");
+    const auto xt = x.scalar_type();
+    TORCH_CHECK(xt == at::kHalf || xt == at::kBFloat16 || xt == at::kFloat, "pbllm_native.linear: fp16, bf16 or fp32 activations");
+    TORCH_CHECK(x.dim() >= 1 && x.size(-1) == K, "pbllm_native.linear: in_features mismatch: x has ", x.size(-1), ", layer has ", K);
+    TORCH_CHECK(blob.device() == x.device(), "pbllm_native.linear: packed weight and input are on different devices");
+    const c10::DeviceGuard guard(x.device());        // a process that drives several GPUs: launch where x lives
+    std::vector<int64_t> shape(x.sizes().begin(), x.sizes().end());
+    shape.back() = N;
+    const at::Tensor x2 = x.reshape({-1, K});
+    const int64_t M = x2.size(0);
+    const auto out_dt = out_f32 ? at::kFloat : xt;
+    if (M == 0) return at::zeros(shape, x.options().dtype(out_dt));
+    const pbl_layer L = make_layer(blob, bias, N, K, P, G, NRB, flags, max_nch, max_nexc, true);
+    pbl_layer Lnb = L;
+    Lnb.bias = nullptr;
+    const bool has_bias = L.bias != nullptr;
+    const int64_t rows = xt == at::kFloat ? 2 * M : M;     // fp32 x runs as two fp16 terms (bf16 converts exactly)
+    const bool mok = mfma_ok(K, G, flags);
+    auto dense_path = [&](at::ScalarType wdt) {
+        const at::Tensor W = unpack(L, x, wdt);
+        at::Tensor y = at::linear(x2.to(wdt), W, has_bias ? c10::optional<at::Tensor>(bias->to(wdt)) : c10::nullopt);
+        return y.to(out_dt).reshape(shape);
+    };
+    if (mok ? rows > MFMA_MAX : M >= GEMM_THRESHOLD) {
+        // GEMM regime.  fp16 weights when the layer is fp16-exact (packed from an fp16 checkpoint) and x is fp16, else fp32.
+        const auto wdt = (xt == at::kHalf && dense_f16) ? at::kHalf : at::kFloat;
+        if (backend != "library" && wdt == at::kHalf && fused_ok(K, G, flags)) {
+            const at::Tensor xc = x2.contiguous();
+            if ((reinterpret_cast<uintptr_t>(xc.data_ptr()) & 15) == 0) {
+                const bool img = image.has_value() && image->defined() && colmax.has_value();
+                if (img || backend == "fused") {
+                    at::Tensor y = at::empty({M, N}, x.options().dtype(out_f32 ? at::kFloat : at::kHalf));
+                    if (img) {
+                        std::vector<uint32_t> cm(colmax->begin(), colmax->end());
+                        check(pbl_gemm_f16_image(&L, xc.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, image->data_ptr(), size_t(image->numel()),
+                                                 cm.data(), stream_of(x)), "gemm_f16_image");
+                    } else {
+                        const size_t nb = pbl_gemm_workspace_bytes(&L, int(M));
+                        at::Tensor ws;
+                        if (nb) ws = at::empty({int64_t(nb)}, x.options().dtype(at::kByte));
+                        check(pbl_gemm_f16_ws(&L, xc.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, nb ? ws.data_ptr() : nullptr, nb, stream_of(x)),
+                              "gemm_f16");
+                    }
+                    return y.reshape(shape);
+                }
+            }
+        }
+        return dense_path(wdt);
+    }
+    if (xt == at::kHalf) return run_small(L, x2.contiguous(), M, out_f32).reshape(shape);
+    if (xt == at::kBFloat16) {
+        // see pb_llm_amd/quant.py (_pb_linear_forward, bf16): range check with one host sync (never under capture) -> dense path
+        // for out-of-range / non-finite inputs; else per-token power-of-two scaling on the device, exact for all finite inputs
+        const bool capturing = c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
+        if (bf16_range_check && !capturing && !x2.abs().le(65504.0).all().item<bool>()) return dense_path(at::kFloat);
+        const at::Tensor xf = x2.to(at::kFloat);
+        const at::Tensor amax = xf.abs().amax({1}, true);
+        const at::Tensor e = amax.view(at::kInt).bitwise_right_shift(23).bitwise_and(0xFF).sub(127 + 14).clamp_min(0);
+        const at::Tensor sc = at::ldexp(at::ones_like(amax), e.neg());
+        at::Tensor y = run_small(Lnb, xf.mul(sc).to(at::kHalf).contiguous(), M, true).div(sc);
+        y = at::where(at::isfinite(amax), y, at::full_like(y, std::numeric_limits<float>::quiet_NaN()));
+        if (has_bias) y = y.add(*bias);
+        return y.to(out_dt).reshape(shape);
+    }
+    // fp32 activations: x = x_hi + x_lo with both terms fp16; the kernels are linear in x, so y = W x_hi + W x_lo accumulated in
+    // fp32 (bias added once)
+    const at::Tensor x_hi = x2.to(at::kHalf);
+    const at::Tensor x_lo = x2.sub(x_hi.to(at::kFloat)).to(at::kHalf);
+    const at::Tensor yy = run_small(Lnb, at::cat({x_hi, x_lo}, 0).contiguous(), 2 * M, true);
+    at::Tensor y = yy.narrow(0, 0, M).add(yy.narrow(0, M, M));
+    if (has_bias) y = y.add(*bias);
+    return y.to(out_dt).reshape(shape);
+}
+
+at::Tensor linear_meta(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
+                       int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
+                       const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> colmax, c10::string_view backend,
+                       bool bf16_range_check) {
+    TORCH_CHECK(x.dim() >= 1 && x.size(-1) == K, "pbllm_native.linear: in_features mismatch: x has ", x.size(-1), ", layer has ", K);
+    std::vector<int64_t> shape(x.sizes().begin(), x.sizes().end());
+    shape.back() = N;
+    return at::empty(shape, x.options().dtype(out_f32 ? at::kFloat : x.scalar_type()));
+}
+
+// the frozen packed weight is differentiable in x: dx = dy @ W, W re-unpacked in the backward (nothing dense is saved)
+class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
+ public:
+    static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& blob, const c10::optional<at::Tensor>& bias,
+                              int64_t N, int64_t K, int64_t P, int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32,
+                              bool dense_f16, const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> colmax, std::string backend,
+                              bool bf16_range_check) {
+        ctx->saved_data["blob"] = blob;
+        ctx->saved_data["meta"] = std::vector<int64_t>{N, K, P, G, NRB, flags, max_nch, max_nexc};
+        ctx->saved_data["xdt"] = int64_t(x.scalar_type());
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("pbllm_native::linear", "")
+                             .typed<at::Tensor(const at::Tensor&, const c10::optional<at::Tensor>&, const at::Tensor&, int64_t, int64_t, int64_t, int64_t,
+                                               int64_t, int64_t, int64_t, int64_t, bool, bool, const c10::optional<at::Tensor>&,
+                                               c10::OptionalArrayRef<int64_t>, c10::string_view, bool)>();
+        return op.call(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, colmax, backend, bf16_range_check);
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
+        const at::Tensor dy = grads[0];
+        const at::Tensor blob = ctx->saved_data["blob"].toTensor();
+        const auto m = ctx->saved_data["meta"].toIntVector();
+        const auto xdt = at::ScalarType(ctx->saved_data["xdt"].toInt());
+        const c10::DeviceGuard guard(dy.device());
+        const pbl_layer L = make_layer(blob, c10::nullopt, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], false);
+        const auto wdt = (dy.scalar_type() == at::kHalf && (m[5] & PBL_FLAG_SAL_F16)) ? at::kHalf : at::kFloat;
+        const at::Tensor W = unpack(L, dy, wdt);
+        std::vector<int64_t> shape(dy.sizes().begin(), dy.sizes().end());
+        shape.back() = m[1];
+        const at::Tensor dx = dy.reshape({-1, m[0]}).to(wdt).matmul(W).reshape(shape).to(xdt);
+        torch::autograd::variable_list out(17);
+        out[0] = dx;
+        return out;
+    }
+};
+
+at::Tensor linear_autograd(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
+                           int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
+                           const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> colmax, c10::string_view backend,
+                           bool bf16_range_check) {
+    return PBLinearFn::apply(x, blob, bias, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, colmax, std::string(backend),
+                             bf16_range_check);
 }
 
 }  // namespace
 
 TORCH_LIBRARY(pbllm_native, m) {
-    m.def("linear(Tensor blob, Tensor? bias, Tensor x, int N, int K, int P, int G, int NRB, int flags, int max_nch, int max_nexc, bool out_f32) -> Tensor");
+    m.def("linear(Tensor blob, Tensor? bias, Tensor x, int N, int K, int P, int G, int NRB, int flags, int max_nch, int max_nexc, bool out_f32, "
+          "bool dense_f16=True, Tensor? image=None, int[]? colmax=None, str backend=\"auto\", bool bf16_range_check=True) -> Tensor");
 }
-TORCH_LIBRARY_IMPL(pbllm_native, CUDA, m) { m.impl("linear", pbl_native_linear); }
+TORCH_LIBRARY_IMPL(pbllm_native, CUDA, m) { m.impl("linear", linear_cuda); }
+TORCH_LIBRARY_IMPL(pbllm_native, Meta, m) { m.impl("linear", linear_meta); }
+TORCH_LIBRARY_IMPL(pbllm_native, Autograd, m) { m.impl("linear", linear_autograd); }

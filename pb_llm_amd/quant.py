@@ -41,17 +41,17 @@ class BinaryInterface:
 # Layers the matrix-core kernel cannot take (odd group sizes, K % 8) switch to the dense path at GEMM_THRESHOLD.
 MFMA_MAX = 32
 GEMM_THRESHOLD = 12
-# GEMM regime backend (rows > 32: prefill).  Two complete implementations; `GEMM_BACKEND` picks one:
+# GEMM regime backend (rows > 32: prefill).  Two complete implementations; `GEMM_BACKEND` picks:
+#   "auto"     (default since round 4) the hand-written kernel over the layer's GEMM image (pbl_gemm_f16_image,
+#              csrc/pbl_gemm_img.hip) wherever the layer has one, the library backend for the rest (a slot with more than 448
+#              entries -- ~20 % salients --, more than 127 half slabs, odd group sizes).  4096^2 x 2048, low_frac 0.95: 64 - 70 us
+#              against 72.5 for unpack + library and 59.7 for the dense library GEMM (profiles/r04_gemm.md).
+#   "fused"    always hand-written: the image kernel, and pbl_gemm_f16_ws (csrc/pbl_gemm_big.hip, round 3; per-call or kept
+#              salient list) for layers without an image.  Never materialises the dense weight.
 #   "library"  pbl_unpack_dev expands the packed layer into a transient dense buffer (2 B per weight, from the caching
-#              allocator) and a library GEMM runs on it.  Default BECAUSE IT IS FASTER on MI355X at the llama shapes:
-#              seq 2048, low_frac 0.95: 4096^2 76 us, 11008x4096 188, 4096x11008 187; llama-7b-shaped forward 45.2 ms
-#              (dense fp16 39.4) -- gpurun_out/r3i, profiles/r03_gemm.md.
-#   "fused"    pbl_gemm_f16_ws (csrc/pbl_gemm_big.hip): the hand-written kernel that rebuilds fp16 weight tiles in LDS from
-#              the packed records and never materialises the dense weight; its only scratch is 4 B per SALIENT entry.  Any
-#              layer kind (see fused_gemm_ok), fp16 activations, fp16 or fp32 result.  Round 3: 91 / 243 / 217 us on the
-#              same shapes (round 2: 120 / 344 / 327), forward 57 ms.  Use it where the dense copy must not exist.
+#              allocator) and a library GEMM runs on it (the default through round 3).
 # fp32 / bf16 activations, an fp32 dense dtype, odd group sizes and K % 8 != 0 always take the library path.
-GEMM_BACKEND = os.environ.get("PBL_GEMM_BACKEND", "library")
+GEMM_BACKEND = os.environ.get("PBL_GEMM_BACKEND", "auto")
 # bf16 activations at <= 32 rows run as ONE fp16 pass (bf16 -> fp16 is exact inside fp16's range).  BF16_RANGE_CHECK (default
 # since round 4): check the range first (one device -> host sync per call, ~10 us) and send out-of-range / non-finite inputs
 # through the dense path, so that large values and inf / NaN behave exactly as in the reference's bf16 F.linear at every token
@@ -61,6 +61,10 @@ GEMM_BACKEND = os.environ.get("PBL_GEMM_BACKEND", "library")
 # salients, 2.6 GB for a 7B model at 10 %) next to its blob instead of rebuilding it on every call: the perplexity loops call the
 # same linears batch after batch (gptq_pb/eval_ppl_utils.py:55-64).  4096^2 x 2048: 81 us instead of 90 (profiles/r03_gemm.md).
 GEMM_KEEP_LIST = os.environ.get("PBL_GEMM_KEEP_LIST", "0") == "1"
+# fused backend, round 4: multiply from the layer's GEMM image (pbl_gemm_f16_image), built on the first prefill call and kept with
+# the layer (1 KiB per 16 rows x 128 columns: 8.4 MB for a 4096^2 layer at 5 % salients, a quarter of the dense fp16 weight).
+# "0": the round-3 kernel over the per-call (or kept) salient list.
+GEMM_KEEP_IMAGE = os.environ.get("PBL_GEMM_KEEP_IMAGE", "1") == "1"
 BF16_RANGE_CHECK = os.environ.get("PBL_BF16_RANGE_CHECK", "1") == "1"
 
 
@@ -73,7 +77,7 @@ def fused_gemm_ok(packed: PackedWeight) -> bool:
 
 
 def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False, workspace: bool = True,
-                       prepared: torch.Tensor | None = None) -> torch.Tensor:
+                       prepared: torch.Tensor | None = None, image: "GemmImage | None" = None) -> torch.Tensor:
     """pbl_gemm_f16_ws: x2 [M, K] fp16 contiguous -> [M, N] fp16 (fp32 with out_f32); raises PblError(UNSUPPORTED) for layers
     it does not take.  workspace: hand the kernel the transient scratch it asks for (more than one 256-token tile: the
     salient entries are decoded once per call by a small kernel ahead of the GEMM; 4 B per entry from the caching allocator,
@@ -84,6 +88,12 @@ def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32
     y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
     layer = packed.layer_struct(bias_f32)
     L = _lib.lib()
+    if image is not None:                  # pbl_gemm_f16_image: the round-4 kernel over the layer's GEMM image
+        cur = torch.cuda.current_stream(x2.device)
+        cur.wait_event(image.ready)        # (a no-op on the building stream; orders a call from any other stream behind the build)
+        _lib.check(L.pbl_gemm_f16_image(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), image.data.data_ptr(),
+                                        image.data.numel(), image.colmax, cur.cuda_stream), "gemm_f16_image")
+        return y
     if prepared is not None:
         _lib.check(L.pbl_gemm_f16_prepared(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), prepared.data_ptr(), prepared.numel(),
                                            torch.cuda.current_stream(x2.device).cuda_stream), "gemm_f16_prepared")
@@ -107,6 +117,74 @@ def gemm_list(packed: PackedWeight) -> torch.Tensor | None:
     ws = torch.empty(nb, dtype=torch.uint8, device=packed.blob.device)
     _lib.check(L.pbl_gemm_prepare(C.byref(layer), ws.data_ptr(), nb, torch.cuda.current_stream(packed.blob.device).cuda_stream), "gemm_prepare")
     return ws
+
+
+class GemmImage:
+    """The per-layer GEMM image of a packed weight (csrc/pbl_gemm_img.hip, pbl_gemm_image_build): what the prefill path multiplies
+    from.  `data`: uint8 tensor on the blob's device; `colmax`: per 128-column half slab the largest entry count of any record
+    (host array: it sizes the slots and travels with every call); `ready`: an event recorded on the building stream behind the
+    build kernel -- a call from another stream waits on it."""
+    __slots__ = ("data", "colmax", "ready", "colmax_list")
+
+    def __init__(self, data, colmax, ready):
+        self.data, self.colmax, self.ready = data, colmax, ready
+        self.colmax_list = list(colmax)                  # (the native operator takes an int list)
+
+    @property
+    def max_entries(self) -> int:
+        return max(self.colmax) if len(self.colmax) else 0
+
+
+def gemm_image(packed: PackedWeight) -> GemmImage | None:
+    """Build the layer's GEMM image: pbl_gemm_image_stats (one small kernel + ONE read-back of ceil(K / 128) words, the only host
+    sync), then pbl_gemm_image_build.  None: the layer has no image (K % 8, more than 127 half slabs, odd group size, a slot with
+    more than 704 entries) -- pbl_gemm_f16_ws serves it."""
+    layer = packed.layer_struct(None)
+    L = _lib.lib()
+    dev = packed.blob.device
+    NH = (packed.K + 127) // 128
+    st = torch.cuda.current_stream(dev).cuda_stream
+    mx = torch.zeros(max(NH, 1), dtype=torch.int32, device=dev)
+    if L.pbl_gemm_image_stats(C.byref(layer), mx.data_ptr(), st) != 0:
+        return None
+    colmax = (C.c_uint32 * NH)(*mx.cpu().tolist()[:NH])
+    nb = int(L.pbl_gemm_image_bytes(C.byref(layer), colmax))
+    if not nb:
+        return None
+    data = torch.empty(nb, dtype=torch.uint8, device=dev)
+    _lib.check(L.pbl_gemm_image_build(C.byref(layer), colmax, data.data_ptr(), nb, st), "gemm_image_build")
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return GemmImage(data, colmax, ev)
+
+
+_CU_COUNT: dict = {}
+
+
+def _image_fills_the_chip(N: int, M: int, device) -> bool:
+    """backend "auto": the image kernel works in tiles of 128 rows x 256 tokens, one per CU and round; a last round that leaves
+    more than ~8 % of the chip idle costs more than the kernel gains over unpack + library (measured: 11008 x 4096 at 2048 rows is
+    688 tiles = 2.69 rounds of 256 CUs: 197 - 200 us against 187 - 189; 4096 x 4096 and 4096 x 11008 are exactly one round: 69 - 70
+    against 74 - 77 and 172 - 177 against 185; profiles/r04_gemm.md).  Such shapes take the library backend."""
+    idx = torch.device(device).index or 0
+    cus = _CU_COUNT.get(idx)
+    if cus is None:
+        cus = _CU_COUNT[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    tiles = ((N + 127) // 128) * ((M + 255) // 256)
+    rounds = (tiles + cus - 1) // cus
+    return tiles >= 0.92 * rounds * cus
+
+
+def _kept_image(packed: PackedWeight) -> GemmImage | None:
+    """the layer's GEMM image, built on first use and kept with the PackedWeight until its blob changes (GEMM_KEEP_IMAGE)"""
+    key = (packed.blob.data_ptr(), packed.blob._version)
+    kept = getattr(packed, "_gemm_image", None)
+    if kept is None or kept[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                  # (the build reads a word back: never under capture; the per-call path serves)
+        kept = (key, gemm_image(packed))
+        packed._gemm_image = kept
+    return kept[1]
 
 
 def _kept_list(packed: PackedWeight) -> torch.Tensor | None:
@@ -184,15 +262,26 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     the GPU, fp16 (native) or fp32/bf16 (split into two fp16 terms, fp32 output).
     out_f32: return the fp32 accumulator unrounded (tensor-parallel partial sums).
     Differentiable in x (see _PackedLinearFn); the kernels themselves never run under autograd."""
+    nat = _lib.native_linear()
+    if nat is not None and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16, torch.float32) and x.shape[-1] == packed.K \
+            and packed.blob.device == x.device:
+        # ONE native call (csrc/pbl_torch.cpp) for every row count and activation dtype: routing, output / workspace allocation,
+        # stream lookup, bf16 / fp32 handling, the autograd formula (dx = dy @ W) all live in the operator.  Python only decides
+        # whether the GEMM regime multiplies from the layer's kept GEMM image.
+        dense_f16 = dense_dtype in (None, torch.float16)
+        img, colmax, backend = None, None, GEMM_BACKEND
+        M = x.numel() // packed.K
+        if M > MFMA_MAX and backend != "library" and x.dtype == torch.float16 and dense_f16 and GEMM_KEEP_IMAGE \
+                and fused_gemm_ok(packed) and (backend == "fused" or _image_fills_the_chip(packed.N, M, x.device)):
+            ki = _kept_image(packed)
+            if ki is not None:
+                torch.cuda.current_stream(x.device).wait_event(ki.ready)
+                img, colmax = ki.data, ki.colmax_list
+        return nat(packed.blob, bias_f32, x, packed.N, packed.K, packed.P, packed.G, packed.NRB, packed.flags,
+                   packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, colmax, backend, BF16_RANGE_CHECK)
+    # the ctypes route (variant libraries through PBL_LIB, PBL_NATIVE=0, a dispatcher that did not build)
     if torch.is_grad_enabled() and x.requires_grad:
         return _PackedLinearFn.apply(x, (packed, bias_f32), out_f32, dense_dtype)
-    if x.dtype == torch.float16 and x.is_cuda and 0 < x.numel() <= MFMA_MAX * packed.K:
-        nat = _lib.native_linear()                   # decode regime: one native call (csrc/pbl_torch.cpp)
-        # (layers the matrix-core kernel does not take -- odd group sizes, K % 8 -- leave the GEMV for the dense path at
-        # GEMM_THRESHOLD rows: _pb_linear_forward decides)
-        if nat is not None and (x.numel() < GEMM_THRESHOLD * packed.K or _mfma_ok(packed)):
-            return nat(packed.blob, bias_f32, x, packed.N, packed.K, packed.P, packed.G, packed.NRB, packed.flags,
-                       packed.max_nch, packed.max_nexc, out_f32)
     with torch.no_grad():
         return _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype)
 
@@ -227,10 +316,15 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         # reference executes (F.linear over the dense fake-quant weight).  fp16 weights when
         # the layer is fp16-exact (packed from an fp16 checkpoint), else fp32.
         wdt = torch.float16 if (x.dtype == torch.float16 and dense_dtype in (None, torch.float16)) else torch.float32
-        if GEMM_BACKEND == "fused" and wdt == torch.float16 and fused_gemm_ok(packed):
+        if GEMM_BACKEND in ("auto", "fused") and wdt == torch.float16 and fused_gemm_ok(packed) and \
+                (GEMM_BACKEND == "fused" or _image_fills_the_chip(packed.N, M, x.device)):
             xc = x2.contiguous()
             if xc.data_ptr() % 16 == 0:
-                return fused_gemm_forward(packed, bias_f32, xc, out_f32, prepared=_kept_list(packed) if GEMM_KEEP_LIST else None).reshape(*lead, packed.N)
+                img = _kept_image(packed) if GEMM_KEEP_IMAGE else None
+                if img is not None:
+                    return fused_gemm_forward(packed, bias_f32, xc, out_f32, image=img).reshape(*lead, packed.N)
+                if GEMM_BACKEND == "fused":
+                    return fused_gemm_forward(packed, bias_f32, xc, out_f32, prepared=_kept_list(packed) if GEMM_KEEP_LIST else None).reshape(*lead, packed.N)
         W = unpack_on_device(packed, wdt)
         y = torch.nn.functional.linear(x2.to(wdt), W, None if bias_f32 is None else bias_f32.to(wdt))
         y = y.float() if out_f32 else y.to(x.dtype)
@@ -407,6 +501,10 @@ class PBLinear(nn.Module, BinaryInterface):
     def forward(self, x):
         if torch.compiler.is_compiling():
             m = self._meta          # (the tracer cannot read tensor version counters; the header fields are constants of the module)
+            if _lib.native_linear() is not None:     # the native operator has a Meta kernel: traced as one node
+                return torch.ops.pbllm_native.linear(self.pbl_blob, self.pbl_bias, x, m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch,
+                                                     m.max_nexc, False, self.weight_dtype == torch.float16, None, None,
+                                                     "library" if GEMM_BACKEND == "auto" else GEMM_BACKEND, BF16_RANGE_CHECK)
             return torch.ops.pbllm.linear(self.pbl_blob, self.pbl_bias, x,
                                           [m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch, m.max_nexc, m.nnz, m.nexc],
                                           self.weight_dtype == torch.float16, False)

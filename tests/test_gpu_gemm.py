@@ -111,6 +111,15 @@ def test_gemm_regime_kernel(N, K, M, gs, lf, fp16, exc, metric):
     if lst is not None:
         assert torch.equal(y, Q.fused_gemm_forward(pd, T(b), xt, prepared=lst))
         assert torch.equal(y32[:33], Q.fused_gemm_forward(pd, None, xt[:33].contiguous(), out_f32=True, prepared=lst))
+    # round 4: the kernel over the layer's GEMM image (pbl_gemm_f16_image) -- what the prefill path runs by default -- agrees with
+    # the round-3 kernel bit for bit (same fp16 tiles, same k order per accumulator), for any M
+    img = Q.gemm_image(pd)
+    mx = int(pd.layer_struct(None).max_nch)                      # (no image: a slot with more than 448 entries, or more than 127 half slabs)
+    assert img is not None or K > 16256 or lf <= 0.85 or metric == "hessian", mx
+    if img is not None:
+        assert torch.equal(y, Q.fused_gemm_forward(pd, T(b), xt, image=img))
+        assert torch.equal(y32, Q.fused_gemm_forward(pd, None, xt, out_f32=True, image=img))
+        assert torch.equal(y32[:33], Q.fused_gemm_forward(pd, None, xt[:33].contiguous(), out_f32=True, image=img))
     # the library backend on the unpacked layer: same operands, different summation order
     Wdev = Q.unpack_on_device(pd, torch.float16)
     np.testing.assert_array_equal(Wdev.float().cpu().numpy()[rows], W16[rows])
@@ -162,24 +171,42 @@ def test_gemm_regime_properties_at_full_size():
     assert torch.equal(z, b.expand(64, N))
 
 
-def test_kept_salient_list_follows_the_blob():
-    """quant.GEMM_KEEP_LIST: the fused backend keeps a layer's salient list between calls (perplexity loops); same results bit for
-    bit, built once, rebuilt when the blob is written in place (its version counter moves)."""
+def test_kept_image_and_kept_list_follow_the_blob():
+    """the fused backend keeps a layer's GEMM image (quant.GEMM_KEEP_IMAGE, the default) -- or, with it off, its salient list
+    (quant.GEMM_KEEP_LIST) -- between calls (perplexity loops): same results bit for bit as the per-call path, built once,
+    rebuilt when the blob is written in place (its version counter moves); a call from another stream waits for the build."""
     p, Wd = rtn_layer(512, 1024, -1, seed=7, low_frac=0.9, fp16=True, exceptions=1)
     layer = Q.PBLinear(p.to(DEV), T(synth.normal((512,), 3, 3, 0.1)))
     x = T(synth.activations((300, 1024), 8, 21))
-    old = (Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST)
+    old = (Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE)
     try:
-        Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST = "fused", False
+        Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = "fused", False, False
         ref = layer(x)
+        # the kept LIST is the ctypes route's option (round 3; the native operator builds the list per call when there is no image)
+        run = lambda xin: Q._pb_linear_forward(layer.packed, layer.pbl_bias, xin, False, torch.float16)       # noqa: E731
+        assert torch.equal(run(x), ref)
         Q.GEMM_KEEP_LIST = True
-        assert torch.equal(layer(x), ref)
+        assert torch.equal(run(x), ref)
         kept = layer.packed._gemm_list
-        assert torch.equal(layer(x[:40]), ref[:40]) and layer.packed._gemm_list is kept          # one list, any M
+        assert torch.equal(run(x[:40]), ref[:40]) and layer.packed._gemm_list is kept               # one list, any M
         layer.pbl_blob.add_(0)                                                                     # written in place
-        assert torch.equal(layer(x), ref) and layer.packed._gemm_list[0] != kept[0]
+        assert torch.equal(run(x), ref) and layer.packed._gemm_list[0] != kept[0]
+        for backend in ("fused", "auto"):
+            Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = backend, False, True
+            assert torch.equal(layer(x), ref)
+            kimg = layer.packed._gemm_image
+            assert kimg[1] is not None and kimg[1].max_entries > 0
+            assert torch.equal(layer(x[:40]), ref[:40]) and layer.packed._gemm_image is kimg      # one image, any M
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ys = layer(x)
+            torch.cuda.current_stream().wait_stream(side)
+            assert torch.equal(ys, ref)
+            layer.pbl_blob.add_(0)
+            assert torch.equal(layer(x), ref) and layer.packed._gemm_image[0] != kimg[0]
     finally:
-        Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST = old
+        Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = old
 
 
 def test_gemm_regime_fully_binarized_layer_in_list_mode():
@@ -201,3 +228,25 @@ def test_gemm_regime_fully_binarized_layer_in_list_mode():
     assert lst is not None and lst.numel() > 0
     assert torch.equal(y, Q.fused_gemm_forward(pd, None, T(x), prepared=lst))
     assert torch.equal(y, Q.fused_gemm_forward(pd, None, T(x), workspace=False))
+    img = Q.gemm_image(pd)
+    assert img is not None and img.max_entries == 0
+    assert torch.equal(y, Q.fused_gemm_forward(pd, None, T(x), image=img))
+
+
+def test_image_kernel_repeatedly_against_the_round3_kernel_at_full_size():
+    """the image kernel's waves hand stages over with counted waits and one barrier per 64-column step; a count that is too lax
+    shows up as a RARE wrong tile (round 4: 2 of 256 workgroups in one of two layers, found by the config-3 test).  The full-size
+    hessian down_proj layer, 2048 rows, 25 launches back to back: every one bit-identical to the round-3 kernel's result."""
+    from cfg_shapes import hessian_layer
+    N, K, M = 4096, 11008, 2048
+    W, mask, r = hessian_layer(N, K, 0.95, seed=302)
+    layer = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+    p = layer.packed
+    x = T(synth.activations((M, K), 77, 21))
+    img = Q.gemm_image(p)
+    assert img is not None
+    ref = Q.fused_gemm_forward(p, None, x)
+    outs = [Q.fused_gemm_forward(p, None, x, image=img) for _ in range(25)]
+    torch.cuda.synchronize()
+    bad = [i for i, y in enumerate(outs) if not torch.equal(y, ref)]
+    assert not bad, f"launches {bad} differ from the round-3 kernel"

@@ -517,8 +517,42 @@ def test_torch_compile_traces_pbllm_linear_op(llama7b_qproj):
         eager = blk(x)
         out = torch.compile(blk, backend=backend, fullgraph=True)(x)
         out2 = torch.compile(blk, backend="aot_eager", fullgraph=True)(x)
-    assert any("pbllm.linear" in t for t in seen), seen
+    assert any("pbllm_native.linear" in t for t in seen), seen          # the NATIVE operator (Meta kernel for tracing), one node
     assert torch.equal(out, eager) and torch.equal(out2, eager)
+
+
+def test_native_operator_all_regimes_and_input_gradient(llama7b_qproj):
+    """torch.ops.pbllm_native.linear (csrc/pbl_torch.cpp) serves every row count and activation dtype, and equals the ctypes
+    route (quant._pb_linear_forward) on the same inputs -- bit for bit where both run the same kernels; its Autograd kernel
+    gives dx = dy @ W like the reference's fake-quant nn.Linear."""
+    W, mask, r = llama7b_qproj
+    lin = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), torch.from_numpy(synth.normal((4096,), 3, 3, 0.1)), torch.from_numpy(mask), -1,
+                                r["hscale"], r["hzero"]).to(DEV)
+    from pb_llm_amd import _lib
+    assert _lib.native_linear() is not None
+    p, b = lin.packed, lin.pbl_bias
+    for M in (1, 3, 12, 32, 33, 300):
+        for dt in (torch.float16, torch.bfloat16, torch.float32):
+            x = T(synth.activations((M, 4096), 50 + M, 21)).to(dt)
+            for f32 in (False, True):
+                with torch.no_grad():
+                    want = Q._pb_linear_forward(p, b, x, f32, None)
+                got = Q.pb_linear_forward(p, b, x, out_f32=f32)
+                assert got.dtype == want.dtype and got.shape == want.shape
+                if M <= 32 or dt != torch.float16:
+                    assert torch.equal(got, want), (M, dt, f32)                   # same kernels / same library calls on both routes
+                else:                                                            # > 32 fp16 rows: the image kernel vs the ctypes route's choice
+                    assert O.parity_errors(got.float().cpu().numpy(), want.float().cpu().numpy().astype(np.float64))[0] < 2e-3
+    # input gradient through the operator's Autograd kernel
+    Wd = lin.weight.float()
+    for M, dt in ((2, torch.float16), (40, torch.float16), (5, torch.float32)):
+        x = T(synth.activations((M, 4096), 7, 21)).to(dt).requires_grad_(True)
+        y = lin(x)
+        assert y.requires_grad
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        ref = (dy.float() @ Wd)
+        assert O.parity_errors(x.grad.float().cpu().numpy(), ref.cpu().numpy().astype(np.float64))[0] < 2e-3
 
 
 def test_bf16_activations_out_of_fp16_range():

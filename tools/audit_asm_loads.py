@@ -107,6 +107,160 @@ def audit(lines):
     return problems, nloads
 
 
+# ---- round 4: the expanding waves of csrc/pbl_gemm_img.hip ---------------------------------------------------------------------
+# Their slot requests are asm loads in the saddr form (`global_load_dwordx4 v[a:b], vOFF, s[c:d]`), waited for by ONE counted
+# `s_waitcnt vmcnt(10 | 12)` per 64-column step.  A set requested in step q is guaranteed to have landed at the counted wait that
+# closes step q + 2 (the third counted wait behind the request: in-order return, see wait_all in the source) and is used in step
+# q + 4; until it has landed nothing may name its registers.  Walked: prologue, the unrolled 4-step loop body twice, the
+# remainder steps.
+IMG_SRC = os.path.join(REPO, "pb_llm_amd", "csrc", "pbl_gemm_img.hip")
+
+
+def img_kernel_bodies(asm):
+    out = {}
+    for m in re.finditer(r"^(_ZN\S*pbl_gemm_img_kernelILb[01]ELb[01]E\S*):.*?\n(.*?)\.end_amdhsa_kernel", asm, re.S | re.M):
+        out[m.group(1)] = m.group(2).split("\n")
+    return out
+
+
+def audit_img(lines):
+    """forward dataflow over the kernel's control-flow graph.  State: {register: age}, age = vector-memory operations issued since
+    the slot request that writes the register (every x piece `buffer_load ... lds` is one operation, every request block AT LEAST
+    one: a slot has 1 - 5 vectors and the loads a small slot skips only make later ones land EARLIER).  `s_waitcnt vmcnt(10)`
+    lands everything of age >= 10 (in-order return), `vmcnt(0)` everything.  Joins keep the youngest age (conservative).
+    Reported: any instruction that names a register still in flight."""
+    is_req = lambda t: re.match(r"global_load_dwordx[24]\s+v\[\d+:\d+\],\s*v\d+,\s*s\[\d+:\d+\]", t)     # noqa: E731
+    CAP = 14
+    # instructions with their asm-block membership
+    ins, in_a, blk_id = [], False, 0
+    label_at = {}
+    for l in lines:
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_a, blk_id = True, blk_id + 1
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_a = False
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            label_at[m.group(1)] = len(ins)
+            continue
+        if not t or t[0] in ";." or t.startswith("s_nop") and False:
+            continue
+        if re.match(r"^[a-z_]+[a-z0-9_]*\b", t):
+            ins.append((t, blk_id if in_a else 0))
+    n = len(ins)
+    if not any(a and is_req(t) for t, a in ins):
+        return ["no slot requests found: the image kernel is not what this script knows"], 0
+    # local numeric labels inside asm blocks ("1:") never reach here as instructions; branches to them ("1f") are intra-block skips
+    succ = [[] for _ in range(n)]
+    for i, (t, a) in enumerate(ins):
+        op = t.split()[0]
+        m = re.search(r"(\.LBB\d+_\d+)", t)
+        if op == "s_endpgm":
+            continue
+        if op == "s_branch" and m:
+            succ[i].append(label_at[m.group(1)])
+            continue
+        if op.startswith("s_cbranch") and m:
+            succ[i].append(label_at[m.group(1)])
+        if i + 1 < n:
+            succ[i].append(i + 1)
+    state = [None] * n
+    state[0] = {}
+    work = [0]
+    nreq = sum(1 for t, a in ins if a and is_req(t))
+
+    def step(i, st):
+        t, a = ins[i]
+        op = t.split()[0]
+        st = dict(st)
+        if a and is_req(t):
+            first_of_block = not (i and ins[i - 1][1] == a and any(is_req(ins[k][0]) for k in range(i - 1, -1, -1) if ins[k][1] == a))
+            if first_of_block:
+                st = {r: min(CAP, g + 1) for r, g in st.items()}
+            for r in regs(t[len(op):].split(",")[0]):
+                st[r] = 0
+            return st
+        if op.startswith("buffer_load") and " lds" in t:
+            st = {r: min(CAP, g + 1) for r, g in st.items()}
+            st["x pieces of this step"] = 0                     # (pseudo register: the youngest x piece issued since the last barrier)
+            return st
+        if op == "s_waitcnt" and "vmcnt(0)" in t:
+            return {}
+        if a and op == "s_waitcnt" and "vmcnt(10)" in t:
+            return {r: g for r, g in st.items() if g < 10}
+        if op == "s_barrier":
+            # the barrier publishes the x pieces issued BEFORE the previous barrier: they must have landed by now (the race the
+            # config-3 test found with a wait that was too lax); this step's pieces become "the previous step's"
+            cur = st.pop("x pieces of this step", None)
+            if cur is not None:
+                st["x pieces of the previous step (in flight at the barrier that publishes them)"] = cur
+            return st
+        return st
+
+    while work:
+        i = work.pop()
+        out = step(i, state[i])
+        for j in succ[i]:
+            if state[j] is None:
+                state[j] = dict(out)
+                work.append(j)
+            else:
+                new = dict(state[j])
+                changed = False
+                for r, g in out.items():
+                    if r not in new or g < new[r]:
+                        new[r] = g
+                        changed = True
+                if changed:
+                    state[j] = new
+                    work.append(j)
+    problems = []
+    for i, (t, a) in enumerate(ins):
+        if state[i] is None:
+            continue
+        op = t.split()[0]
+        if a and (is_req(t) or (op == "s_waitcnt")):
+            if is_req(t):
+                bad = sorted(r for r in regs(t[len(op):].split(",")[1]) if r in state[i])      # (the offset register; the destination is re-requested)
+                if bad:
+                    problems.append((i, t, bad))
+            continue
+        if a and op in ("s_cmp_lt_u32", "s_cbranch_scc1"):
+            continue
+        if op == "s_barrier":
+            key = "x pieces of the previous step (in flight at the barrier that publishes them)"
+            if key in state[i]:
+                problems.append((i, t, [key, f"age {state[i][key]}"]))
+            continue
+        bad = sorted(r for r in regs(t) if r in state[i])
+        if bad:
+            problems.append((i, t, bad))
+    return problems, nreq
+
+
+def main_img():
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.check_call([HIPCC, "-std=c++17", "-O3", "--offload-arch=gfx950", "--cuda-device-only", "-S", IMG_SRC, "-o", out],
+                              stderr=subprocess.DEVNULL)
+        asm = open(out).read()
+    bodies = img_kernel_bodies(asm)
+    if not bodies:
+        print("no image kernels found in the assembly")
+        return 1
+    rc = 0
+    for name, lines in sorted(bodies.items()):
+        problems, nloads = audit_img(lines)
+        print(f"{name[:70]}...: {nloads} slot requests walked, {len(problems)} touches of in-flight registers")
+        for p in problems[:20]:
+            print("   ", p)
+            rc = 1
+    return rc
+
+
 def main():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
@@ -128,4 +282,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main() | main_img())

@@ -20,7 +20,8 @@ def measure():
     res = {"native_dispatcher": _lib.native_linear() is not None}
     for M in (1, 4, 16):
         x = torch.from_numpy(synth.activations((M, K), 5, 21)).to("cuda:0")
-        for name, fn in (("pb", lambda: layer(x)), ("dense", lambda: dense(x))):
+        xb = x.bfloat16()
+        for name, fn in (("pb", lambda: layer(x)), ("pb_bf16", lambda: layer(xb)), ("dense", lambda: dense(x))):
             with torch.no_grad():
                 for _ in range(200): fn()
                 torch.cuda.synchronize()

@@ -78,16 +78,15 @@ with torch.no_grad():
 out["logits_rel_max_diff_vs_dense"] = float((got - ref).abs().max() / ref.abs().max())
 if "prefill" in MODES:
     from pb_llm_amd import quant as Qm
-    for backend in ("library", "fused"):
+    for backend in ("library", "auto"):
         Qm.GEMM_BACKEND = backend
         t = timeit(lambda: model(ids))
         out[f"prefill_pb_{backend}_ms"] = round(t * 1e3, 2)
         out[f"prefill_tokens_per_s_pb_{backend}"] = round(SEQ / t)
-    Qm.GEMM_BACKEND, Qm.GEMM_KEEP_LIST = "fused", True       # salient lists kept per layer (4 B per salient entry)
-    t = timeit(lambda: model(ids))
-    out["prefill_pb_fused_kept_list_ms"] = round(t * 1e3, 2)
-    Qm.GEMM_KEEP_LIST = False
-    Qm.GEMM_BACKEND = "library"
+    imgs = [getattr(m_.packed, "_gemm_image", (None, None))[1] for m_ in model.modules() if isinstance(m_, PBLinear)]
+    out["layers_with_gemm_image"] = sum(1 for i_ in imgs if i_ is not None)
+    out["gemm_image_GB"] = round(sum(i_.data.numel() for i_ in imgs if i_ is not None) / 1e9, 2)
+    Qm.GEMM_BACKEND = "auto"
 if "decode" in MODES:
     out["decode_pb_eager_ms_per_token"] = round(timeit(lambda: model(tok1), 20) * 1e3, 3)
     n = H.fuse_decode_(model)

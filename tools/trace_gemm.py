@@ -16,9 +16,13 @@ M = int(os.environ.get("PBL_BENCH_M", 2048))
 NC = int(os.environ.get("PBL_TRACE_NCONS", 8))          # consumer waves of the build (then the producers)
 NP = int(os.environ.get("PBL_TRACE_NPROD", 4))
 SHAPES = sys.argv[1:] or ["4096x4096:0.95"]
+IMG = os.environ.get("PBL_TRACE_IMG", "0") == "1"         # the round-4 kernel over the GEMM image (4 MFMA + 4 expanding waves)
+if IMG:
+    NC, NP = 4, 4
 L = _lib.lib()
-L.pbl_debug_trace_gemm.restype = None
-L.pbl_debug_trace_gemm.argtypes = [C.c_void_p]
+set_trace = L.pbl_debug_trace_gemm_img if IMG else L.pbl_debug_trace_gemm
+set_trace.restype = None
+set_trace.argtypes = [C.c_void_p]
 
 
 def stats(a):
@@ -38,8 +42,11 @@ for t in SHAPES:
     nwg = ((N // 16 + 7) // 8) * ((M + 255) // 256)
     trace = torch.zeros(nwg * 16 * 16, dtype=torch.int64, device="cuda:0")
     run = lambda: Q.fused_gemm_forward(layer.packed, None, x, prepared=lst)
+    if IMG:
+        img = Q.gemm_image(layer.packed)
+        run = lambda: Q.fused_gemm_forward(layer.packed, None, x, image=img)
     # warm: sustained launches without the probe buffer (the stamps are skipped), then ONE traced launch in the same stream
-    L.pbl_debug_trace_gemm(None)
+    set_trace(None)
     import time
     t0 = time.time()
     while time.time() - t0 < float(os.environ.get("PBL_BENCH_PREHEAT_S", 1.0)):
@@ -50,16 +57,16 @@ for t in SHAPES:
     for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
     us_plain = e0.elapsed_time(e1) * 1e3 / 20
-    L.pbl_debug_trace_gemm(trace.data_ptr())
+    set_trace(trace.data_ptr())
     for _ in range(3): run()                      # the last launch's stamps survive
     torch.cuda.synchronize()
-    L.pbl_debug_trace_gemm(None)
+    set_trace(None)
     tr = trace.cpu().numpy().reshape(nwg, 16, 16).astype(np.int64)
     tr = tr[:, :NC + NP]
     rt = tr[..., 0:8:2].astype(np.float64) * 0.01          # us (100 MHz)
     ct = tr[..., 1:8:2].astype(np.float64)
     t_first = rt[..., 0].min()
-    out = dict(lib=os.path.basename(os.environ["PBL_LIB"]), shape=shp, low_frac=lf, M=M, us_per_call_events=round(us_plain, 1), workgroups=nwg)
+    out = dict(lib=os.path.basename(os.environ["PBL_LIB"]) + ("/img" if IMG else ""), shape=shp, low_frac=lf, M=M, us_per_call_events=round(us_plain, 1), workgroups=nwg)
     span = rt[..., 3].max() - t_first
     out["kernel_span_us"] = round(float(span), 2)
     dt = rt[..., 3] - rt[..., 0]; dc = ct[..., 3] - ct[..., 0]
