@@ -241,7 +241,7 @@ def main():
                          "layer streams per rank (weak scaling, no collective)")
     ap.add_argument("--collective", choices=["rccl", "p2p"], default="rccl",
                     help="tp all-reduce: RCCL (torch.distributed) or libpbl's one-shot peer-to-peer all-reduce")
-    ap.add_argument("--tp-collectives", choices=["per-layer", "stacked"], default="per-layer",
+    ap.add_argument("--tp-collectives", choices=["per-layer", "stacked", "fused"], default="per-layer",
                     help="tp: per-layer = one all-reduce of [M, N] fp32 per K-split layer (64 per step, 16 KB each at M = 1: what a "
                          "decoder executes); stacked = ONE all-reduce of all K-split partials per step (the easy case)")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
@@ -335,7 +335,24 @@ def main():
         singles = [(PBLinear(p, None), x) for g, _ in groups for p, x in zip(g.packed, g.x)]
     kev = []            # (start, end) events around the GEMV launches of a step (tp only: the timed region also holds the collective)
 
+    fused_tp = tp and a.tp_collectives == "fused" and comm is not None
+    if fused_tp:   # every K-split layer as its own push GEMV + reduce (pbl_linear_f16_push / pbl_p2p_reduce_f32_dev), as a decoder runs them
+        gkq = groups[1][0]
+        yk16 = [torch.empty(a.M, a.N, dtype=torch.float16, device=dev) for _ in gkq.packed]
+
     def step(record=False):
+        if fused_tp:
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            groups[0][0].launch()
+            if record:
+                e1.record()
+                kev.append((e0, e1))
+            for pk, xk, yk in zip(gkq.packed, gkq.x, yk16):
+                if not comm.fused_linear_(pk, None, xk, yk):
+                    raise SystemExit("--tp-collectives fused: the K-split shard is not one GEMV pass")
+            return
         if a.mode == "grouped":
             if record:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -447,7 +464,8 @@ def main():
             nk = len(groups[1][0].packed)
             coll = 'libpbl one-shot p2p' if a.collective == 'p2p' else 'RCCL'
             par = (f"tp{world}: llama mapping, q/k/v/gate/up N-split (no exchange), o/down K-split + " +
-                   (f"{nk} {coll} all-reduces of [{a.M},{a.N}] fp32 per step (one per K-split layer)" if a.tp_collectives == "per-layer"
+                   (f"{nk} fused K-split layers per step (GEMV epilogue pushes the partial to every rank + reduce kernel)" if a.tp_collectives == "fused" else
+                    f"{nk} {coll} all-reduces of [{a.M},{a.N}] fp32 per step (one per K-split layer)" if a.tp_collectives == "per-layer"
                     else f"one {coll} all-reduce of [{nk},{a.M},{a.N}] fp32 per step"))
         else:
             par = f"dp{world} (independent layer streams, no collective)"

@@ -449,6 +449,19 @@ int pbl_p2p_allreduce_f32(void* const* peer_bufs, int rank, int world, float* x,
                           void* stream);
 int pbl_p2p_allreduce_f32_dev(void* const* peer_bufs, int rank, int world, float* x, void* y_f16, size_t n, size_t max_elems,
                               void* stream);
+/* Fused K-split layer (round 4): pbl_linear_f16_push runs this rank's column shard as ONE GEMV pass (M <= 4, group-free layer)
+ * whose row owners write their fp32 partials straight into slot [call & 1][rank] of EVERY rank's communication buffer (7 xGMI
+ * stores + 1 local) and count each finished 16-row record at the peers; pbl_p2p_reduce_f32_dev waits until every rank has
+ * pushed `expect_records` (= layer->NRB) records, sums the slots in rank order into y_f32 and / or y_f16 (either may be NULL) and
+ * publishes the call number (device counted: both launches are hipGraph-capturable and replayable).  Against pbl_linear_f16 +
+ * pbl_p2p_allreduce_f32_dev the partial never makes the round trip through local HBM and the push has no launch of its own.
+ * PBL_ERR_UNSUPPORTED from the push (column groups, more tokens than one pass takes): run the unfused pair.  The bias is added by
+ * rank 0's partial only. */
+int pbl_linear_f16_push(const pbl_layer* layer, const void* x, int M, void* const* peer_bufs, int rank, int world, size_t max_elems,
+                        void* stream);
+int pbl_p2p_reduce_f32_dev(void* const* peer_bufs, int rank, int world, float* y_f32, void* y_f16, size_t n, size_t max_elems,
+                           uint32_t expect_records, void* stream);
+
 int pbl_p2p_check(const void* own_buf);                        /* SYNCHRONOUS debugging aid: 1 if a wait ever timed out */
 
 #ifdef __cplusplus

@@ -54,7 +54,8 @@ EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_pack_d
            "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad",
            "pbl_prep_workspace_bytes", "pbl_kth_pair", "pbl_outlier_mask", "pbl_quant8_rows", "pbl_high_calibrate", "pbl_gptq_block",
            "pbl_p2p_buffer_bytes", "pbl_comm_alloc", "pbl_comm_free", "pbl_ipc_export", "pbl_ipc_open", "pbl_ipc_close",
-           "pbl_p2p_allreduce_f32", "pbl_p2p_allreduce_f32_dev", "pbl_p2p_buffer_bytes_world", "pbl_p2p_check"]
+           "pbl_p2p_allreduce_f32", "pbl_p2p_allreduce_f32_dev", "pbl_p2p_buffer_bytes_world", "pbl_p2p_check",
+           "pbl_linear_f16_push", "pbl_p2p_reduce_f32_dev"]
 
 
 def lib() -> C.CDLL:
@@ -166,6 +167,10 @@ def lib() -> C.CDLL:
     L.pbl_p2p_buffer_bytes_world.argtypes = [sz, C.c_int]
     L.pbl_p2p_check.restype = C.c_int
     L.pbl_p2p_check.argtypes = [vp]
+    L.pbl_linear_f16_push.restype = C.c_int
+    L.pbl_linear_f16_push.argtypes = [C.POINTER(PblLayer), vp, C.c_int, C.POINTER(vp), C.c_int, C.c_int, sz, vp]
+    L.pbl_p2p_reduce_f32_dev.restype = C.c_int
+    L.pbl_p2p_reduce_f32_dev.argtypes = [C.POINTER(vp), C.c_int, C.c_int, vp, vp, sz, sz, u32, vp]
     _lib = L
     return L
 

@@ -25,17 +25,11 @@
 #include <stdint.h>
 
 #include "../../include/pbl.h"
+#include "pbl_p2p_layout.h"
 
 namespace {
 
-constexpr int MAXB = PBL_P2P_MAX_BLOCKS;
-constexpr int MAXW = PBL_P2P_MAX_WORLD;
-// header of a communication buffer: flags[2][MAXW][MAXB] u32 (8 KiB), then the control words, padded to HDR_BYTES
-//   ctl[0] status (1: a wait timed out), ctl[1] seq of the last finished device-counted call, ctl[2] blocks finished in the
-//   running call.  The slots follow: data[2][world][cap] floats (strided by the communicator's world size).
-constexpr size_t HDR_BYTES = 4096;
-
-__host__ __device__ inline size_t flags_bytes() { return size_t(2) * MAXW * MAXB * 4; }
+using namespace pblp2p;   // buffer layout: csrc/pbl_p2p_layout.h (shared with the K-split GEMV's fused push, csrc/pbl_kernels.hip)
 
 struct P2PArgs {
     uint8_t* peer[MAXW];     // this process's mapping of every rank's buffer (peer[rank] = own)
@@ -45,14 +39,6 @@ struct P2PArgs {
     uint32_t seq;            // 0: take the call number from the buffer's own counter (hipGraph-replayable)
     int rank, world, nblk;
 };
-
-__device__ __forceinline__ uint32_t* flag_ptr(uint8_t* buf, int set, int src, int b) {
-    return reinterpret_cast<uint32_t*>(buf) + (size_t(set) * MAXW + src) * MAXB + b;
-}
-__device__ __forceinline__ uint32_t* ctl_ptr(uint8_t* buf) { return reinterpret_cast<uint32_t*>(buf + flags_bytes()); }
-__device__ __forceinline__ float* slot_ptr(uint8_t* buf, int set, int src, int world, size_t cap) {
-    return reinterpret_cast<float*>(buf + HDR_BYTES + flags_bytes()) + (size_t(set) * world + src) * cap;
-}
 
 __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
     __shared__ uint32_t s_seq, s_timeout;
@@ -128,6 +114,61 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
     }
 }
 
+// The second half of a FUSED K-split layer (round 4): the GEMV's row owners have written their fp32 partials straight into every
+// rank's slot [set][rank] and counted their records at count[set][rank] (pbl_linear_f16_push, csrc/pbl_kernels.hip); this
+// kernel only waits until every rank has pushed `expect` records, sums the slots in rank order and publishes the call number.
+// Compared with GEMV -> p2p_allreduce_kernel the partial never makes the round trip through local HBM and the push costs no
+// launch of its own.  The last block to finish zeroes the counters of its set: a peer can only push into this set again after it
+// has seen THIS rank's push of the next call, which comes after this kernel (same argument as for the slots).
+__global__ __launch_bounds__(256) void p2p_reduce_kernel(P2PArgs a, uint32_t expect) {
+    __shared__ uint32_t s_seq, s_timeout;
+    const int b = blockIdx.x;
+    uint8_t* own = a.peer[a.rank];
+    uint32_t* ctl = ctl_ptr(own);
+    if (threadIdx.x == 0) {
+        const uint32_t q = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        s_seq = q ? q : 1u;
+        s_timeout = 0;
+    }
+    __syncthreads();
+    const uint32_t seq = s_seq;
+    const int set = int(seq & 1u);
+    const size_t per = ((a.n + a.nblk - 1) / a.nblk + 3) & ~size_t(3);
+    const size_t lo = size_t(b) * per, hi = lo + per < a.n ? lo + per : a.n;
+    if (int(threadIdx.x) < a.world) {
+        const uint32_t* c = count_ptr(own, set, int(threadIdx.x));
+        const uint64_t t0 = wall_clock64();                                          // 100 MHz
+        while (__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < expect) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > 300000000ull) {                                  // 3 s
+                atomicExch(ctl, 1u);
+                s_timeout = 1;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    const bool bad = s_timeout != 0;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) {
+        float s = 0.f;
+        for (int p = 0; p < a.world; ++p) s += __builtin_nontemporal_load(slot_ptr(own, set, p, a.world, a.cap) + i);
+        if (bad) s = __builtin_nanf("");
+        if (a.x) a.x[i] = s;
+        if (a.y16) a.y16[i] = _Float16(s);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const uint32_t done = atomicAdd(ctl + 2, 1u);
+        if (done == uint32_t(a.nblk) - 1u) {
+            for (int p = 0; p < a.world; ++p) __hip_atomic_store(count_ptr(own, set, p), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(ctl + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctl + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 int launch_allreduce(void* const* peer_bufs, int rank, int world, float* x, void* y16, size_t n, size_t max_elems, uint32_t seq,
                      void* stream) {
     if (!peer_bufs || !x || world < 1 || world > MAXW || rank < 0 || rank >= world || !n) return PBL_ERR_INVALID_ARG;
@@ -194,6 +235,23 @@ int pbl_p2p_allreduce_f32(void* const* peer_bufs, int rank, int world, float* x,
 int pbl_p2p_allreduce_f32_dev(void* const* peer_bufs, int rank, int world, float* x, void* y_f16, size_t n, size_t max_elems,
                               void* stream) {
     return launch_allreduce(peer_bufs, rank, world, x, y_f16, n, max_elems, 0u, stream);
+}
+
+int pbl_p2p_reduce_f32_dev(void* const* peer_bufs, int rank, int world, float* y_f32, void* y_f16, size_t n, size_t max_elems,
+                           uint32_t expect_records, void* stream) {
+    if (!peer_bufs || (!y_f32 && !y_f16) || world < 1 || world > MAXW || rank < 0 || rank >= world || !n || !expect_records) return PBL_ERR_INVALID_ARG;
+    const size_t cap = (max_elems + 3) & ~size_t(3);
+    if (n > cap) return PBL_ERR_CAPACITY;
+    P2PArgs a;
+    for (int p = 0; p < MAXW; ++p) a.peer[p] = p < world ? static_cast<uint8_t*>(peer_bufs[p]) : nullptr;
+    for (int p = 0; p < world; ++p) if (!a.peer[p]) return PBL_ERR_INVALID_ARG;
+    a.x = y_f32; a.y16 = static_cast<_Float16*>(y_f16); a.n = n; a.cap = cap; a.seq = 0; a.rank = rank; a.world = world;
+    a.nblk = int((n + 4095) / 4096);
+    if (a.nblk > MAXB) a.nblk = MAXB;
+    if (a.nblk < 1) a.nblk = 1;
+    void* argv[] = {&a, &expect_records};
+    return hipLaunchKernel(reinterpret_cast<const void*>(p2p_reduce_kernel), dim3(a.nblk), dim3(256), argv, 0,
+                           static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
 }
 
 int pbl_p2p_check(const void* own_buf) {

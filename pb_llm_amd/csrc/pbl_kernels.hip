@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include "../../include/pbl.h"
+#include "pbl_p2p_layout.h"
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -217,6 +218,12 @@ struct GemvArgs {
     int n_inl;
     pbl_layer inl[PBL_FUSED_INLINE_MAX];
     uint64_t inl_off[PBL_FUSED_INLINE_MAX];
+    // fused peer push (pbl_linear_f16_push; K-split tensor parallelism): the row owners write their fp32 partials straight into
+    // slot [set][rank] of EVERY rank's communication buffer (csrc/pbl_p2p_layout.h) instead of y, and every record counts itself
+    // at the peers once its rows are visible system wide; pbl_p2p_reduce_f32_dev sums the slots.  push_world == 0: off.
+    int push_world, push_rank;
+    size_t push_cap;
+    uint8_t* push_peer[PBL_P2P_MAX_WORLD];
 };
 
 // Gather 8 fp16 values from LDS byte addresses a[0..7] into 4 packed half2 registers
@@ -334,6 +341,14 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     const uint32_t xq = nwg >> 3, xr_ = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
     const uint32_t wg = (xcd < xr_ ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq) + xi;
     const uint32_t rb0 = SPLIT > 1 ? wg : wg * WPB;
+    // fused push: the call number lives in this rank's buffer (last finished call + 1; the reduce kernel of the previous call has
+    // published it: same stream); its parity picks the slot set
+    int push_set = 0;
+    if (args.push_world) {
+        uint32_t q = __hip_atomic_load(pblp2p::ctl_ptr(args.push_peer[args.push_rank]) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        q = q ? q : 1u;
+        push_set = int(__builtin_amdgcn_readfirstlane(q) & 1u);
+    }
     const int wslot = SPLIT > 1 ? wave : 0;      // this wave's first panel / salient round
     constexpr int WSTEP = SPLIT;                 // ... and its stride
 
@@ -582,9 +597,20 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
         if (L.bias && row < L.N) yv += L.bias[row];
         if (PBL_ABLATE == 1 && abl == 0x9E3779B9u) yv += 1.f;
         if (sub == 0 && row < L.N) {
-            if (args.y_f32) static_cast<float*>(yg)[size_t(m) * ldy + row] = yv;
+            if (args.push_world) {
+                for (int p = 0; p < args.push_world; ++p)       // 7 xGMI stores + 1 local, 4 bytes each from 16 lanes (64-byte runs)
+                    pblp2p::slot_ptr(args.push_peer[p], push_set, args.push_rank, args.push_world, args.push_cap)[size_t(m) * ldy + row] = yv;
+            } else if (args.y_f32) static_cast<float*>(yg)[size_t(m) * ldy + row] = yv;
             else static_cast<_Float16*>(yg)[size_t(m) * ldy + row] = _Float16(yv);
         }
+    }
+    if (args.push_world) {
+        // this record's rows are visible system wide, THEN it counts itself at every rank (program order of one wave: the
+        // fence drains the stores above before the atomics below are issued)
+        __threadfence_system();
+        if (lane == 0)
+            for (int p = 0; p < args.push_world; ++p)
+                __hip_atomic_fetch_add(pblp2p::count_ptr(args.push_peer[p], push_set, args.push_rank), 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1166,6 +1192,46 @@ int pbl_linear_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int
         if (rc != PBL_OK) return rc;
     }
     return PBL_OK;
+}
+
+// K-split tensor parallelism, fused: the GEMV of this rank's column shard with its epilogue pushing the fp32 partial y[M, N]
+// straight into slot [set][rank] of every rank's peer-mapped communication buffer (pbl_comm_alloc / pbl_ipc_open; layout in
+// csrc/pbl_p2p_layout.h) -- 7 xGMI stores + 1 local per row owner -- and counting every finished record at the peers.
+// pbl_p2p_reduce_f32_dev(.., expect_records = layer->NRB, ..) then sums the slots: the partial never makes the round trip
+// through local HBM and the push has no launch of its own.  One GEMV pass only (M <= 4 with the x tile in LDS, group-free
+// layers): PBL_ERR_UNSUPPORTED otherwise -- the caller then runs pbl_linear_f16 + pbl_p2p_allreduce_f32_dev.
+int pbl_linear_f16_push(const pbl_layer* layer, const void* x, int M, void* const* peer_bufs, int rank, int world, size_t max_elems,
+                        void* stream) {
+    if (!layer || !layer->blob || !x || !peer_bufs || M < 1 || world < 1 || world > PBL_P2P_MAX_WORLD || rank < 0 || rank >= world)
+        return PBL_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
+    const size_t cap = (max_elems + 3) & ~size_t(3);
+    if (size_t(M) * layer->N > cap) return PBL_ERR_CAPACITY;
+    if (layer->G != 1) return PBL_ERR_UNSUPPORTED;
+    const Route r = route_of(layer, M, !(reinterpret_cast<uintptr_t>(x) & 15));
+    if (M > r.mb_max) return PBL_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool sf = layer->flags & PBL_FLAG_SAL_F16;
+    GemvArgs a{};
+    a.layer = *layer;
+    a.layer.bias = rank == 0 ? layer->bias : nullptr;         // (the bias is added once: by rank 0's partial)
+    a.x = static_cast<const _Float16*>(x);
+    a.y = nullptr;
+    a.M = M; a.y_f32 = 1; a.grouped = 0;
+    a.push_world = world; a.push_rank = rank; a.push_cap = cap;
+    for (int p = 0; p < world; ++p) {
+        if (!peer_bufs[p]) return PBL_ERR_INVALID_ARG;
+        a.push_peer[p] = static_cast<uint8_t*>(peer_bufs[p]);
+    }
+    const int split = r.split, wpb = r.wpb;
+    const dim3 grid(split > 1 ? layer->NRB : (layer->NRB + wpb - 1) / wpb, 1, 1);
+    const size_t lds = lds_bytes(layer->P, layer->max_nch, M, wpb, split);
+    switch (split) {
+        case 8: return launch_split<8>(M, sf, a, grid, lds, st);
+        case 4: return launch_split<4>(M, sf, a, grid, lds, st);
+        case 2: return launch_split<2>(M, sf, a, grid, lds, st);
+        default: return wpb == 4 ? launch_mb<4>(M, sf, a, grid, lds, st) : launch_mb<1>(M, sf, a, grid, lds, st);
+    }
 }
 
 int pbl_unpack_dev(const pbl_layer* layer, void* W_out, int out_f32, void* stream) {

@@ -179,6 +179,29 @@ class P2PAllReduce:
                                                         self.max_numel, st), "p2p_allreduce")
         return t
 
+    def fused_linear_(self, packed, bias_f32, x2: torch.Tensor, out: torch.Tensor) -> bool:
+        """K-split layer with the push fused into the GEMV's epilogue (pbl_linear_f16_push) + the reduce (pbl_p2p_reduce_f32_dev):
+        x2 [M, K_shard] fp16 contiguous, out [M, N] fp16 or fp32 receives the all-reduced result.  False: this call is not one GEMV
+        pass (more than 4 tokens, column groups) -- the caller runs the unfused pair; nothing was launched."""
+        if self._own is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.PblError("P2PAllReduce: run one all-reduce eagerly before capturing (the buffers are mapped on first use)")
+            self._allocate()
+        M = x2.shape[0]
+        if M * packed.N > self.max_numel:
+            return False
+        L = _lib.lib()
+        layer = packed.layer_struct(bias_f32)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        rc = L.pbl_linear_f16_push(C.byref(layer), x2.data_ptr(), M, self._ptrs, self.rank, self.world, self.max_numel, st)
+        if rc == _lib.PBL_ERR_UNSUPPORTED:
+            return False
+        _lib.check(rc, "linear_f16_push")
+        f32 = out.dtype == torch.float32
+        _lib.check(L.pbl_p2p_reduce_f32_dev(self._ptrs, self.rank, self.world, out.data_ptr() if f32 else None,
+                                            None if f32 else out.data_ptr(), M * packed.N, self.max_numel, packed.NRB, st), "p2p_reduce")
+        return True
+
     def check(self) -> None:
         """synchronous: raises if any wait timed out since construction (a peer died or never launched; the affected
         outputs were overwritten with NaN by the kernel)"""
@@ -240,6 +263,7 @@ class PBLinearKSplit(nn.Module):
         # a timed-out peer wait poisons the output with NaN and sets the communicator's status word; the word is polled
         # (synchronously) every `check_every` eager forwards, so a dead peer surfaces as an exception, not only as NaN logits
         self.check_every, self._calls = 256, 0
+        self.fuse_push = True       # <= 4 fp16 rows: pbl_linear_f16_push + pbl_p2p_reduce_f32_dev instead of GEMV + all-reduce
         if collective == "p2p":
             # ONE communicator per (device, group) for all K-split layers, sized to the largest message
             self.comm = P2PAllReduce.shared(shard.pbl_blob.device, group, max_tokens * shard.out_features)
@@ -250,6 +274,17 @@ class PBLinearKSplit(nn.Module):
 
     def forward(self, x):
         xl = x if self.input_is_sharded else x[..., self.cols[0]:self.cols[1]]
+        if self.comm is not None and self.fuse_push and x.dtype == torch.float16 and not (torch.is_grad_enabled() and x.requires_grad):
+            # decode: ONE GEMV pass whose epilogue pushes the partial to every rank + the reduce (round 4): no all-reduce launch
+            # that first reads the partial back from local HBM
+            x2 = xl.reshape(-1, xl.shape[-1]).contiguous()
+            if 0 < x2.shape[0] <= _lib.PBL_MAX_TOKENS_PER_LAUNCH:
+                self._calls += 1
+                if self.check_every and self._calls % self.check_every == 0 and not torch.cuda.is_current_stream_capturing():
+                    self.comm.check()
+                out = torch.empty(x2.shape[0], self.shard.out_features, dtype=torch.float16, device=x.device)
+                if self.comm.fused_linear_(self.shard.packed, self.shard.pbl_bias, x2, out):
+                    return out.reshape(*x.shape[:-1], self.shard.out_features)
         y = self.local_forward(xl)               # fp32, contiguous: the kernels' own output
         if self.comm is not None and y.numel() <= self.comm.max_numel:
             self._calls += 1

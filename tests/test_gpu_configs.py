@@ -169,6 +169,16 @@ def _tp_worker(rank, world, port, collective, out):
         if mod.comm is not None:
             for _ in range(5):            # more calls than buffer sets
                 same = same and bool(torch.equal(mod(x), y))
+            # round 4: <= 4 rows take the FUSED pair (GEMV epilogue pushes the partial to every rank + reduce kernel); the unfused
+            # pair (GEMV -> y in HBM -> one-shot all-reduce) on the same communicator gives the same bits, in any interleaving
+            assert mod.fuse_push
+            mod.fuse_push = False
+            y_unf = mod(x)
+            mod.fuse_push = True
+            same = same and bool(torch.equal(y_unf, y)) and bool(torch.equal(mod(x), y))
+            x8 = torch.from_numpy(synth.activations((8, K), 16, 21)).to(dev)        # more rows than one GEMV pass: unfused
+            r8, q8 = O.parity_errors(mod(x8).float().cpu().numpy(), O.dense_linear(x8.cpu().numpy(), W16.numpy()))
+            same = same and r8 < 1e-3 and q8 < 1.0 and bool(torch.equal(mod(x), y))
             # a second K-split layer shares the communicator (one buffer per rank, sized to the largest message) ...
             W2 = synth.llm_weight(128, K, seed=43, heavy_tail=True)
             mask2 = O.ptq_low_mask(W2, 0.9, "magnitude", None, -1)

@@ -191,7 +191,13 @@ def test_kept_image_and_kept_list_follow_the_blob():
         assert torch.equal(run(x[:40]), ref[:40]) and layer.packed._gemm_list is kept               # one list, any M
         layer.pbl_blob.add_(0)                                                                     # written in place
         assert torch.equal(run(x), ref) and layer.packed._gemm_list[0] != kept[0]
-        for backend in ("fused", "auto"):
+        # backend "auto" sends a shape whose tiles do not fill the chip (here 8 of 256) to the library: same weights, other
+        # summation order; a chip-filling shape takes the image kernel
+        Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = "auto", False, True
+        assert not Q._image_fills_the_chip(512, 300, DEV) and Q._image_fills_the_chip(4096, 2048, DEV) and not Q._image_fills_the_chip(11008, 2048, DEV)
+        assert_parity(layer(x), ref.float().cpu().numpy().astype(np.float64), 2e-3)
+        assert getattr(layer.packed, "_gemm_image", None) is None
+        for backend in ("fused",):
             Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = backend, False, True
             assert torch.equal(layer(x), ref)
             kimg = layer.packed._gemm_image

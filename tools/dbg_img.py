@@ -1,26 +1,66 @@
 import sys, os, numpy as np, torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
-from cfg_shapes import hessian_layer, LLAMA7B
+import test_gpu_gemm as TG
+from oracle import pb_oracle as O
 from pb_llm_amd import quant as Q, synth
-N, K = LLAMA7B["down_proj"]
-for seed in (302, 301):
-    W, mask, r = hessian_layer(N, K, 0.95, seed=seed)
-    layer = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to("cuda:0")
-    p = layer.packed
-    x = torch.from_numpy(synth.activations((2048, K), 77, 21)).cuda()
-    img = Q.gemm_image(p)
-    print("seed", seed, "colmax max", img.max_entries, "nv hist", np.bincount(np.digitize(list(img.colmax), [193, 449, 705, 961]), minlength=5).tolist())
-    y_img = Q.fused_gemm_forward(p, None, x, image=img)
-    y_old = Q.fused_gemm_forward(p, None, x)
+p, Wd = TG.rtn_layer(512, 1024, -1, seed=7, low_frac=0.9, fp16=True, exceptions=1)
+pd = p.to("cuda:0")
+b = TG.T(synth.normal((512,), 3, 3, 0.1))
+x = TG.T(synth.activations((300, 1024), 8, 21))
+img = Q.gemm_image(pd)
+print("colmax", list(img.colmax))
+for bias in (None, b):
+    y_img = Q.fused_gemm_forward(pd, bias, x, image=img, out_f32=True)
+    y_old = Q.fused_gemm_forward(pd, bias, x, out_f32=True)
+    y_nl = Q.fused_gemm_forward(pd, bias, x, out_f32=True, workspace=False)
     bad = (y_img != y_old)
-    print("mismatching elements", int(bad.sum()), "of", bad.numel())
+    print("bias" if bias is not None else "no bias", "mismatches img vs list:", int(bad.sum()), " list vs in-kernel:", int((y_old != y_nl).sum()))
     if bad.any():
         rows = bad.any(0).nonzero().flatten().cpu().numpy(); toks = bad.any(1).nonzero().flatten().cpu().numpy()
-        print("rows", len(rows), rows[:40], "records", np.unique(rows // 16)[:40], "row tiles", np.unique(rows // 128))
-        print("tokens", len(toks), toks[:10], toks[-5:])
-        d = (y_img.float() - y_old.float()).abs()
-        print("max abs diff", float(d.max()), "ref max", float(y_old.float().abs().max()))
-        # per column-of-K effect cannot be seen directly; per row count of salients in hot columns
-        c = (~mask).reshape(N // 16, 16, K // 128, 128).sum(axis=(1, 3))
-        recs = np.unique(rows // 16)
-        print("entries per slot for a bad record (max over h):", c[recs[0]].max(), "argmax h", c[recs[0]].argmax(), " overall max", c.max())
+        print("rows", rows[:20], len(rows), "tokens", len(toks), toks[:8])
+        ref = O.dense_linear(x.cpu().numpy(), Wd.astype(np.float16).astype(np.float32)[rows], None if bias is None else bias.cpu().numpy()[rows])
+        print("err img", np.abs(y_img[:, rows].cpu().numpy() - ref).max(), "err old", np.abs(y_old[:, rows].cpu().numpy() - ref).max())
+        d = (y_img - y_old)[:, rows[0]].cpu().numpy(); print("diff vs x? corr with each column impossible; diff sample", d[:6])
+        # which column explains it: diff = dw * x[:, c]  -> least squares over columns
+        xs = x.float().cpu().numpy(); dd = (y_img - y_old)[:, rows[0]].double().cpu().numpy()
+        c = np.abs(xs.T @ dd) / (np.linalg.norm(xs, axis=0) * np.linalg.norm(dd) + 1e-30)
+        cb = int(c.argmax()); print("best column", cb, "cos", c[cb], "half slab", cb // 128, "dw ~", float(dd @ xs[:, cb] / (xs[:, cb] @ xs[:, cb])), "W there", Wd[rows[0], cb])
+print("---- fp16 outputs, module path")
+layer = Q.PBLinear(pd, b)
+Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = "fused", False, False
+ref = layer(x)
+y16_old = Q.fused_gemm_forward(pd, b, x)
+y16_img = Q.fused_gemm_forward(pd, b, x, image=img)
+print("ctypes fp16: img vs list", int((y16_img != y16_old).sum()), " module(no image) vs ctypes list", int((ref != y16_old).sum()))
+Q.GEMM_KEEP_IMAGE = True
+ym = layer(x)
+print("module(image) vs ctypes img", int((ym != y16_img).sum()), " vs ref", int((ym != ref).sum()), "kept image colmax", list(layer.packed._gemm_image[1].colmax))
+ki = layer.packed._gemm_image[1]
+print("image bytes equal to ctypes-built image:", bool(torch.equal(ki.data, img.data)))
+ym2 = layer(x); print("second call vs first", int((ym2 != ym).sum()))
+print("---- repeatability: rebuild the image / the list every time")
+base_img = Q.fused_gemm_forward(pd, b, x, image=img)
+base_old = Q.fused_gemm_forward(pd, b, x)
+nb_i = nb_o = 0
+for it in range(60):
+    im2 = Q.gemm_image(pd)
+    yi = Q.fused_gemm_forward(pd, b, x, image=im2)
+    yo = Q.fused_gemm_forward(pd, b, x)
+    di, do_ = int((yi != base_img).sum()), int((yo != base_old).sum())
+    nb_i += di > 0; nb_o += do_ > 0
+    if di or do_:
+        print("iter", it, "img diff", di, "old diff", do_)
+print("runs that differ: image", nb_i, "list", nb_o)
+# the test's exact sequence
+layer = Q.PBLinear(pd, b)
+Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = "fused", False, False
+ref = layer(x)
+run = lambda xin: Q._pb_linear_forward(layer.packed, layer.pbl_bias, xin, False, torch.float16)
+print("run==ref", bool(torch.equal(run(x), ref)))
+Q.GEMM_KEEP_LIST = True
+print("kept list run==ref", bool(torch.equal(run(x), ref)))
+layer.pbl_blob.add_(0)
+print("after add_: run==ref", bool(torch.equal(run(x), ref)))
+Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = "fused", False, True
+y = layer(x)
+print("image via module == ref", bool(torch.equal(y, ref)), int((y != ref).sum()))

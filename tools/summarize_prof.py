@@ -96,7 +96,8 @@ def main():
             print(f"\n## {sub}: kernel trace, un-instrumented timing (durations in us)")
             for s in kernel_stats(p)[:10]:
                 print(json.dumps(s))
-        want = "pbl_mfma_kernel" if sub.startswith("mfma") else ("pbl_gemm_kernel" if sub.startswith("gemm") else "pbl_gemv")
+        want = "pbl_mfma_kernel" if sub.startswith("mfma") else ("pbl_gemm_img_kernel" if sub.startswith("gemmimg") else
+                                                                ("pbl_gemm_kernel" if sub.startswith("gemm") else "pbl_gemv"))
         if "pmc" in sub or "fetch" in sub or "write" in sub or "tcc" in sub:
             st = pmc_stats(p, want)
             if st:
