@@ -172,6 +172,8 @@ def run_side_workload(a):
             for _ in range(6):                                                    # 6 device copies each: beyond the Infinity Cache
                 layers.append(Q.PBLinear(base.packed.to(dev), None))
     Q.GEMM_BACKEND = a.gemm_backend
+    if a.workload == "cfg4":
+        Q.SMALL_BATCH_IMAGE = a.small_batch_image        # "1": the small-batch kernel over the layers' GEMM images (built on first use)
     xs = {K: torch.from_numpy(synth.activations((M, K), 3, 21)).to(dev) for K in {l.in_features for l in layers}}
     alg = sum(l.packed.algorithmic_bytes(M) for l in layers)
 
@@ -206,14 +208,19 @@ def run_side_workload(a):
         work = "llama-7b decoder-layer linears (q,k,v,o 4096x4096; gate,up 11008x4096; down 4096x11008), low_frac 0.95 hessian, M=2048"
     else:
         roof = {"bound": "hbm", "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                "kernel": "pbl_mfma_kernel", "us_per_step": 1e6 * dev_s, "us_per_layer": 1e6 * dev_s / len(layers)}
+                "kernel": (f"pbl_sb_img_kernel + sb_reduce_kernel over the layers' GEMM images ({n_img} of {len(layers)} layers)" if n_img
+                           else "pbl_mfma_kernel + pbl_mfma_reduce over the packed records"),
+                "us_per_step": 1e6 * dev_s, "us_per_layer": 1e6 * dev_s / len(layers),
+                "blob_bytes": sum(l.packed.blob.numel() for l in layers),
+                "image_bytes": sum(l.packed._gemm_image[1].data.numel() for l in layers if getattr(l.packed, "_gemm_image", (None, None))[1] is not None)}
         value, unit = len(layers) * M / (wall / a.steps), "layer-tokens/s"
         work = "llama-13b FFN 13824x5120 + 5120x13824 (6 device copies each), low_frac 0.8, M=32"
     roof["frac"] = roof["achieved"] / roof["peak"]
     print(json.dumps({"metric": f"PB-linear side workload {a.workload}", "value": value, "unit": unit, "n_gpus": 1,
                       "steps": a.steps, "warmup": a.warmup, "preheat_s": a.preheat_s, "ms_per_step": 1e3 * wall / a.steps,
                       "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 in/out, f32 accumulate",
-                      "data": "synthetic", "config": {"workload": work, "gemm_backend": a.gemm_backend}, "roofline": roof}), flush=True)
+                      "data": "synthetic", "config": {"workload": work, "gemm_backend": a.gemm_backend, **({"small_batch_image": a.small_batch_image} if a.workload == "cfg4" else {})},
+                      "roofline": roof}), flush=True)
 
 
 # role of layer i in a llama decoder layer (SURVEY 8(e) "LLaMA layer mapping"): True = K-split (+ all-reduce)
@@ -244,6 +251,9 @@ def main():
     ap.add_argument("--tp-collectives", choices=["per-layer", "stacked", "fused"], default="per-layer",
                     help="tp: per-layer = one all-reduce of [M, N] fp32 per K-split layer (64 per step, 16 KB each at M = 1: what a "
                          "decoder executes); stacked = ONE all-reduce of all K-split partials per step (the easy case)")
+    ap.add_argument("--small-batch-image", choices=["auto", "0", "1"], default="1",
+                    help="cfg4: 1 = the small-batch kernel over the layers' GEMM images (built on the first call; 2.5 x the blob's bytes at "
+                         "20 %% salients), 0 = the kernel over the packed records, auto = the library default (an image only if a prefill call built one)")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
                     help="cfg2 = BASELINE configs[1], the headline GEMV stream (default, what the driver runs); cfg3 / cfg4: "
                          "configs[2] / configs[3] as side lines (see run_side_workload)")

@@ -350,6 +350,14 @@ size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* colmax);
 int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* colmax, void* image, size_t image_bytes, void* stream);
 int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
                        const uint32_t* colmax, void* stream);
+/* The same product for 1 <= M <= 32 rows of x over the same image (HBM-bound: the image is read once; every wave owns 32 rows of W
+ * and a range of 128-column half slabs, K is split over the grid).  workspace: pbl_gemm_small_image_workspace_bytes(layer, M) bytes,
+ * 16-byte aligned, any content (the splits' fp32 partial outputs, added in split order by a second small kernel: deterministic);
+ * NULL / too small: one split.
+ * Replaces F.linear at a small serving batch (quant/outlier_quantizer.py:101-106 at <= 32 rows; BASELINE.json configs[3]). */
+size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, int M);
+int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
+                            const uint32_t* colmax, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Decode-time FUSED projections (q/k/v, gate/up: layers that read the same activation): L layers, ONE x [M, K] (fp16,
  * 16-B aligned rows are not required), ONE output matrix y [M, ldy] in which layer l owns the columns

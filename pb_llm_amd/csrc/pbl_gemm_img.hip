@@ -21,6 +21,7 @@
 // accumulator sums its k-steps in the same order as pbl_gemm_big.hip: the two kernels agree bit for bit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "../../include/pbl.h"
@@ -45,7 +46,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define GI_LDS (GI_X_OFF + 3 * GI_XSLOT)           // 163840 B
 #define GI_MAX_NH 127
 #define GI_NVMAX 5                // 16-byte vectors per lane in the largest slot
-#define GI_IMG_MAGIC 0x31494250u                   // "PBI1"
+#define GI_IMG_MAGIC 0x32494250u                   // "PBI2" (slots vector-major: every 16-byte load of a wave is one contiguous KiB)
 #define GI_PREP_THREADS 1024
 #ifndef PBL_GEMM_PPRIO
 #define PBL_GEMM_PPRIO 1
@@ -75,7 +76,8 @@ extern "C" void pbl_debug_trace_gemm_img(void* p) { g_img_trace = static_cast<ui
 namespace {
 
 // image header (64 bytes); the records' slot rows follow at slots_off (record stride = tab.t[NH] * 256 bytes, slot h of a record at
-// (tab.t[h] & 0xFFFF) * 256, [64 lanes][4 nv_h] u32), the level table [NRB][G][16] u32 at levels_off
+// (tab.t[h] & 0xFFFF) * 256, [nv_h vectors][64 lanes][4] u32: word w of lane l at (w >> 2) * 256 + 4 l + (w & 3)), the level table
+// [NRB][G][16] u32 at levels_off
 struct ImgHeader {
     uint32_t magic, stride256, NH, NRB, G, K, N, flags;
     uint64_t slots_off, levels_off, total;
@@ -145,7 +147,8 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
     auto put = [&](uint32_t h, uint32_t j, uint32_t word) {   // entry j of half slab h: lane j & 63, word 1 + (j >> 6)
         if (j == 0) s_first[h] = word;
         const uint32_t EW = 4u * (tab.t[h] >> 16);
-        if (j < 64u * (EW - 1u)) slot_of(h)[(j & 63u) * EW + 1u + (j >> 6)] = word;
+        const uint32_t w = 1u + (j >> 6);
+        if (j < 64u * (EW - 1u)) slot_of(h)[(w >> 2) * 256u + (j & 63u) * 4u + (w & 3u)] = word;
     };
     // a quarter of a chunk per thread
     for (int u = tid; u < 4 * nch; u += GI_PREP_THREADS) {
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
         const int h = it >> 6, l = it & 63;
         const uint32_t d = uint32_t(h >> 2) < L.P ? tile_dw[size_t(h >> 2) * 256 + l * 4 + (h & 3)] : 0u;
         const uint32_t EW = 4u * (tab.t[h] >> 16);
-        uint32_t* sl = slot_of(uint32_t(h)) + size_t(l) * EW;
+        uint32_t* sl = slot_of(uint32_t(h)) + size_t(l) * 4;       // word k of this lane: sl[(k >> 2) * 256 + (k & 3)]
         sl[0] = d;
         const uint32_t n = s_cnt[h];
         uint32_t padw = s_first[h];
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
             padw = ((d0 >> 8) & 1u) ? h16(hi) : h16(lo);                                                    // row 0 <-> bit 8 (pbl.h), offset 0
         }
         for (uint32_t k = 1; k < EW; ++k)
-            if ((k - 1u) * 64u + uint32_t(l) >= n) sl[k] = padw;
+            if ((k - 1u) * 64u + uint32_t(l) >= n) sl[(k >> 2) * 256u + (k & 3u)] = padw;
     }
     // level rows: (hi - lo) mod 2^16 : lo as fp16 bit patterns, 16 per (record, group)
     uint32_t* lev = reinterpret_cast<uint32_t*>(img + sizeof(ImgHeader) + size_t(L.NRB) * stride256 * 256) + size_t(rb) * L.G * 16;
@@ -336,22 +339,22 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
         auto request = [&](int i, int hh, u32x4 (&dst)[GI_NVMAX], int& nv_out) {
             const uint32_t t = a.tab.t[min(hh, NH - 1)];
             const uint32_t nv = t >> 16;
-            const uint8_t* sp = sbase[i] + size_t(t & 0xFFFFu) * 256;
-            const uint32_t lo = lane16 * nv;                    // the lane's bytes in a slot of nv vectors
+            const uint8_t* sp = sbase[i] + size_t(t & 0xFFFFu) * 256 + 2048;      // (biased: the instruction offset is 13 bits, signed)
+            const uint32_t lo = lane16;                         // vector v of the slot: one contiguous KiB, 16 bytes per lane
             static_assert(GI_NVMAX == 5, "the request block spells five loads out");
-            asm volatile("global_load_dwordx4 %0, %5, %6\n\t"
+            asm volatile("global_load_dwordx4 %0, %5, %6 offset:-2048\n\t"
                          "s_cmp_lt_u32 %7, 2\n\t"
                          "s_cbranch_scc1 1f\n\t"
-                         "global_load_dwordx4 %1, %5, %6 offset:16\n\t"
+                         "global_load_dwordx4 %1, %5, %6 offset:-1024\n\t"
                          "s_cmp_lt_u32 %7, 3\n\t"
                          "s_cbranch_scc1 1f\n\t"
-                         "global_load_dwordx4 %2, %5, %6 offset:32\n\t"
+                         "global_load_dwordx4 %2, %5, %6\n\t"
                          "s_cmp_lt_u32 %7, 4\n\t"
                          "s_cbranch_scc1 1f\n\t"
-                         "global_load_dwordx4 %3, %5, %6 offset:48\n\t"
+                         "global_load_dwordx4 %3, %5, %6 offset:1024\n\t"
                          "s_cmp_lt_u32 %7, 5\n\t"
                          "s_cbranch_scc1 1f\n\t"
-                         "global_load_dwordx4 %4, %5, %6 offset:64\n"
+                         "global_load_dwordx4 %4, %5, %6 offset:2048\n"
                          "1:"
                          : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]) : "v"(lo), "s"(sp), "s"(nv) : "memory", "scc");
             nv_out = int(nv);
@@ -631,6 +634,258 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
 #endif
 }
 
+// ---- <= 32 rows of x over the same image ------------------------------------------------------------------------------------
+// Replaces the same call at 5 - 32 rows (quant/outlier_quantizer.py:101-106 under a small serving batch; BASELINE.json configs[3]).
+// HBM-bound: the image is read once, x (32 x K fp16) lives in L2.  No roles: every WAVE owns a pair of records (32 rows) and the
+// workgroup's range of half slabs, and per half slab
+//   * rebuilds its two records' 16 x 128 fp16 tiles in its PRIVATE 8 KiB of LDS from the slots (plane dword -> 16 stores, every
+//     entry word one 2-byte store: the GEMM kernel's expansion), which arrive through a ring of four slot register sets requested
+//     two half slabs ahead (plain loads: the compiler counts vmcnt),
+//   * reads the A fragments back (a wave's LDS operations execute in order: no wait between the stores and the reads) and
+//     multiplies them with x's 32 x 128 tile, which a FIFTH wave of the workgroup stages by LDS-DMA (eight 1 KiB pieces per half
+//     slab, whole 128-byte lines of x; a fragment read straight from global memory touches 32 lines per instruction) into a
+//     double buffer: ONE workgroup barrier per half slab.  The staging wave exists so that the x pieces are not in the working
+//     waves' vmcnt queue: memory operations return in order, and waiting for a piece would also wait for every slot request
+//     issued before it -- the look-ahead of the slot ring would shrink to one half slab.
+// K is split over gridDim.y; the splits' fp32 partial tiles are added in split order by sb_reduce_kernel (deterministic): a second
+// small launch, 2.9 us behind the first.  (Folding the sum into the LAST split to arrive was built and measured, call r4-23/24: with
+// release / acquire fences at agent scope -- a buffer_wbl2 per wave -- 44 - 110 us per launch instead of 25; with agent-scope
+// stores and loads of the partial tiles and no fence 36 - 61 us: traffic past the XCD's L2 costs more than the launch.)
+struct SbArgs {
+    pbl_layer L;
+    const _Float16* x;      // [M, K]
+    void* y;                // [M, N] fp16 / fp32 (KS == 1)
+    float* part;            // [KS][M][N] fp32 (KS > 1)
+    int M, y_f32, KS, hps;  // hps: half slabs per K split
+    const uint8_t* img;
+    int dbg;
+    ImgTab tab;
+};
+#define SB_WAVES 4                   // working waves of a workgroup (+ 1 that stages x)
+#define SB_X_OFF (SB_WAVES * 8192)
+#define SB_LDS (SB_X_OFF + 2 * 8192)
+
+typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;        // constant address space: scalar loads
+template <int NVK, bool KT>
+__global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_per_eu(NVK <= 3 ? 4 : 3, NVK <= 3 ? 4 : 3))) void pbl_sb_img_kernel(SbArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem_s[SB_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const pbl_layer& L = a.L;
+    const int K = int(L.K), M = a.M;
+    const int NH = (K + GI_HS - 1) / GI_HS;
+    const int ks = int(blockIdx.y);
+    const int h0 = ks * a.hps, h1 = min(h0 + a.hps, NH);
+    if (wave == SB_WAVES) {
+        // ---- the staging wave.  x tile of a half slab in LDS: [32 tokens][16 units of 8 columns], unit u of token t at
+        // 256 t + 16 (u ^ (t & 15)).  A DMA piece is 1 KiB = 4 token rows: lane l lands on unit (l & 15) of token 4 piece + (l >> 4),
+        // which holds the LOGICAL unit (l & 15) ^ (token & 15).  Through a buffer descriptor over the M rows of x: tokens >= M read zeros.
+        __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x), 0, int(size_t(M) * size_t(K) * 2), 0x00020000);
+        uint32_t xvoff[8], xvlast[KT ? 8 : 1];
+        const uint32_t ktail_units = uint32_t(K & (GI_HS - 1)) >> 3;               // valid units of the last half slab (0: no tail)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t tl = uint32_t(4 * q + (lane >> 4));
+            const uint32_t lu = uint32_t(lane & 15) ^ (tl & 15);
+            xvoff[q] = tl * uint32_t(K) * 2u + (lu << 4);
+            // the units of the LAST half slab beyond K would hold the next token row: pushed out of the descriptor's range, they read zeros
+            if constexpr (KT) xvlast[q] = xvoff[q] + ((ktail_units && lu >= ktail_units) ? 0x40000000u : 0u);
+        }
+        for (int h = h0; h <= h1; ++h) {                     // x of half slab h into buffer (h - h0) & 1, then the barrier the others open half slab h behind
+            if (h < h1) {
+                const uint32_t buf = uint32_t(h - h0) & 1u;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    uint32_t vo = xvoff[q];
+                    if constexpr (KT) vo = (h == NH - 1) ? xvlast[q] : vo;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_s + SB_X_OFF + buf * 8192u + uint32_t(q) * 1024u), 16, int(vo), h * (GI_HS * 2), 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // barrier h - h0: x(h) is complete; everyone has left the buffer x(h + 1) goes to
+            asm volatile("" ::: "memory");
+        }
+        return;
+    }
+    const uint32_t npairs = (L.NRB + 1) / 2;
+    const uint32_t pair_raw = blockIdx.x * SB_WAVES + uint32_t(wave);
+    const uint32_t pair = min(pair_raw, npairs - 1);         // (a surplus wave mirrors the last pair: it keeps the barriers and stores nothing)
+    char* const As = smem_s + wave * 8192;
+    const uint32_t stride256 = a.tab.t[NH];
+    const uint8_t* slots = a.img + sizeof(ImgHeader);
+    const uint32_t* levels = reinterpret_cast<const uint32_t*>(slots + size_t(L.NRB) * stride256 * 256);
+    const uint32_t gs = L.K / L.G;
+    uint32_t rbv[2];
+    const uint8_t* sbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        rbv[i] = min(2 * pair + uint32_t(i), L.NRB - 1);     // (an odd record count: the last pair mirrors the last record, whose rows are stored once)
+        sbase[i] = slots + size_t(rbv[i]) * stride256 * 256;
+    }
+    uint32_t hl[2][16];
+    auto load_levels = [&](int i, uint32_t g) {
+        const_u32_ptr lp = (const_u32_ptr)(reinterpret_cast<uintptr_t>(levels + (size_t(rbv[i]) * L.G + g) * 16));   // (the image is read-only here)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hl[i][r] = lp[r];
+    };
+    // ring of four slot sets: record-step t = 2 (h - h0) + i sits in set t & 3; nvs: the vectors of the slot a set holds
+    u32x4 e[4][NVK];
+    uint32_t nvs[4];
+    const uint32_t lane16 = uint32_t(lane) * 16u;
+    auto request = [&](int i, int h, u32x4 (&dst)[NVK], uint32_t& nv_out) {
+        const uint32_t t = a.tab.t[min(h, NH - 1)];          // (past the end: a slot that exists, never used)
+        const uint32_t nv = t >> 16;
+        const uint8_t* sp = sbase[i] + size_t(t & 0xFFFFu) * 256 + lane16;
+#pragma unroll
+        for (int v = 0; v < NVK; ++v) dst[v] = *reinterpret_cast<const u32x4*>(sp + 1024u * min(uint32_t(v), nv - 1u));   // (a smaller slot: its last vector again, a cache hit; not stored)
+        nv_out = nv;
+    };
+    const uint32_t v0 = (uint32_t(lane >> 2) << 4) + (uint32_t(lane & 3) << 2);
+    auto expand = [&](int i, const u32x4 (&s)[NVK], uint32_t nv) {
+        char* base = As + i * 4096;
+        const uint32_t d = s[0][0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pos = r < 8 ? r + 8 : r - 8;
+            const uint32_t m = (d >> pos) & 0x00010001u;
+            uint32_t val;
+            asm("v_pk_mad_u16 %0, %1, %2, %2 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(val) : "v"(m), "s"(hl[i][r]));
+            *reinterpret_cast<uint32_t*>(base + (v0 ^ uint32_t(0x110 * r))) = val;
+        }
+        asm volatile("" ::: "memory");                       // (the overlay comes after the plane: in order)
+        auto put_word = [&](uint32_t w) { *reinterpret_cast<uint16_t*>(base + (w >> 16)) = uint16_t(w & 0xFFFFu); };
+        put_word(s[0][1]); put_word(s[0][2]); put_word(s[0][3]);
+#pragma unroll
+        for (int v = 1; v < NVK; ++v)
+            if (nv > uint32_t(v)) { put_word(s[v][0]); put_word(s[v][1]); put_word(s[v][2]); put_word(s[v][3]); }
+        asm volatile("" ::: "memory");
+    };
+    const int i32 = lane & 31, g = lane >> 5;
+    uint32_t aq[8], bq[8];
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+        aq[k8] = uint32_t(i32) * 256u + ((uint32_t(2 * k8 + g) ^ uint32_t(i32 & 15)) << 4);
+        bq[k8] = SB_X_OFF + aq[k8];                           // (the x tile has the A tile's geometry: 32 rows of 256 bytes, the same swizzle)
+    }
+    v16f acc;
+#pragma unroll
+    for (int e_ = 0; e_ < 16; ++e_) acc[e_] = 0.f;
+
+    {
+        const uint32_t g0 = (uint32_t(h0) * GI_HS) / gs;
+        load_levels(0, g0); load_levels(1, g0);
+    }
+    request(0, h0, e[0], nvs[0]); request(1, h0, e[1], nvs[1]);
+    request(0, h0 + 1, e[2], nvs[2]); request(1, h0 + 1, e[3], nvs[3]);
+    __builtin_amdgcn_s_barrier();                            // barrier 0: x of the first half slab is in LDS
+    asm volatile("" ::: "memory");
+    auto half_slab = [&](int h, uint32_t buf, u32x4 (&sa)[NVK], u32x4 (&sb)[NVK], uint32_t& nva, uint32_t& nvb) {
+        if (L.G > 1 && h > h0 && (uint32_t(h) * GI_HS) % gs == 0) { const uint32_t gg = (uint32_t(h) * GI_HS) / gs; load_levels(0, gg); load_levels(1, gg); }
+        expand(0, sa, nva); request(0, h + 2, sa, nva);
+        expand(1, sb, nvb); request(1, h + 2, sb, nvb);
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) {
+            const v8h af = *reinterpret_cast<const v8h*>(As + aq[k8]);
+            const v8h bf = *reinterpret_cast<const v8h*>(smem_s + bq[k8] + buf * 8192u);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of the x tile are done; then everyone's, and the next tile is in
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    for (int h = h0; h < h1; h += 2) {
+        half_slab(h, 0u, e[0], e[1], nvs[0], nvs[1]);
+        if (h + 1 < h1) half_slab(h + 1, 1u, e[2], e[3], nvs[2], nvs[3]);
+        else break;
+    }
+    // (an odd number of half slabs leaves the buffers swapped for nobody: the kernel ends)
+
+    // ---- the 32 x 32 tile: rows (reg & 3) + 8 (reg >> 2) + 4 g of the pair, token i32
+    const uint32_t row0 = pair_raw * 32u;
+    const int tok = i32;
+    if (pair_raw >= npairs) return;
+    const bool whole = row0 + 32 <= L.N && (L.N & 3) == 0;
+    float o[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const uint32_t row = row0 + uint32_t(8 * (q >> 2) + 4 * g + (q & 3));
+        o[q] = acc[q];
+        if (L.bias && ks == 0 && row < L.N) o[q] += L.bias[row];
+    }
+    if (tok >= M) return;
+    if (a.KS > 1) {                                           // this split's partial tile; sb_reduce_kernel adds the splits
+        float* dst = a.part + (size_t(ks) * M + tok) * L.N + row0 + 4 * g;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            if (whole) *reinterpret_cast<v4f*>(dst + 8 * q4) = v4f{o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]};
+            else
+                for (int r = 0; r < 4; ++r) if (row0 + 4 * g + 8 * q4 + r < L.N) dst[8 * q4 + r] = o[4 * q4 + r];
+        }
+        return;
+    }
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        const uint32_t row = row0 + uint32_t(8 * q4 + 4 * g);
+        if (a.y_f32) {
+            float* dst = static_cast<float*>(a.y) + size_t(tok) * L.N + row;
+            if (whole) *reinterpret_cast<v4f*>(dst) = v4f{o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]};
+            else
+                for (int r = 0; r < 4; ++r) if (row + r < L.N) dst[r] = o[4 * q4 + r];
+        } else {
+            _Float16* dst = static_cast<_Float16*>(a.y) + size_t(tok) * L.N + row;
+            if (whole) {
+                uint2 pk;
+                pk.x = h16(o[4 * q4]) | (h16(o[4 * q4 + 1]) << 16); pk.y = h16(o[4 * q4 + 2]) | (h16(o[4 * q4 + 3]) << 16);
+                *reinterpret_cast<uint2*>(dst) = pk;
+            } else
+                for (int r = 0; r < 4; ++r) if (row + r < L.N) dst[r] = _Float16(o[4 * q4 + r]);
+        }
+    }
+}
+
+// y = the K splits' partial tiles added in split order; 4 elements per thread (MN % 4 == 0 whenever N % 4 == 0)
+__global__ __launch_bounds__(256) void sb_reduce_kernel(const float* __restrict__ part, void* __restrict__ y, int KS, size_t MN, int y_f32) {
+    const size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * 4;
+    if (i >= MN) return;
+    if (!(MN & 3)) {
+        v4f sum = *reinterpret_cast<const v4f*>(part + i);
+        for (int k0 = 1; k0 < KS; k0 += 8) {
+            v4f v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = k0 + j < KS ? *reinterpret_cast<const v4f*>(part + size_t(k0 + j) * MN + i) : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (k0 + j < KS) sum += v[j];
+        }
+        if (y_f32) *reinterpret_cast<v4f*>(static_cast<float*>(y) + i) = sum;
+        else {
+            uint2 pk;
+            pk.x = h16(sum[0]) | (h16(sum[1]) << 16); pk.y = h16(sum[2]) | (h16(sum[3]) << 16);
+            *reinterpret_cast<uint2*>(static_cast<_Float16*>(y) + i) = pk;
+        }
+        return;
+    }
+    for (size_t j = i; j < MN && j < i + 4; ++j) {
+        float sum = part[j];
+        for (int k = 1; k < KS; ++k) sum += part[size_t(k) * MN + j];
+        if (y_f32) static_cast<float*>(y)[j] = sum;
+        else static_cast<_Float16*>(y)[j] = _Float16(sum);
+    }
+}
+
+// K splits of the small-batch kernel: about g_sb_waves waves in all (two per SIMD by default), at least 2 half slabs each
+int g_sb_waves = 2048;
+int g_sb_debug = 0;          // tools only: bit 0 skip the reduce launch, bit 1 the kernel leaves after its prologue (both: wrong results)
+void sb_split(const pbl_layer* L, int& KS, int& hps) {
+    static const int env_waves = [] { const char* e = getenv("PBL_SB_WAVES_DEFAULT"); return e ? atoi(e) : 0; }();   // (tools/: sweeps through bench.py)
+    if (env_waves > 0 && g_sb_waves == 2048) g_sb_waves = env_waves;
+    const int NH = int((L->K + GI_HS - 1) / GI_HS), npairs = int((L->NRB + 1) / 2);
+    int ks = (g_sb_waves + npairs / 2) / npairs;
+    if (ks > NH / 2) ks = NH / 2;
+    if (ks < 1) ks = 1;
+    hps = (NH + ks - 1) / ks;
+    KS = (NH + hps - 1) / hps;
+}
+
 size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
 bool layer_ok(const pbl_layer* layer) {
     if (!layer || (layer->K & 7) || !(layer->flags & PBL_FLAG_SLABS) || !(layer->flags & PBL_FLAG_TAIL_REPEAT)) return false;
@@ -727,4 +982,54 @@ extern "C" int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y
     void* argv[] = {&a};
     const dim3 grid(((layer->NRB + 7) / 8) * uint32_t((M + GI_TOK - 1) / GI_TOK));
     return hipLaunchKernel(k, grid, dim3((GI_NCONS + GI_NPROD) * GW), argv, GI_LDS, static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+// tuning hook (tools/): the number of waves the small-batch kernel's K split aims at
+extern "C" void pbl_debug_set_small_image_waves(int n) { g_sb_waves = n > 0 ? n : 2048; }
+extern "C" void pbl_debug_set_small_image_flags(int f) { g_sb_debug = f; }
+
+// Transient workspace of pbl_gemm_small_image_ws for M <= 32 rows: the K splits' fp32 partial outputs (0: one split).
+extern "C" size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, int M) {
+    if (!layer_ok(layer) || M < 1 || M > 32) return 0;
+    int KS, hps;
+    sb_split(layer, KS, hps);
+    return KS > 1 ? size_t(KS) * M * layer->N * sizeof(float) : 0;
+}
+
+// y[M, N] = x[M, K] . W^T (+ bias) for 1 <= M <= 32 rows over the GEMM image (the same image, the same colmax as
+// pbl_gemm_f16_image).  `workspace` (pbl_gemm_small_image_workspace_bytes(layer, M), 16-byte aligned; any content) holds the K
+// splits' partial outputs; NULL / too small: one split (slow for layers with few rows).  The same numbers as the other kernels up
+// to fp32 summation order (within the parity tolerance of tests/test_gpu_gemm.py); repeatable run to run.
+extern "C" int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
+                                       const uint32_t* colmax, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!layer || !layer->blob || !x || !y || !image || !colmax || M < 1 || M > 32) return PBL_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return PBL_ERR_MISALIGNED;
+    if (!layer_ok(layer) || layer->K < 16) return PBL_ERR_UNSUPPORTED;
+    SbArgs a;
+    if (!make_tab(layer, colmax, a.tab)) return PBL_ERR_UNSUPPORTED;
+    if (image_bytes < image_bytes_of(layer, a.tab)) return PBL_ERR_CAPACITY;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32; a.img = static_cast<const uint8_t*>(image);
+    sb_split(layer, a.KS, a.hps);
+    a.dbg = g_sb_debug;
+    const uint32_t NH = (layer->K + GI_HS - 1) / GI_HS;
+    if (a.KS > 1 && (!workspace || workspace_bytes < size_t(a.KS) * M * layer->N * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15))) { a.KS = 1; a.hps = int(NH); }
+    a.part = a.KS > 1 ? static_cast<float*>(workspace) : nullptr;
+    uint32_t nvk = 1;
+    for (uint32_t h = 0; h < NH; ++h) nvk = nvk > (a.tab.t[h] >> 16) ? nvk : (a.tab.t[h] >> 16);
+    const bool kt = (layer->K & (GI_HS - 1)) != 0;
+#define SB_PICK(NV_) (kt ? reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, true>) : reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, false>))
+    const void* k = nvk == 1 ? SB_PICK(1) : nvk == 2 ? SB_PICK(2) : nvk == 3 ? SB_PICK(3) : nvk == 4 ? SB_PICK(4) : SB_PICK(5);
+#undef SB_PICK
+    void* argv[] = {&a};
+    const uint32_t npairs = (layer->NRB + 1) / 2;
+    if (hipLaunchKernel(k, dim3((npairs + SB_WAVES - 1) / SB_WAVES, uint32_t(a.KS)), dim3((SB_WAVES + 1) * GW), argv, 0, st) != hipSuccess) return PBL_ERR_LAUNCH;
+    if (a.KS > 1 && !(g_sb_debug & 1)) {
+        const float* part = a.part;
+        size_t MN = size_t(M) * layer->N;
+        int KS = a.KS;
+        void* rv[] = {&part, &y, &KS, &MN, &y_f32};
+        if (hipLaunchKernel(reinterpret_cast<const void*>(sb_reduce_kernel), dim3(uint32_t((MN + 1023) / 1024)), dim3(256), rv, 0, st) != hipSuccess) return PBL_ERR_LAUNCH;
+    }
+    return PBL_OK;
 }

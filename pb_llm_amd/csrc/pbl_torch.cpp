@@ -3,7 +3,9 @@
 // north_star asks for "a PyTorch-ROCm C++/HIP extension with the same nn.Linear-compatible signature".  The boundary stays the
 // C ABI (include/pbl.h); this file is the torch side of it in C++: ONE operator that does everything `module(x)` needs for any
 // row count and activation dtype --
-//   * decode / small batch (<= 32 rows): pbl_linear_f16_ws (GEMV passes or the matrix-core kernel, routed by the library);
+//   * decode / small batch (<= 32 rows): pbl_linear_f16_ws (GEMV passes or the matrix-core kernel, routed by the library), or --
+//     from 8 rows, when the caller hands the layer's GEMM image over -- the small-batch kernel over the image
+//     (pbl_gemm_small_image_ws);
 //     bf16 activations as one fp16 pass (exact inside fp16's range; per-token power-of-two scaling outside it, or the dense
 //     path when the range check finds out-of-range / non-finite values), fp32 activations as two fp16 terms;
 //   * GEMM regime (> 32 rows: prefill, the reference's perplexity loops gptq_pb/eval_ppl_utils.py:55-64): the hand-written
@@ -32,6 +34,7 @@ namespace {
 
 constexpr int64_t MFMA_MAX = 32;        // rows the packed small-batch kernels take (pb_llm_amd/quant.py: MFMA_MAX)
 constexpr int64_t GEMM_THRESHOLD = 12;  // ... and where layers the matrix-core kernel refuses switch to the dense path
+constexpr int64_t SMALL_IMAGE_MIN = 8;  // rows from which the small-batch kernel over the GEMM image beats the one over the records (pb_llm_amd/quant.py)
 
 pbl_layer make_layer(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, int64_t N, int64_t K, int64_t P, int64_t G,
                      int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool with_bias) {
@@ -63,9 +66,27 @@ void check(int rc, const char* what) { TORCH_CHECK(rc == PBL_OK, "libpbl ", what
 
 hipStream_t stream_of(const at::Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 
-// <= 32 rows of fp16 x [M, K] -> y [M, N] (fp16 / fp32); scratch from the caching allocator (stream ordered, graph safe)
-at::Tensor run_small(const pbl_layer& L, const at::Tensor& xc, int64_t M, bool f32) {
+// the layer's GEMM image as the caller handed it over (pb_llm_amd/quant.py keeps it with the packed weight)
+struct ImageRef {
+    const void* data = nullptr;
+    size_t bytes = 0;
+    std::vector<uint32_t> colmax;
+    explicit operator bool() const { return data != nullptr; }
+};
+
+// <= 32 rows of fp16 x [M, K] -> y [M, N] (fp16 / fp32); scratch from the caching allocator (stream ordered, graph safe).  With
+// the layer's GEMM image and SMALL_IMAGE_MIN rows or more: the small-batch kernel over the image (pbl_gemm_small_image_ws).
+at::Tensor run_small(const pbl_layer& L, const at::Tensor& xc, int64_t M, bool f32, const ImageRef& img) {
     at::Tensor y = at::empty({M, int64_t(L.N)}, xc.options().dtype(f32 ? at::kFloat : at::kHalf));
+    if (img && M >= SMALL_IMAGE_MIN && (reinterpret_cast<uintptr_t>(xc.data_ptr()) & 15) == 0) {
+        const size_t nbi = pbl_gemm_small_image_workspace_bytes(&L, int(M));
+        at::Tensor wsi;
+        if (nbi) wsi = at::empty({int64_t(nbi)}, xc.options().dtype(at::kByte));
+        const int rc = pbl_gemm_small_image_ws(&L, xc.data_ptr(), y.data_ptr(), int(M), f32 ? 1 : 0, img.data, img.bytes, img.colmax.data(),
+                                               nbi ? wsi.data_ptr() : nullptr, nbi, stream_of(xc));
+        if (rc == PBL_OK) return y;
+        TORCH_CHECK(rc == PBL_ERR_UNSUPPORTED, "libpbl gemm_small_image: ", pbl_status_string(rc), " (", rc, ")");   // (a layer it does not take: the records kernel)
+    }
     const size_t nb = M > 1 ? pbl_linear_workspace_bytes(&L, int(M)) : 0;      // one token is always one GEMV pass
     at::Tensor ws;
     if (nb) ws = at::empty({int64_t(nb)}, xc.options().dtype(at::kByte));
@@ -103,6 +124,11 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
     const bool has_bias = L.bias != nullptr;
     const int64_t rows = xt == at::kFloat ? 2 * M : M;     // fp32 x runs as two fp16 terms (bf16 converts exactly)
     const bool mok = mfma_ok(K, G, flags);
+    ImageRef iref;
+    if (image.has_value() && image->defined() && colmax.has_value()) {
+        iref.data = image->data_ptr(); iref.bytes = size_t(image->numel());
+        iref.colmax.assign(colmax->begin(), colmax->end());
+    }
     auto dense_path = [&](at::ScalarType wdt) {
         const at::Tensor W = unpack(L, x, wdt);
         at::Tensor y = at::linear(x2.to(wdt), W, has_bias ? c10::optional<at::Tensor>(bias->to(wdt)) : c10::nullopt);
@@ -114,13 +140,12 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
         if (backend != "library" && wdt == at::kHalf && fused_ok(K, G, flags)) {
             const at::Tensor xc = x2.contiguous();
             if ((reinterpret_cast<uintptr_t>(xc.data_ptr()) & 15) == 0) {
-                const bool img = image.has_value() && image->defined() && colmax.has_value();
+                const bool img = bool(iref);
                 if (img || backend == "fused") {
                     at::Tensor y = at::empty({M, N}, x.options().dtype(out_f32 ? at::kFloat : at::kHalf));
                     if (img) {
-                        std::vector<uint32_t> cm(colmax->begin(), colmax->end());
-                        check(pbl_gemm_f16_image(&L, xc.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, image->data_ptr(), size_t(image->numel()),
-                                                 cm.data(), stream_of(x)), "gemm_f16_image");
+                        check(pbl_gemm_f16_image(&L, xc.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, iref.data, iref.bytes, iref.colmax.data(),
+                                                 stream_of(x)), "gemm_f16_image");
                     } else {
                         const size_t nb = pbl_gemm_workspace_bytes(&L, int(M));
                         at::Tensor ws;
@@ -134,7 +159,7 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
         }
         return dense_path(wdt);
     }
-    if (xt == at::kHalf) return run_small(L, x2.contiguous(), M, out_f32).reshape(shape);
+    if (xt == at::kHalf) return run_small(L, x2.contiguous(), M, out_f32, iref).reshape(shape);
     if (xt == at::kBFloat16) {
         // see pb_llm_amd/quant.py (_pb_linear_forward, bf16): range check with one host sync (never under capture) -> dense path
         // for out-of-range / non-finite inputs; else per-token power-of-two scaling on the device, exact for all finite inputs
@@ -144,7 +169,7 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
         const at::Tensor amax = xf.abs().amax({1}, true);
         const at::Tensor e = amax.view(at::kInt).bitwise_right_shift(23).bitwise_and(0xFF).sub(127 + 14).clamp_min(0);
         const at::Tensor sc = at::ldexp(at::ones_like(amax), e.neg());
-        at::Tensor y = run_small(Lnb, xf.mul(sc).to(at::kHalf).contiguous(), M, true).div(sc);
+        at::Tensor y = run_small(Lnb, xf.mul(sc).to(at::kHalf).contiguous(), M, true, iref).div(sc);
         y = at::where(at::isfinite(amax), y, at::full_like(y, std::numeric_limits<float>::quiet_NaN()));
         if (has_bias) y = y.add(*bias);
         return y.to(out_dt).reshape(shape);
@@ -153,7 +178,7 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
     // fp32 (bias added once)
     const at::Tensor x_hi = x2.to(at::kHalf);
     const at::Tensor x_lo = x2.sub(x_hi.to(at::kFloat)).to(at::kHalf);
-    const at::Tensor yy = run_small(Lnb, at::cat({x_hi, x_lo}, 0).contiguous(), 2 * M, true);
+    const at::Tensor yy = run_small(Lnb, at::cat({x_hi, x_lo}, 0).contiguous(), 2 * M, true, iref);
     at::Tensor y = yy.narrow(0, 0, M).add(yy.narrow(0, M, M));
     if (has_bias) y = y.add(*bias);
     return y.to(out_dt).reshape(shape);

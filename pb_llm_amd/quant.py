@@ -65,6 +65,12 @@ GEMM_KEEP_LIST = os.environ.get("PBL_GEMM_KEEP_LIST", "0") == "1"
 # the layer (1 KiB per 16 rows x 128 columns: 8.4 MB for a 4096^2 layer at 5 % salients, a quarter of the dense fp16 weight).
 # "0": the round-3 kernel over the per-call (or kept) salient list.
 GEMM_KEEP_IMAGE = os.environ.get("PBL_GEMM_KEEP_IMAGE", "1") == "1"
+# 8 - 32 rows (a small serving batch; BASELINE.json configs[3]): the small-batch kernel over the same image
+# (pbl_gemm_small_image_ws; 13824 x 5120 at 20 % salients and 32 rows: 24.7 us against 39.7 for the kernel over the packed
+# records).  The image costs memory (2.5 x the blob at 20 % salients), so by default ("auto") only an image that a prefill call
+# already built is used; "1" builds it on the first small-batch call as well, "0" never uses it.
+SMALL_BATCH_IMAGE = os.environ.get("PBL_SMALL_BATCH_IMAGE", "auto")
+SMALL_IMAGE_MIN = 8
 BF16_RANGE_CHECK = os.environ.get("PBL_BF16_RANGE_CHECK", "1") == "1"
 
 
@@ -102,6 +108,22 @@ def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32
     ws = torch.empty(nb, dtype=torch.uint8, device=x2.device) if nb else None
     _lib.check(L.pbl_gemm_f16_ws(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), ws.data_ptr() if ws is not None else None, nb,
                                  torch.cuda.current_stream(x2.device).cuda_stream), "gemm_f16")
+    return y
+
+
+def small_image_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, image: "GemmImage", out_f32: bool = False) -> torch.Tensor:
+    """pbl_gemm_small_image_ws: x2 [M <= 32, K] fp16 contiguous -> [M, N] over the layer's GEMM image (the small-batch kernel of
+    csrc/pbl_gemm_img.hip); the K splits' partial outputs go through a transient workspace from the caching allocator."""
+    M = x2.shape[0]
+    y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
+    layer = packed.layer_struct(bias_f32)
+    L = _lib.lib()
+    cur = torch.cuda.current_stream(x2.device)
+    cur.wait_event(image.ready)
+    nb = int(L.pbl_gemm_small_image_workspace_bytes(C.byref(layer), M))
+    ws = torch.empty(nb, dtype=torch.uint8, device=x2.device) if nb else None
+    _lib.check(L.pbl_gemm_small_image_ws(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), image.data.data_ptr(), image.data.numel(),
+                                         image.colmax, ws.data_ptr() if nb else None, nb, cur.cuda_stream), "gemm_small_image")
     return y
 
 
@@ -185,6 +207,17 @@ def _kept_image(packed: PackedWeight) -> GemmImage | None:
         kept = (key, gemm_image(packed))
         packed._gemm_image = kept
     return kept[1]
+
+
+def _small_batch_image(packed: PackedWeight) -> GemmImage | None:
+    """the image the small-batch kernel (8 - 32 rows) multiplies from, by SMALL_BATCH_IMAGE: "auto" -- the kept image if an earlier
+    GEMM-regime call built one; "1" -- built here on first use; "0" -- never (the kernel over the packed records runs)."""
+    if SMALL_BATCH_IMAGE == "0" or not GEMM_KEEP_IMAGE or not fused_gemm_ok(packed):
+        return None
+    if SMALL_BATCH_IMAGE == "1":
+        return _kept_image(packed)
+    kept = getattr(packed, "_gemm_image", None)
+    return kept[1] if kept is not None and kept[0] == (packed.blob.data_ptr(), packed.blob._version) else None
 
 
 def _kept_list(packed: PackedWeight) -> torch.Tensor | None:
@@ -271,12 +304,17 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
         dense_f16 = dense_dtype in (None, torch.float16)
         img, colmax, backend = None, None, GEMM_BACKEND
         M = x.numel() // packed.K
-        if M > MFMA_MAX and backend != "library" and x.dtype == torch.float16 and dense_f16 and GEMM_KEEP_IMAGE \
-                and fused_gemm_ok(packed) and (backend == "fused" or _image_fills_the_chip(packed.N, M, x.device)):
-            ki = _kept_image(packed)
-            if ki is not None:
-                torch.cuda.current_stream(x.device).wait_event(ki.ready)
-                img, colmax = ki.data, ki.colmax_list
+        rows = 2 * M if x.dtype == torch.float32 else M
+        ki = None
+        if rows > MFMA_MAX:
+            if backend != "library" and x.dtype == torch.float16 and dense_f16 and GEMM_KEEP_IMAGE \
+                    and fused_gemm_ok(packed) and (backend == "fused" or _image_fills_the_chip(packed.N, M, x.device)):
+                ki = _kept_image(packed)
+        elif rows >= SMALL_IMAGE_MIN and dense_f16:          # (the image holds fp16 weights: layers an fp16 checkpoint is exact for)
+            ki = _small_batch_image(packed)
+        if ki is not None:
+            torch.cuda.current_stream(x.device).wait_event(ki.ready)
+            img, colmax = ki.data, ki.colmax_list
         return nat(packed.blob, bias_f32, x, packed.N, packed.K, packed.P, packed.G, packed.NRB, packed.flags,
                    packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, colmax, backend, BF16_RANGE_CHECK)
     # the ctypes route (variant libraries through PBL_LIB, PBL_NATIVE=0, a dispatcher that did not build)
@@ -331,6 +369,9 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         return y.reshape(*lead, packed.N)
     if x.dtype == torch.float16:
         xc = x2.contiguous()
+        simg = _small_batch_image(packed) if M >= SMALL_IMAGE_MIN and xc.data_ptr() % 16 == 0 and dense_dtype in (None, torch.float16) else None
+        if simg is not None:
+            return small_image_forward(packed, bias_f32, xc, simg, out_f32).reshape(*lead, packed.N)
         y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
         run(layer, xc, y, M, out_f32)
         return y.reshape(*lead, packed.N)

@@ -120,6 +120,23 @@ def test_gemm_regime_kernel(N, K, M, gs, lf, fp16, exc, metric):
         assert torch.equal(y, Q.fused_gemm_forward(pd, T(b), xt, image=img))
         assert torch.equal(y32, Q.fused_gemm_forward(pd, None, xt, out_f32=True, image=img))
         assert torch.equal(y32[:33], Q.fused_gemm_forward(pd, None, xt[:33].contiguous(), out_f32=True, image=img))
+        # ... and the small-batch kernel over the same image (<= 32 rows: pbl_gemm_small_image_ws; K split over the grid, partial
+        # tiles added in split order): the oracle's numbers within the same tolerance, the same bits run after run
+        for ms in (1, 8, 32):
+            xs = xt[:ms].contiguous()
+            ys = Q.small_image_forward(pd, T(b), xs, img)
+            assert ys.shape == (ms, N) and ys.dtype == torch.float16
+            assert_parity(ys[:, ridx], O.dense_linear(x[:ms], W16[rows], b[rows]))
+            ys32 = Q.small_image_forward(pd, None, xs, img, out_f32=True)
+            assert_parity(ys32[:, ridx], O.dense_linear(x[:ms], W16[rows]), 3e-4)
+            assert torch.equal(ys, Q.small_image_forward(pd, T(b), xs, img)) and torch.equal(ys32, Q.small_image_forward(pd, None, xs, img, out_f32=True))
+        # one K split (no workspace): the same product
+        lay_s = pd.layer_struct(None)
+        y1 = torch.empty(8, N, dtype=torch.float32, device=DEV)
+        x8 = xt[:8].contiguous()
+        _lib.check(_lib.lib().pbl_gemm_small_image_ws(C.byref(lay_s), x8.data_ptr(), y1.data_ptr(), 8, 1, img.data.data_ptr(), img.data.numel(),
+                                                      img.colmax, None, 0, torch.cuda.current_stream().cuda_stream), "gemm_small_image")
+        assert_parity(y1[:, ridx], O.dense_linear(x[:8], W16[rows]), 3e-4)
     # the library backend on the unpacked layer: same operands, different summation order
     Wdev = Q.unpack_on_device(pd, torch.float16)
     np.testing.assert_array_equal(Wdev.float().cpu().numpy()[rows], W16[rows])

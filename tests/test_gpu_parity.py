@@ -292,6 +292,26 @@ def test_llama13b_ffn_shapes_m32():
         y = Q.PBLinear(p.to(DEV), None)(T(x))
         assert_parity(y, g["y_f32"])
         assert_parity(y, g["y"], 2e-3)   # reference fp16-weight output (weights rounded to fp16 there)
+        # the same layer as an fp16 checkpoint holds it, through the small-batch kernel over the GEMM image (round 4;
+        # quant.SMALL_BATCH_IMAGE = "1": the image is built on the first small-batch call): against the reference's fp16-weight output
+        # and the kernel over the packed records
+        lay = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+        old = Q.SMALL_BATCH_IMAGE
+        try:
+            Q.SMALL_BATCH_IMAGE = "0"
+            y_rec = lay(T(x))
+            assert getattr(lay.packed, "_gemm_image", None) is None
+            Q.SMALL_BATCH_IMAGE = "1"
+            y_img = lay(T(x))
+            img = lay.packed._gemm_image[1]
+            assert img is not None and torch.equal(y_img, Q.small_image_forward(lay.packed, None, T(x), img))
+            assert torch.equal(y_img, lay(T(x)))                                     # repeatable
+            assert_parity(y_img, g["y"], 2e-3)
+            assert_parity(y_img, y_rec.float().cpu().numpy().astype(np.float64), 2e-3)
+            assert_parity(lay(T(x)[:8]), g["y"][:8], 2e-3)                            # 8 rows: still the image kernel
+            assert_parity(lay(T(x)[:7]), g["y"][:7], 2e-3)                            # 7 rows: the records kernel
+        finally:
+            Q.SMALL_BATCH_IMAGE = old
 
 
 # ---------------------------------------------------------------- GEMM regime (device unpack + library GEMM)
