@@ -329,27 +329,30 @@ int pbl_gemm_f16_prepared(const pbl_layer* layer, const void* x, void* y, int M,
 /* GEMM regime over a per-layer GEMM IMAGE (round 4, csrc/pbl_gemm_img.hip) -- the form the prefill path uses by default.
  * Callers that run the same linears batch after batch at more than 32 rows (the reference's perplexity loops,
  * gptq_pb/eval_ppl_utils.py:55-64, evaluate.py:126-145, call every nn.Linear with 2048 rows) re-lay the packed layer ONCE
- * into fixed-size slots -- one per (16-row record, 128-column half slab): per lane the sign-plane dword and the salient
- * entries as ready-to-store {LDS offset : fp16 value} words, padded with idempotent repeats -- plus one row of level pairs
- * per (record, column group).  The GEMM kernel over an image has four matrix-core waves that only read fragments and
- * multiply, and four waves that expand one slot per 64-column step with ~105 instructions and stage x by LDS-DMA; results
- * are bit-identical to pbl_gemm_f16_ex / _ws / _prepared.  Slot size per half-slab COLUMN h (the same for every record): 1 KiB
- * (up to 192 entries in any record's slot of that column), 2 KiB (448), 3 KiB (704), 4 KiB (960) or 5 KiB (1216) -- salient density varies mostly along the
- * columns (the hessian metric concentrates salients in a few input channels, gptq_pb/gptq.py:93-99).  8.4 MB for a 4096 x 4096
- * layer at 5 % magnitude salients (packed blob 5.1 MB, dense fp16 33.5 MB).
- *   pbl_gemm_image_stats   one small kernel: per column h the largest entry count of any record's slot -> the device words
- *                          colmax_dev[0 .. ceil(K / 128)) (uint32, zeroed by the caller); the caller reads them back ONCE per
- *                          layer and passes the HOST copy to the other three calls
- *   pbl_gemm_image_bytes   size of the image for those maxima; 0 = no image for this layer (K % 8, more than 127 half slabs,
- *                          a group size that is not a multiple of 128, more than 1216 entries in one slot): use pbl_gemm_f16_ws
- *   pbl_gemm_image_build   one small kernel on `stream` into caller-owned memory (16-byte aligned); valid until the blob changes
+ * into slots -- one per (16-row record, 128-column half slab): per lane the sign-plane dword and the salient entries as
+ * ready-to-store {LDS offset : fp16 value} words, padded with idempotent repeats -- plus one row of level pairs per (record,
+ * column group).  The GEMM kernel over an image has four matrix-core waves that only read fragments and multiply, and four
+ * waves that expand one slot per 64-column step with ~105 instructions and stage x by LDS-DMA; results are bit-identical to
+ * pbl_gemm_f16_ex / _ws / _prepared.  Every slot is sized for its own entry count: 1 KiB (up to 192 entries), 2 KiB (448),
+ * 3 KiB (704), 4 KiB (960) or 5 KiB (1216); a table of 128 words per record says where its slots are.  8.6 MB for a
+ * 4096 x 4096 layer at 5 % magnitude salients (packed blob 5.1 MB, dense fp16 33.5 MB).
+ *   pbl_gemm_image_stats_bytes  size of the statistics buffer (device) the next call fills; 0 = no image for this layer (K % 8,
+ *                          more than 127 half slabs, a group size that is not a multiple of 128): use pbl_gemm_f16_ws
+ *   pbl_gemm_image_stats   two small kernels: entry counts, slot sizes and record starts into stats_dev (16-byte aligned, any
+ *                          content).  Its first TWO uint32 words are the geometry: geom[0] = all slots in 256-byte units,
+ *                          geom[1] = the largest slot in KiB (0xFFFFFFFF: a slot with more than 1216 entries: no image); the
+ *                          caller reads them back ONCE per layer and passes the HOST copy to the other calls
+ *   pbl_gemm_image_bytes   size of the image for that geometry; 0 = no image for this layer
+ *   pbl_gemm_image_build   one small kernel on `stream` into caller-owned memory (16-byte aligned) from the layer and stats_dev
+ *                          (which may be released behind it); the image is valid until the blob changes
  *   pbl_gemm_f16_image     y[M, N] = x[M, K] . W^T (+ bias), fp16 x, fp16 or fp32 y, any M >= 1
- * The library keeps no reference to the image or to colmax between calls. */
-int pbl_gemm_image_stats(const pbl_layer* layer, void* colmax_dev, void* stream);
-size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* colmax);
-int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* colmax, void* image, size_t image_bytes, void* stream);
+ * The library keeps no reference to the image, the statistics buffer or geom between calls. */
+size_t pbl_gemm_image_stats_bytes(const pbl_layer* layer);
+int pbl_gemm_image_stats(const pbl_layer* layer, void* stats_dev, void* stream);
+size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* geom);
+int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, void* stream);
 int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
-                       const uint32_t* colmax, void* stream);
+                       const uint32_t* geom, void* stream);
 /* The same product for 1 <= M <= 32 rows of x over the same image (HBM-bound: the image is read once; every wave owns 32 rows of W
  * and a range of 128-column half slabs, K is split over the grid).  workspace: pbl_gemm_small_image_workspace_bytes(layer, M) bytes,
  * 16-byte aligned, any content (the splits' fp32 partial outputs, added in split order by a second small kernel: deterministic);
@@ -357,7 +360,7 @@ int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, in
  * Replaces F.linear at a small serving batch (quant/outlier_quantizer.py:101-106 at <= 32 rows; BASELINE.json configs[3]). */
 size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, int M);
 int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
-                            const uint32_t* colmax, void* workspace, size_t workspace_bytes, void* stream);
+                            const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Decode-time FUSED projections (q/k/v, gate/up: layers that read the same activation): L layers, ONE x [M, K] (fp16,
  * 16-B aligned rows are not required), ONE output matrix y [M, ldy] in which layer l owns the columns

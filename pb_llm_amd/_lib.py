@@ -50,7 +50,7 @@ _lib = None
 EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_pack_dev_count", "pbl_pack_dev_write", "pbl_blob_describe",
            "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_linear_f16_ws", "pbl_gemm_mfma_f16",
            "pbl_gemm_mfma_f16_ws", "pbl_mfma_workspace_bytes", "pbl_linear_workspace_bytes", "pbl_gemv_f16_grouped", "pbl_gemv_f16_fused", "pbl_gemv_f16_fused_host", "pbl_gemm_f16", "pbl_gemm_f16_ex", "pbl_gemm_f16_ws", "pbl_gemm_workspace_bytes", "pbl_gemm_list_bytes", "pbl_gemm_prepare", "pbl_gemm_f16_prepared",
-           "pbl_gemm_image_stats", "pbl_gemm_image_bytes", "pbl_gemm_image_build", "pbl_gemm_f16_image",
+           "pbl_gemm_image_stats_bytes", "pbl_gemm_image_stats", "pbl_gemm_image_bytes", "pbl_gemm_image_build", "pbl_gemm_f16_image",
            "pbl_gemm_small_image_workspace_bytes", "pbl_gemm_small_image_ws",
            "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad",
            "pbl_prep_workspace_bytes", "pbl_kth_pair", "pbl_outlier_mask", "pbl_quant8_rows", "pbl_high_calibrate", "pbl_gptq_block",
@@ -116,12 +116,14 @@ def lib() -> C.CDLL:
     L.pbl_gemm_prepare.argtypes = [C.POINTER(PblLayer), vp, sz, vp]
     L.pbl_gemm_f16_prepared.restype = C.c_int
     L.pbl_gemm_f16_prepared.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, sz, vp]
+    L.pbl_gemm_image_stats_bytes.restype = sz
+    L.pbl_gemm_image_stats_bytes.argtypes = [C.POINTER(PblLayer)]
     L.pbl_gemm_image_stats.restype = C.c_int
     L.pbl_gemm_image_stats.argtypes = [C.POINTER(PblLayer), vp, vp]
     L.pbl_gemm_image_bytes.restype = sz
     L.pbl_gemm_image_bytes.argtypes = [C.POINTER(PblLayer), vp]
     L.pbl_gemm_image_build.restype = C.c_int
-    L.pbl_gemm_image_build.argtypes = [C.POINTER(PblLayer), vp, vp, sz, vp]
+    L.pbl_gemm_image_build.argtypes = [C.POINTER(PblLayer), vp, vp, vp, sz, vp]
     L.pbl_gemm_f16_image.restype = C.c_int
     L.pbl_gemm_f16_image.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, sz, vp, vp]
     L.pbl_gemm_small_image_workspace_bytes.restype = sz

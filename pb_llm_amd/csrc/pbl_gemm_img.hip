@@ -46,7 +46,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define GI_LDS (GI_X_OFF + 3 * GI_XSLOT)           // 163840 B
 #define GI_MAX_NH 127
 #define GI_NVMAX 5                // 16-byte vectors per lane in the largest slot
-#define GI_IMG_MAGIC 0x32494250u                   // "PBI2" (slots vector-major: every 16-byte load of a wave is one contiguous KiB)
+#define GI_IMG_MAGIC 0x33494250u                   // "PBI3" (slots vector-major, sized per record and half slab)
 #define GI_PREP_THREADS 1024
 #ifndef PBL_GEMM_PPRIO
 #define PBL_GEMM_PPRIO 1
@@ -75,23 +75,21 @@ extern "C" void pbl_debug_trace_gemm_img(void* p) { g_img_trace = static_cast<ui
 
 namespace {
 
-// image header (64 bytes); the records' slot rows follow at slots_off (record stride = tab.t[NH] * 256 bytes, slot h of a record at
-// (tab.t[h] & 0xFFFF) * 256, [nv_h vectors][64 lanes][4] u32: word w of lane l at (w >> 2) * 256 + 4 l + (w & 3)), the level table
-// [NRB][G][16] u32 at levels_off
+// The image: [header 64 B][rbase: NRB u32][rtab: NRB x 128 u32][slots][levels: NRB x G x 16 u32].
+//   rbase[r]    where record r's slots start, in 256-byte units from slots_off;
+//   rtab[r][h]  slot of half slab h of record r: (offset from the record's start, 256-byte units) | nv << 16, nv = 1 .. 5 sixteen-byte
+//               vectors per lane = 3, 7, 11, 15 or 19 entry words per lane = up to 192 / 448 / 704 / 960 / 1216 entries.  Every slot is
+//               sized for ITS OWN entry count (round 4, second layout): with one size per column (the maximum over the records) a
+//               layer with 20 % salients needed 3 KiB for slots that hold 410 entries on average -- 106 MB where 71 do, and the
+//               small-batch kernel is bound by exactly those bytes.
+//   slot        [nv vectors][64 lanes][4] u32: word w of lane l at (w >> 2) * 256 + 4 l + (w & 3); word 0 the lane's sign-plane dword.
+// Geometry words (host side, read back once after pbl_gemm_image_stats): geom[0] = all slots in 256-byte units, geom[1] = the largest nv.
 struct ImgHeader {
-    uint32_t magic, stride256, NH, NRB, G, K, N, flags;
-    uint64_t slots_off, levels_off, total;
-    uint32_t pad[2];
+    uint32_t magic, NH, NRB, G, K, N, flags, nvmax;
+    uint64_t rtab_off, slots_off, levels_off, total;
 };
 static_assert(sizeof(ImgHeader) == 64, "image header is 64 bytes");
-
-// Slot geometry per half-slab COLUMN h (the same for every record): t[h] = offset in the record's slot row (256-byte units) |
-// nv_h << 16, nv_h = 1 .. 5 sixteen-byte vectors per lane = 3, 7, 11, 15 or 19 entry words per lane = up to 192 / 448 / 704 / 960 /
-// 1216 entries;
-// t[NH] = the row's length.  Salient density varies mostly along the columns (the hessian metric concentrates salients in a few
-// input channels, gptq_pb/gptq.py:93-99): sizing every slot for the densest one would triple the image.  Passed by value in the
-// kernel arguments (512 B): a scalar load with a uniform index, tracked by the compiler.
-struct ImgTab { uint32_t t[128]; };
+#define GI_TABW 128                // words of a record's slot table
 
 __device__ __forceinline__ _Float16 round_f16_twice(float prod) {
     asm volatile("" : "+v"(prod));   // keep the fp32 product: an fp16-checkpoint value is double rounded
@@ -100,14 +98,23 @@ __device__ __forceinline__ _Float16 round_f16_twice(float prod) {
 __device__ __forceinline__ uint32_t h16(float v) { return uint32_t(__builtin_bit_cast(uint16_t, _Float16(v))); }
 
 // ---- building the image ---------------------------------------------------------------------------------------------------
-// One workgroup per record.  STATS: only count the entries of every (record, half slab) and fold the maximum into *maxn (the
-// caller sizes the slots with it).  Otherwise fill the record's NH slots and its level rows.
+// One workgroup per record.  STATS: count the entries of every half slab of the record, size its slots (rtab[rb][..], rlen[rb] = the
+// record's slots in 256-byte units, geom[1] = the largest nv; 0xFFFFFFFF: a slot would need more than five vectors).  Otherwise fill
+// the record's slots (at rbase[rb], sized by rtab[rb]), copy its table row and start into the image, and write its level rows.
+struct PrepArgs {
+    uint8_t* img;                  // build: the image
+    uint32_t* geom;                // stats: geom[1] (max nv)
+    uint32_t* rlen;                // stats: out, slots of the record in 256-byte units; build: in, rbase (the exclusive prefix sum)
+    uint32_t* rtab;                // stats: out; build: in
+    uint64_t rtab_off, slots_off, levels_off, total;
+};
 template <bool STATS>
-__global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, uint8_t* __restrict__ img, ImgTab tab, uint32_t* __restrict__ colmax) {
+__global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, PrepArgs pa) {
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
     uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem_p);            // entries per half slab
     uint32_t* s_first = s_cnt + (GI_MAX_NH + 1);                       // the first word written to a half slab (padding repeats it)
-    float* s_ss = reinterpret_cast<float*>(s_first + (GI_MAX_NH + 1));
+    uint32_t* s_tab = s_first + (GI_MAX_NH + 1);                       // the record's slot table
+    float* s_ss = reinterpret_cast<float*>(s_tab + GI_TABW);
     float* s_sz = s_ss + 16;
     pbl_rowinfo* s_ri = reinterpret_cast<pbl_rowinfo*>(s_sz + 16);
     uint8_t* s_crow = reinterpret_cast<uint8_t*>(s_ri + 16);
@@ -129,9 +136,11 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
     const pbl_rowparams* params = reinterpret_cast<const pbl_rowparams*>(rec + PBL_REC_PARAMS_OFF);
     const float2* ghl = reinterpret_cast<const float2*>(rec + PBL_REC_GHL_OFF);
     const uint32_t* tile_dw = reinterpret_cast<const uint32_t*>(rec + tiles_off);
-    const uint32_t stride256 = tab.t[NH];
-    uint8_t* slotrow = STATS ? nullptr : img + sizeof(ImgHeader) + size_t(rb) * stride256 * 256;
-    auto slot_of = [&](uint32_t h) -> uint32_t* { return reinterpret_cast<uint32_t*>(slotrow + size_t(tab.t[h] & 0xFFFFu) * 256); };
+    uint8_t* const img = pa.img;
+    uint8_t* slotrow = STATS ? nullptr : img + pa.slots_off + size_t(pa.rlen[rb]) * 256;
+    auto slot_of = [&](uint32_t h) -> uint32_t* { return reinterpret_cast<uint32_t*>(slotrow + size_t(s_tab[h] & 0xFFFFu) * 256); };
+    if (!STATS)
+        for (int h = tid; h < GI_TABW; h += GI_PREP_THREADS) s_tab[h] = pa.rtab[size_t(rb) * GI_TABW + h];
     if (tid < 16) {
         s_ri[tid] = reinterpret_cast<const pbl_rowinfo*>(rec + PBL_REC_ROWINFO_OFF)[tid];
         s_ss[tid] = params[tid].sscale; s_sz[tid] = params[tid].szero;
@@ -146,7 +155,7 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
     __syncthreads();
     auto put = [&](uint32_t h, uint32_t j, uint32_t word) {   // entry j of half slab h: lane j & 63, word 1 + (j >> 6)
         if (j == 0) s_first[h] = word;
-        const uint32_t EW = 4u * (tab.t[h] >> 16);
+        const uint32_t EW = 4u * (s_tab[h] >> 16);
         const uint32_t w = 1u + (j >> 6);
         if (j < 64u * (EW - 1u)) slot_of(h)[(w >> 2) * 256u + (j & 63u) * 4u + (w & 3u)] = word;
     };
@@ -191,8 +200,22 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
     }
     __syncthreads();
     if (STATS) {
-        for (int h = tid; h < NH; h += GI_PREP_THREADS)
-            if (s_cnt[h]) atomicMax(colmax + h, s_cnt[h]);
+        if (tid == 0) {
+            uint32_t off = 0, nvmax = 0;
+            for (int h = 0; h < GI_TABW; ++h) {
+                uint32_t t = 0;
+                if (h < NH) {
+                    const uint32_t m = s_cnt[h];
+                    const uint32_t nv = m <= 192u ? 1u : (m <= 448u ? 2u : (m <= 704u ? 3u : (m <= 960u ? 4u : (m <= 1216u ? 5u : 0u))));
+                    nvmax = max(nvmax, nv ? nv : 0xFFFFFFFFu);
+                    t = off | (nv << 16);
+                    off += 4u * nv;                        // 1 KiB = four 256-byte units per vector
+                }
+                pa.rtab[size_t(rb) * GI_TABW + h] = t;
+            }
+            pa.rlen[rb] = off;
+            atomicMax(pa.geom + 1, nvmax);
+        }
         return;
     }
     // the plane dword of every (half slab, lane) and the padding: unused words repeat the half slab's first entry (the same
@@ -201,7 +224,7 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
     for (int it = tid; it < NH * 64; it += GI_PREP_THREADS) {
         const int h = it >> 6, l = it & 63;
         const uint32_t d = uint32_t(h >> 2) < L.P ? tile_dw[size_t(h >> 2) * 256 + l * 4 + (h & 3)] : 0u;
-        const uint32_t EW = 4u * (tab.t[h] >> 16);
+        const uint32_t EW = 4u * (s_tab[h] >> 16);
         uint32_t* sl = slot_of(uint32_t(h)) + size_t(l) * 4;       // word k of this lane: sl[(k >> 2) * 256 + (k & 3)]
         sl[0] = d;
         const uint32_t n = s_cnt[h];
@@ -217,7 +240,7 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
             if ((k - 1u) * 64u + uint32_t(l) >= n) sl[(k >> 2) * 256u + (k & 3u)] = padw;
     }
     // level rows: (hi - lo) mod 2^16 : lo as fp16 bit patterns, 16 per (record, group)
-    uint32_t* lev = reinterpret_cast<uint32_t*>(img + sizeof(ImgHeader) + size_t(L.NRB) * stride256 * 256) + size_t(rb) * L.G * 16;
+    uint32_t* lev = reinterpret_cast<uint32_t*>(img + pa.levels_off) + size_t(rb) * L.G * 16;
     for (uint32_t it = tid; it < 16u * L.G; it += GI_PREP_THREADS) {
         const uint32_t g = it >> 4, r = it & 15u;
         float hi, lo;
@@ -226,14 +249,34 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
         const uint32_t hh = h16(hi), ll = h16(lo);
         lev[it] = (((hh - ll) & 0xFFFFu) << 16) | ll;
     }
+    // the record's table row and start, into the image
+    for (int h = tid; h < GI_TABW; h += GI_PREP_THREADS) reinterpret_cast<uint32_t*>(img + pa.rtab_off)[size_t(rb) * GI_TABW + h] = s_tab[h];
+    if (tid == 0) reinterpret_cast<uint32_t*>(img + sizeof(ImgHeader))[rb] = pa.rlen[rb];
     if (rb == 0 && tid == 0) {
         ImgHeader* w = reinterpret_cast<ImgHeader*>(img);
-        w->magic = GI_IMG_MAGIC; w->stride256 = stride256; w->NH = uint32_t(NH); w->NRB = L.NRB; w->G = L.G; w->K = L.K; w->N = L.N; w->flags = L.flags;
-        w->slots_off = sizeof(ImgHeader);
-        w->levels_off = sizeof(ImgHeader) + uint64_t(L.NRB) * stride256 * 256;
-        w->total = w->levels_off + uint64_t(L.NRB) * L.G * 64;
-        w->pad[0] = w->pad[1] = 0;
+        w->magic = GI_IMG_MAGIC; w->NH = uint32_t(NH); w->NRB = L.NRB; w->G = L.G; w->K = L.K; w->N = L.N; w->flags = L.flags; w->nvmax = 0;
+        w->rtab_off = pa.rtab_off; w->slots_off = pa.slots_off; w->levels_off = pa.levels_off; w->total = pa.total;
     }
+}
+
+// rlen[0 .. NRB) -> its exclusive prefix sum in place; geom[0] = the sum.  One workgroup.
+__global__ __launch_bounds__(1024) void img_scan_kernel(uint32_t* __restrict__ geom, uint32_t* __restrict__ rlen, uint32_t NRB) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, per = (NRB + 1023u) / 1024u;
+    const uint32_t b = tid * per, e = min(b + per, NRB);
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; ++i) sum += rlen[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (uint32_t i = b; i < e; ++i) { const uint32_t v = rlen[i]; rlen[i] = run; run += v; }
+    if (tid == 1023u) geom[0] = part[1023];
 }
 
 // ---- the GEMM ---------------------------------------------------------------------------------------------------------------
@@ -242,8 +285,10 @@ struct ImgArgs {
     const _Float16* x;      // [M, K]
     void* y;                // [M, N] fp16 / fp32
     int M, y_f32;
-    const uint8_t* img;
-    ImgTab tab;
+    const uint8_t* slots;   // the image's slots, its record starts, slot tables and level rows
+    const uint32_t* rbase;
+    const uint32_t* rtab;
+    const uint32_t* levels;
 #if PBL_TRACE
     uint64_t* trace;
 #endif
@@ -304,17 +349,22 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
 #if PBL_GEMM_PPRIO
         __builtin_amdgcn_s_setprio(PBL_GEMM_PPRIO);
 #endif
-        const uint32_t stride256 = a.tab.t[NH];
-        const uint8_t* slots = a.img + sizeof(ImgHeader);
-        const uint32_t* levels = reinterpret_cast<const uint32_t*>(slots + size_t(L.NRB) * stride256 * 256);
+        const uint32_t* levels = a.levels;
         const uint32_t gs = L.K / L.G;                          // columns per group (a multiple of 128)
         uint32_t rbv[2];
-        const uint8_t* sbase[2];                                // the record's slot row (wave uniform)
+        const uint8_t* sbase[2];                                // the record's slots (wave uniform)
+        uint32_t tabv[2][2];                                    // its slot table: lane l holds the words of half slabs l and 64 + l
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             rbv[i] = min(rowblk * 8 + 2 * uint32_t(p) + uint32_t(i), L.NRB - 1);      // (a record beyond the layer mirrors the last one; its rows are never stored)
-            sbase[i] = slots + size_t(rbv[i]) * stride256 * 256;
+            sbase[i] = a.slots + size_t(__builtin_amdgcn_readfirstlane(a.rbase[rbv[i]])) * 256;
+            tabv[i][0] = a.rtab[size_t(rbv[i]) * GI_TABW + lane];
+            tabv[i][1] = a.rtab[size_t(rbv[i]) * GI_TABW + 64 + lane];
         }
+        auto slot_word = [&](int i, int hh) -> uint32_t {         // rtab[record i][hh], hh uniform
+            const uint32_t lo = __builtin_amdgcn_readlane(tabv[i][0], hh & 63), hi = __builtin_amdgcn_readlane(tabv[i][1], hh & 63);
+            return hh < 64 ? lo : hi;
+        };
         const uint32_t lane16 = uint32_t(lane) * 16u;
         uint32_t hl[2][16];                                     // (hi - lo : lo) of the 16 rows, current column group: SGPRs
         auto load_levels = [&](int i, uint32_t g) {
@@ -337,7 +387,7 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
         // scalar branch INSIDE the block: with the loads under C++ branches the compiler merges the paths with register copies
         // (v_mov of registers whose load is in flight -- found by tools/audit_asm_loads.py in the first per-column build).
         auto request = [&](int i, int hh, u32x4 (&dst)[GI_NVMAX], int& nv_out) {
-            const uint32_t t = a.tab.t[min(hh, NH - 1)];
+            const uint32_t t = slot_word(i, min(hh, NH - 1));
             const uint32_t nv = t >> 16;
             const uint8_t* sp = sbase[i] + size_t(t & 0xFFFFu) * 256 + 2048;      // (biased: the instruction offset is 13 bits, signed)
             const uint32_t lo = lane16;                         // vector v of the slot: one contiguous KiB, 16 bytes per lane
@@ -657,9 +707,11 @@ struct SbArgs {
     void* y;                // [M, N] fp16 / fp32 (KS == 1)
     float* part;            // [KS][M][N] fp32 (KS > 1)
     int M, y_f32, KS, hps;  // hps: half slabs per K split
-    const uint8_t* img;
+    const uint8_t* slots;   // the image's slots, its record starts, slot tables and level rows
+    const uint32_t* rbase;
+    const uint32_t* rtab;
+    const uint32_t* levels;
     int dbg;
-    ImgTab tab;
 };
 #define SB_WAVES 4                   // working waves of a workgroup (+ 1 that stages x)
 #define SB_X_OFF (SB_WAVES * 8192)
@@ -711,17 +763,22 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
     const uint32_t pair_raw = blockIdx.x * SB_WAVES + uint32_t(wave);
     const uint32_t pair = min(pair_raw, npairs - 1);         // (a surplus wave mirrors the last pair: it keeps the barriers and stores nothing)
     char* const As = smem_s + wave * 8192;
-    const uint32_t stride256 = a.tab.t[NH];
-    const uint8_t* slots = a.img + sizeof(ImgHeader);
-    const uint32_t* levels = reinterpret_cast<const uint32_t*>(slots + size_t(L.NRB) * stride256 * 256);
+    const uint32_t* levels = a.levels;
     const uint32_t gs = L.K / L.G;
     uint32_t rbv[2];
     const uint8_t* sbase[2];
+    uint32_t tabv[2][2];                                     // the records' slot tables: lane l holds the words of half slabs l and 64 + l
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         rbv[i] = min(2 * pair + uint32_t(i), L.NRB - 1);     // (an odd record count: the last pair mirrors the last record, whose rows are stored once)
-        sbase[i] = slots + size_t(rbv[i]) * stride256 * 256;
+        sbase[i] = a.slots + size_t(__builtin_amdgcn_readfirstlane(a.rbase[rbv[i]])) * 256;
+        tabv[i][0] = a.rtab[size_t(rbv[i]) * GI_TABW + lane];
+        tabv[i][1] = a.rtab[size_t(rbv[i]) * GI_TABW + 64 + lane];
     }
+    auto slot_word = [&](int i, int hh) -> uint32_t {          // rtab[record i][hh], hh uniform
+        const uint32_t lo = __builtin_amdgcn_readlane(tabv[i][0], hh & 63), hi = __builtin_amdgcn_readlane(tabv[i][1], hh & 63);
+        return hh < 64 ? lo : hi;
+    };
     uint32_t hl[2][16];
     auto load_levels = [&](int i, uint32_t g) {
         const_u32_ptr lp = (const_u32_ptr)(reinterpret_cast<uintptr_t>(levels + (size_t(rbv[i]) * L.G + g) * 16));   // (the image is read-only here)
@@ -733,7 +790,7 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
     uint32_t nvs[4];
     const uint32_t lane16 = uint32_t(lane) * 16u;
     auto request = [&](int i, int h, u32x4 (&dst)[NVK], uint32_t& nv_out) {
-        const uint32_t t = a.tab.t[min(h, NH - 1)];          // (past the end: a slot that exists, never used)
+        const uint32_t t = slot_word(i, min(h, NH - 1));     // (past the end: a slot that exists, never used)
         const uint32_t nv = t >> 16;
         const uint8_t* sp = sbase[i] + size_t(t & 0xFFFFu) * 256 + lane16;
 #pragma unroll
@@ -872,106 +929,139 @@ __global__ __launch_bounds__(256) void sb_reduce_kernel(const float* __restrict_
     }
 }
 
-// K splits of the small-batch kernel: about g_sb_waves waves in all (two per SIMD by default), at least 2 half slabs each
-int g_sb_waves = 2048;
-int g_sb_debug = 0;          // tools only: bit 0 skip the reduce launch, bit 1 the kernel leaves after its prologue (both: wrong results)
+// K splits of the small-batch kernel.  A workgroup (four pairs of records, one range of half slabs) needs two co-resident
+// neighbours to hide its memory latency, and every workgroup beyond a whole number per CU is a second round for a few CUs: the
+// split is the LARGEST for which the workgroups still fit two per CU (13824 x 5120: 108 x 4 = 432 workgroups 22.6 us, 108 x 5 = 540
+// 29.9 us, 108 x 2 27.8 us), with at least four half slabs per split (the partial outputs cost 2 x 4 x M x N bytes per split).
+int g_sb_waves = 0;          // tools only: aim at this many working waves instead (0: the rule above)
+int g_sb_debug = 0;          // tools only: bit 0 skip the reduce launch (wrong results)
+int sb_cu_count() {
+    static int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
 void sb_split(const pbl_layer* L, int& KS, int& hps) {
     static const int env_waves = [] { const char* e = getenv("PBL_SB_WAVES_DEFAULT"); return e ? atoi(e) : 0; }();   // (tools/: sweeps through bench.py)
-    if (env_waves > 0 && g_sb_waves == 2048) g_sb_waves = env_waves;
+    const int waves = g_sb_waves > 0 ? g_sb_waves : env_waves;
     const int NH = int((L->K + GI_HS - 1) / GI_HS), npairs = int((L->NRB + 1) / 2);
-    int ks = (g_sb_waves + npairs / 2) / npairs;
-    if (ks > NH / 2) ks = NH / 2;
+    const int cols = (npairs + SB_WAVES - 1) / SB_WAVES;
+    int ks = waves > 0 ? (waves + npairs / 2) / npairs : int((2 * sb_cu_count() * 51LL / 50) / cols);
+    if (ks > NH / 4) ks = NH / 4;
     if (ks < 1) ks = 1;
     hps = (NH + ks - 1) / ks;
     KS = (NH + hps - 1) / hps;
 }
 
 size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
+size_t align256(size_t v) { return (v + 255) & ~size_t(255); }
 bool layer_ok(const pbl_layer* layer) {
     if (!layer || (layer->K & 7) || !(layer->flags & PBL_FLAG_SLABS) || !(layer->flags & PBL_FLAG_TAIL_REPEAT)) return false;
     if (layer->G < 1 || (layer->G > 1 && (layer->K % layer->G || (layer->K / layer->G) % GI_HS))) return false;
     return (layer->K + GI_HS - 1) / GI_HS <= GI_MAX_NH;
 }
-// slot geometry from the per-column maxima (pbl_gemm_image_stats): false when a column needs more than 1216 entries in a slot
-bool make_tab(const pbl_layer* layer, const uint32_t* colmax, ImgTab& tab) {
-    const uint32_t NH = (layer->K + GI_HS - 1) / GI_HS;
-    uint32_t off = 0;
-    for (uint32_t h = 0; h < 128; ++h) tab.t[h] = 0;
-    for (uint32_t h = 0; h < NH; ++h) {
-        const uint32_t m = colmax[h];
-        const uint32_t nv = m <= 192u ? 1u : (m <= 448u ? 2u : (m <= 704u ? 3u : (m <= 960u ? 4u : (m <= 1216u ? 5u : 0u))));
-        if (!nv) return false;
-        tab.t[h] = off | (nv << 16);
-        off += 4u * nv;                                    // 1 KiB = four 256-byte units per vector
-    }
-    tab.t[NH] = off;
-    return off <= 0xFFFFu;
-}
-size_t image_bytes_of(const pbl_layer* layer, const ImgTab& tab) {
-    const uint32_t NH = (layer->K + GI_HS - 1) / GI_HS;
-    return align16(sizeof(ImgHeader) + size_t(layer->NRB) * tab.t[NH] * 256 + size_t(layer->NRB) * layer->G * 64);
+// where the image's parts are, from the geometry words (geom[0]: all slots in 256-byte units, geom[1]: the largest nv)
+struct ImgGeom { uint64_t rtab_off, slots_off, levels_off, total; };
+bool make_geom(const pbl_layer* layer, const uint32_t* geom, ImgGeom& g) {
+    if (!geom || geom[1] < 1 || geom[1] > GI_NVMAX) return false;          // (0xFFFFFFFF: a slot with more than 1216 entries)
+    g.rtab_off = align256(sizeof(ImgHeader) + size_t(layer->NRB) * 4);
+    g.slots_off = g.rtab_off + size_t(layer->NRB) * GI_TABW * 4;
+    g.levels_off = g.slots_off + uint64_t(geom[0]) * 256;
+    g.total = align16(g.levels_off + size_t(layer->NRB) * layer->G * 64);
+    return true;
 }
 size_t prep_lds(const pbl_layer* layer) {
-    return size_t(2 * (GI_MAX_NH + 1)) * 4 + 32 * 4 + 16 * sizeof(pbl_rowinfo) + ((size_t(layer->max_nch) + 15) & ~size_t(15));
+    return size_t(2 * (GI_MAX_NH + 1) + GI_TABW) * 4 + 32 * 4 + 16 * sizeof(pbl_rowinfo) + ((size_t(layer->max_nch) + 15) & ~size_t(15));
 }
+// the statistics buffer of pbl_gemm_image_stats: [geom: 2 words + 8 bytes][rlen -> rbase: NRB words, padded to 16 bytes][rtab: NRB x 128 words]
+size_t stats_rlen_off() { return 16; }
+size_t stats_rtab_off(const pbl_layer* layer) { return 16 + align16(size_t(layer->NRB) * 4); }
 
 }  // namespace
 
-// For every 128-column half slab h of the layer: the largest number of salient entries + exceptions any 16-row record holds there,
-// folded into the device words colmax_dev[0 .. ceil(K / 128)) (uint32, zeroed by the caller): what sizes the image's slots.  One
-// small kernel, no x.
-extern "C" int pbl_gemm_image_stats(const pbl_layer* layer, void* colmax_dev, void* stream) {
-    if (!layer || !layer->blob || !colmax_dev) return PBL_ERR_INVALID_ARG;
-    if (!layer_ok(layer)) return PBL_ERR_UNSUPPORTED;
-    pbl_layer lcopy = *layer;
-    uint8_t* img = nullptr;
-    ImgTab tab;
-    for (uint32_t h = 0; h < 128; ++h) tab.t[h] = 0;
-    uint32_t* mx = static_cast<uint32_t*>(colmax_dev);
-    void* argv[] = {&lcopy, &img, &tab, &mx};
-    return hipLaunchKernel(reinterpret_cast<const void*>(img_prep_kernel<true>), dim3(layer->NRB), dim3(GI_PREP_THREADS), argv, prep_lds(layer),
-                           static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+// Bytes of the device buffer pbl_gemm_image_stats fills (0: no image for this layer: K % 8, more than 127 half slabs, an odd group size).
+extern "C" size_t pbl_gemm_image_stats_bytes(const pbl_layer* layer) {
+    if (!layer_ok(layer)) return 0;
+    return stats_rtab_off(layer) + size_t(layer->NRB) * GI_TABW * 4;
 }
 
-// Bytes of the layer's GEMM image for the per-column maxima colmax[0 .. ceil(K / 128)) (HOST array, read back from
-// pbl_gemm_image_stats): per record and column a slot of 1 KiB (up to 192 entries), 2 KiB (448) ... 5 KiB (1216), + 64 B of levels per
-// (record, group).  0: no image for this layer (K % 8, more than 127 half slabs, an odd group size, or more than 1216 entries in
-// one slot) -- pbl_gemm_f16_ws serves it.
-extern "C" size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* colmax) {
-    if (!layer_ok(layer) || !colmax) return 0;
-    ImgTab tab;
-    if (!make_tab(layer, colmax, tab)) return 0;
-    return image_bytes_of(layer, tab);
+// Size the image: for every (16-row record, 128-column half slab) the number of salient entries + exceptions, the slot that holds them
+// (1 - 5 KiB), every record's start -- into the device buffer stats_dev (pbl_gemm_image_stats_bytes(layer), 16-byte aligned, any
+// content), which pbl_gemm_image_build reads.  Its first two words are the geometry the host needs (read them back ONCE, after this
+// call's kernels: the only host synchronisation of building an image): geom[0] = all slots in 256-byte units, geom[1] = the largest
+// slot in 1 KiB vectors (0xFFFFFFFF: some slot has more than 1216 entries -- no image for this layer).  Two small kernels, no x.
+extern "C" int pbl_gemm_image_stats(const pbl_layer* layer, void* stats_dev, void* stream) {
+    if (!layer || !layer->blob || !stats_dev) return PBL_ERR_INVALID_ARG;
+    if (!layer_ok(layer)) return PBL_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(stats_dev) & 15) return PBL_ERR_MISALIGNED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* sb = static_cast<char*>(stats_dev);
+    if (hipMemsetAsync(sb, 0, 16, st) != hipSuccess) return PBL_ERR_LAUNCH;
+    pbl_layer lcopy = *layer;
+    PrepArgs pa = {};
+    pa.geom = reinterpret_cast<uint32_t*>(sb);
+    pa.rlen = reinterpret_cast<uint32_t*>(sb + stats_rlen_off());
+    pa.rtab = reinterpret_cast<uint32_t*>(sb + stats_rtab_off(layer));
+    void* argv[] = {&lcopy, &pa};
+    if (hipLaunchKernel(reinterpret_cast<const void*>(img_prep_kernel<true>), dim3(layer->NRB), dim3(GI_PREP_THREADS), argv, prep_lds(layer), st) != hipSuccess)
+        return PBL_ERR_LAUNCH;
+    uint32_t nrb = layer->NRB;
+    void* sv[] = {&pa.geom, &pa.rlen, &nrb};
+    return hipLaunchKernel(reinterpret_cast<const void*>(img_scan_kernel), dim3(1), dim3(1024), sv, 0, st) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
 }
 
-// Build the image into `image` (>= pbl_gemm_image_bytes(layer, colmax), 16-byte aligned): one small kernel.  It depends on the blob
-// only and stays valid as long as the blob is unchanged.
-extern "C" int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* colmax, void* image, size_t image_bytes, void* stream) {
-    if (!layer || !layer->blob || !image || !colmax) return PBL_ERR_INVALID_ARG;
+// Bytes of the layer's GEMM image for the geometry words geom[0 .. 2) (HOST array, read back from the head of pbl_gemm_image_stats'
+// buffer): 64 B header + 4 B per record + 512 B of slot table per record + the slots (1 KiB per 16 rows x 128 columns with up to 192
+// entries, 2 KiB up to 448 ... 5 KiB up to 1216) + 64 B of levels per (record, group).  0: no image for this layer --
+// pbl_gemm_f16_ws serves it.
+extern "C" size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* geom) {
+    ImgGeom g;
+    if (!layer_ok(layer) || !make_geom(layer, geom, g)) return 0;
+    return g.total;
+}
+
+// Build the image into `image` (>= pbl_gemm_image_bytes(layer, geom), 16-byte aligned) from the layer and the statistics buffer
+// pbl_gemm_image_stats filled for it: one small kernel.  It depends on the blob only and stays valid as long as the blob is
+// unchanged; the statistics buffer may be released once this call's kernel has run.
+extern "C" int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, void* stream) {
+    if (!layer || !layer->blob || !image || !geom || !stats_dev) return PBL_ERR_INVALID_ARG;
     if (!layer_ok(layer)) return PBL_ERR_UNSUPPORTED;
-    ImgTab tab;
-    if (!make_tab(layer, colmax, tab)) return PBL_ERR_UNSUPPORTED;
-    if (image_bytes < image_bytes_of(layer, tab)) return PBL_ERR_CAPACITY;
-    if (reinterpret_cast<uintptr_t>(image) & 15) return PBL_ERR_MISALIGNED;
+    ImgGeom g;
+    if (!make_geom(layer, geom, g)) return PBL_ERR_UNSUPPORTED;
+    if (image_bytes < g.total) return PBL_ERR_CAPACITY;
+    if ((reinterpret_cast<uintptr_t>(image) & 15) || (reinterpret_cast<uintptr_t>(stats_dev) & 15)) return PBL_ERR_MISALIGNED;
     pbl_layer lcopy = *layer;
-    uint8_t* img = static_cast<uint8_t*>(image);
-    uint32_t* mx = nullptr;
-    void* argv[] = {&lcopy, &img, &tab, &mx};
+    char* sb = const_cast<char*>(static_cast<const char*>(stats_dev));
+    PrepArgs pa = {};
+    pa.img = static_cast<uint8_t*>(image);
+    pa.rlen = reinterpret_cast<uint32_t*>(sb + stats_rlen_off());
+    pa.rtab = reinterpret_cast<uint32_t*>(sb + stats_rtab_off(layer));
+    pa.rtab_off = g.rtab_off; pa.slots_off = g.slots_off; pa.levels_off = g.levels_off; pa.total = g.total;
+    void* argv[] = {&lcopy, &pa};
     return hipLaunchKernel(reinterpret_cast<const void*>(img_prep_kernel<false>), dim3(layer->NRB), dim3(GI_PREP_THREADS), argv, prep_lds(layer),
                            static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
 }
 
-// y[M, N] = x[M, K] . W^T (+ bias) over an image pbl_gemm_image_build made for THIS layer with the same colmax (any M >= 1).
-// Bit-identical to pbl_gemm_f16_ws / _prepared.
+// y[M, N] = x[M, K] . W^T (+ bias) over an image pbl_gemm_image_build made for THIS layer, with the same geometry words (any
+// M >= 1).  Bit-identical to pbl_gemm_f16_ws / _prepared.
 extern "C" int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
-                                  const uint32_t* colmax, void* stream) {
-    if (!layer || !layer->blob || !x || !y || !image || !colmax || M < 1) return PBL_ERR_INVALID_ARG;
+                                  const uint32_t* geom, void* stream) {
+    if (!layer || !layer->blob || !x || !y || !image || !geom || M < 1) return PBL_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return PBL_ERR_MISALIGNED;
     if (!layer_ok(layer)) return PBL_ERR_UNSUPPORTED;
+    ImgGeom g;
+    if (!make_geom(layer, geom, g)) return PBL_ERR_UNSUPPORTED;
+    if (image_bytes < g.total) return PBL_ERR_CAPACITY;
     ImgArgs a;
-    if (!make_tab(layer, colmax, a.tab)) return PBL_ERR_UNSUPPORTED;
-    if (image_bytes < image_bytes_of(layer, a.tab)) return PBL_ERR_CAPACITY;
-    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32; a.img = static_cast<const uint8_t*>(image);
+    const uint8_t* ib = static_cast<const uint8_t*>(image);
+    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32;
+    a.slots = ib + g.slots_off; a.rbase = reinterpret_cast<const uint32_t*>(ib + sizeof(ImgHeader));
+    a.rtab = reinterpret_cast<const uint32_t*>(ib + g.rtab_off); a.levels = reinterpret_cast<const uint32_t*>(ib + g.levels_off);
 #if PBL_TRACE
     a.trace = g_img_trace;
 #endif
@@ -985,7 +1075,7 @@ extern "C" int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y
 }
 
 // tuning hook (tools/): the number of waves the small-batch kernel's K split aims at
-extern "C" void pbl_debug_set_small_image_waves(int n) { g_sb_waves = n > 0 ? n : 2048; }
+extern "C" void pbl_debug_set_small_image_waves(int n) { g_sb_waves = n > 0 ? n : 0; }
 extern "C" void pbl_debug_set_small_image_flags(int f) { g_sb_debug = f; }
 
 // Transient workspace of pbl_gemm_small_image_ws for M <= 32 rows: the K splits' fp32 partial outputs (0: one split).
@@ -996,27 +1086,30 @@ extern "C" size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, i
     return KS > 1 ? size_t(KS) * M * layer->N * sizeof(float) : 0;
 }
 
-// y[M, N] = x[M, K] . W^T (+ bias) for 1 <= M <= 32 rows over the GEMM image (the same image, the same colmax as
+// y[M, N] = x[M, K] . W^T (+ bias) for 1 <= M <= 32 rows over the GEMM image (the same image, the same geometry words as
 // pbl_gemm_f16_image).  `workspace` (pbl_gemm_small_image_workspace_bytes(layer, M), 16-byte aligned; any content) holds the K
 // splits' partial outputs; NULL / too small: one split (slow for layers with few rows).  The same numbers as the other kernels up
 // to fp32 summation order (within the parity tolerance of tests/test_gpu_gemm.py); repeatable run to run.
 extern "C" int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
-                                       const uint32_t* colmax, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!layer || !layer->blob || !x || !y || !image || !colmax || M < 1 || M > 32) return PBL_ERR_INVALID_ARG;
+                                       const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!layer || !layer->blob || !x || !y || !image || !geom || M < 1 || M > 32) return PBL_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return PBL_ERR_MISALIGNED;
     if (!layer_ok(layer) || layer->K < 16) return PBL_ERR_UNSUPPORTED;
+    ImgGeom g;
+    if (!make_geom(layer, geom, g)) return PBL_ERR_UNSUPPORTED;
+    if (image_bytes < g.total) return PBL_ERR_CAPACITY;
     SbArgs a;
-    if (!make_tab(layer, colmax, a.tab)) return PBL_ERR_UNSUPPORTED;
-    if (image_bytes < image_bytes_of(layer, a.tab)) return PBL_ERR_CAPACITY;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32; a.img = static_cast<const uint8_t*>(image);
+    const uint8_t* ib = static_cast<const uint8_t*>(image);
+    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32;
+    a.slots = ib + g.slots_off; a.rbase = reinterpret_cast<const uint32_t*>(ib + sizeof(ImgHeader));
+    a.rtab = reinterpret_cast<const uint32_t*>(ib + g.rtab_off); a.levels = reinterpret_cast<const uint32_t*>(ib + g.levels_off);
     sb_split(layer, a.KS, a.hps);
     a.dbg = g_sb_debug;
     const uint32_t NH = (layer->K + GI_HS - 1) / GI_HS;
     if (a.KS > 1 && (!workspace || workspace_bytes < size_t(a.KS) * M * layer->N * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15))) { a.KS = 1; a.hps = int(NH); }
     a.part = a.KS > 1 ? static_cast<float*>(workspace) : nullptr;
-    uint32_t nvk = 1;
-    for (uint32_t h = 0; h < NH; ++h) nvk = nvk > (a.tab.t[h] >> 16) ? nvk : (a.tab.t[h] >> 16);
+    const uint32_t nvk = geom[1];
     const bool kt = (layer->K & (GI_HS - 1)) != 0;
 #define SB_PICK(NV_) (kt ? reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, true>) : reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, false>))
     const void* k = nvk == 1 ? SB_PICK(1) : nvk == 2 ? SB_PICK(2) : nvk == 3 ? SB_PICK(3) : nvk == 4 ? SB_PICK(4) : SB_PICK(5);

@@ -70,7 +70,7 @@ hipStream_t stream_of(const at::Tensor& t) { return c10::hip::getCurrentHIPStrea
 struct ImageRef {
     const void* data = nullptr;
     size_t bytes = 0;
-    std::vector<uint32_t> colmax;
+    std::vector<uint32_t> geom;
     explicit operator bool() const { return data != nullptr; }
 };
 
@@ -82,7 +82,7 @@ at::Tensor run_small(const pbl_layer& L, const at::Tensor& xc, int64_t M, bool f
         const size_t nbi = pbl_gemm_small_image_workspace_bytes(&L, int(M));
         at::Tensor wsi;
         if (nbi) wsi = at::empty({int64_t(nbi)}, xc.options().dtype(at::kByte));
-        const int rc = pbl_gemm_small_image_ws(&L, xc.data_ptr(), y.data_ptr(), int(M), f32 ? 1 : 0, img.data, img.bytes, img.colmax.data(),
+        const int rc = pbl_gemm_small_image_ws(&L, xc.data_ptr(), y.data_ptr(), int(M), f32 ? 1 : 0, img.data, img.bytes, img.geom.data(),
                                                nbi ? wsi.data_ptr() : nullptr, nbi, stream_of(xc));
         if (rc == PBL_OK) return y;
         TORCH_CHECK(rc == PBL_ERR_UNSUPPORTED, "libpbl gemm_small_image: ", pbl_status_string(rc), " (", rc, ")");   // (a layer it does not take: the records kernel)
@@ -104,7 +104,7 @@ at::Tensor unpack(const pbl_layer& L, const at::Tensor& like, at::ScalarType dt)
 
 at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                        int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
-                       const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> colmax, c10::string_view backend,
+                       const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
                        bool bf16_range_check) {
     TORCH_CHECK(x.is_cuda() && blob.is_cuda(), "pbllm_native.linear: GPU tensors only (the HIP kernels are the only compute path)");
     const auto xt = x.scalar_type();
@@ -125,9 +125,9 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
     const int64_t rows = xt == at::kFloat ? 2 * M : M;     // fp32 x runs as two fp16 terms (bf16 converts exactly)
     const bool mok = mfma_ok(K, G, flags);
     ImageRef iref;
-    if (image.has_value() && image->defined() && colmax.has_value()) {
+    if (image.has_value() && image->defined() && geom.has_value()) {
         iref.data = image->data_ptr(); iref.bytes = size_t(image->numel());
-        iref.colmax.assign(colmax->begin(), colmax->end());
+        iref.geom.assign(geom->begin(), geom->end());
     }
     auto dense_path = [&](at::ScalarType wdt) {
         const at::Tensor W = unpack(L, x, wdt);
@@ -144,7 +144,7 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
                 if (img || backend == "fused") {
                     at::Tensor y = at::empty({M, N}, x.options().dtype(out_f32 ? at::kFloat : at::kHalf));
                     if (img) {
-                        check(pbl_gemm_f16_image(&L, xc.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, iref.data, iref.bytes, iref.colmax.data(),
+                        check(pbl_gemm_f16_image(&L, xc.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, iref.data, iref.bytes, iref.geom.data(),
                                                  stream_of(x)), "gemm_f16_image");
                     } else {
                         const size_t nb = pbl_gemm_workspace_bytes(&L, int(M));
@@ -186,7 +186,7 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
 
 at::Tensor linear_meta(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                        int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
-                       const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> colmax, c10::string_view backend,
+                       const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
                        bool bf16_range_check) {
     TORCH_CHECK(x.dim() >= 1 && x.size(-1) == K, "pbllm_native.linear: in_features mismatch: x has ", x.size(-1), ", layer has ", K);
     std::vector<int64_t> shape(x.sizes().begin(), x.sizes().end());
@@ -199,7 +199,7 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
  public:
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& blob, const c10::optional<at::Tensor>& bias,
                               int64_t N, int64_t K, int64_t P, int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32,
-                              bool dense_f16, const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> colmax, std::string backend,
+                              bool dense_f16, const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, std::string backend,
                               bool bf16_range_check) {
         ctx->saved_data["blob"] = blob;
         ctx->saved_data["meta"] = std::vector<int64_t>{N, K, P, G, NRB, flags, max_nch, max_nexc};
@@ -209,7 +209,7 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
                              .typed<at::Tensor(const at::Tensor&, const c10::optional<at::Tensor>&, const at::Tensor&, int64_t, int64_t, int64_t, int64_t,
                                                int64_t, int64_t, int64_t, int64_t, bool, bool, const c10::optional<at::Tensor>&,
                                                c10::OptionalArrayRef<int64_t>, c10::string_view, bool)>();
-        return op.call(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, colmax, backend, bf16_range_check);
+        return op.call(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, backend, bf16_range_check);
     }
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
         const at::Tensor dy = grads[0];
@@ -231,9 +231,9 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
 
 at::Tensor linear_autograd(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                            int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
-                           const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> colmax, c10::string_view backend,
+                           const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
                            bool bf16_range_check) {
-    return PBLinearFn::apply(x, blob, bias, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, colmax, std::string(backend),
+    return PBLinearFn::apply(x, blob, bias, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, std::string(backend),
                              bf16_range_check);
 }
 
@@ -241,7 +241,7 @@ at::Tensor linear_autograd(const at::Tensor& blob, const c10::optional<at::Tenso
 
 TORCH_LIBRARY(pbllm_native, m) {
     m.def("linear(Tensor blob, Tensor? bias, Tensor x, int N, int K, int P, int G, int NRB, int flags, int max_nch, int max_nexc, bool out_f32, "
-          "bool dense_f16=True, Tensor? image=None, int[]? colmax=None, str backend=\"auto\", bool bf16_range_check=True) -> Tensor");
+          "bool dense_f16=True, Tensor? image=None, int[]? geom=None, str backend=\"auto\", bool bf16_range_check=True) -> Tensor");
 }
 TORCH_LIBRARY_IMPL(pbllm_native, CUDA, m) { m.impl("linear", linear_cuda); }
 TORCH_LIBRARY_IMPL(pbllm_native, Meta, m) { m.impl("linear", linear_meta); }

@@ -98,7 +98,7 @@ def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32
         cur = torch.cuda.current_stream(x2.device)
         cur.wait_event(image.ready)        # (a no-op on the building stream; orders a call from any other stream behind the build)
         _lib.check(L.pbl_gemm_f16_image(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), image.data.data_ptr(),
-                                        image.data.numel(), image.colmax, cur.cuda_stream), "gemm_f16_image")
+                                        image.data.numel(), image.geom, cur.cuda_stream), "gemm_f16_image")
         return y
     if prepared is not None:
         _lib.check(L.pbl_gemm_f16_prepared(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), prepared.data_ptr(), prepared.numel(),
@@ -123,7 +123,7 @@ def small_image_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, image:
     nb = int(L.pbl_gemm_small_image_workspace_bytes(C.byref(layer), M))
     ws = torch.empty(nb, dtype=torch.uint8, device=x2.device) if nb else None
     _lib.check(L.pbl_gemm_small_image_ws(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), image.data.data_ptr(), image.data.numel(),
-                                         image.colmax, ws.data_ptr() if nb else None, nb, cur.cuda_stream), "gemm_small_image")
+                                         image.geom, ws.data_ptr() if nb else None, nb, cur.cuda_stream), "gemm_small_image")
     return y
 
 
@@ -142,42 +142,45 @@ def gemm_list(packed: PackedWeight) -> torch.Tensor | None:
 
 
 class GemmImage:
-    """The per-layer GEMM image of a packed weight (csrc/pbl_gemm_img.hip, pbl_gemm_image_build): what the prefill path multiplies
-    from.  `data`: uint8 tensor on the blob's device; `colmax`: per 128-column half slab the largest entry count of any record
-    (host array: it sizes the slots and travels with every call); `ready`: an event recorded on the building stream behind the
-    build kernel -- a call from another stream waits on it."""
-    __slots__ = ("data", "colmax", "ready", "colmax_list")
+    """The per-layer GEMM image of a packed weight (csrc/pbl_gemm_img.hip, pbl_gemm_image_build): what the prefill path and the
+    small-batch kernel multiply from.  `data`: uint8 tensor on the blob's device; `geom`: the two geometry words (all slots in
+    256-byte units, the largest slot in KiB; host array: it travels with every call); `ready`: an event recorded on the building
+    stream behind the build kernel -- a call from another stream waits on it."""
+    __slots__ = ("data", "geom", "ready", "geom_list")
 
-    def __init__(self, data, colmax, ready):
-        self.data, self.colmax, self.ready = data, colmax, ready
-        self.colmax_list = list(colmax)                  # (the native operator takes an int list)
+    def __init__(self, data, geom, ready):
+        self.data, self.geom, self.ready = data, geom, ready
+        self.geom_list = list(geom)                      # (the native operator takes an int list)
 
     @property
-    def max_entries(self) -> int:
-        return max(self.colmax) if len(self.colmax) else 0
+    def max_slot_kib(self) -> int:
+        return int(self.geom[1])
 
 
 def gemm_image(packed: PackedWeight) -> GemmImage | None:
-    """Build the layer's GEMM image: pbl_gemm_image_stats (one small kernel + ONE read-back of ceil(K / 128) words, the only host
-    sync), then pbl_gemm_image_build.  None: the layer has no image (K % 8, more than 127 half slabs, odd group size, a slot with
-    more than 704 entries) -- pbl_gemm_f16_ws serves it."""
+    """Build the layer's GEMM image: pbl_gemm_image_stats (two small kernels + ONE read-back of two words, the only host sync),
+    then pbl_gemm_image_build.  None: the layer has no image (K % 8, more than 127 half slabs, odd group size, a slot with more
+    than 1216 entries) -- pbl_gemm_f16_ws serves it."""
     layer = packed.layer_struct(None)
     L = _lib.lib()
     dev = packed.blob.device
-    NH = (packed.K + 127) // 128
     st = torch.cuda.current_stream(dev).cuda_stream
-    mx = torch.zeros(max(NH, 1), dtype=torch.int32, device=dev)
-    if L.pbl_gemm_image_stats(C.byref(layer), mx.data_ptr(), st) != 0:
+    sb = int(L.pbl_gemm_image_stats_bytes(C.byref(layer)))
+    if not sb:
         return None
-    colmax = (C.c_uint32 * NH)(*mx.cpu().tolist()[:NH])
-    nb = int(L.pbl_gemm_image_bytes(C.byref(layer), colmax))
+    stats = torch.empty(sb, dtype=torch.uint8, device=dev)
+    if L.pbl_gemm_image_stats(C.byref(layer), stats.data_ptr(), st) != 0:
+        return None
+    g = stats[:8].view(torch.int32).cpu().tolist()
+    geom = (C.c_uint32 * 2)(g[0] & 0xFFFFFFFF, g[1] & 0xFFFFFFFF)
+    nb = int(L.pbl_gemm_image_bytes(C.byref(layer), geom))
     if not nb:
         return None
     data = torch.empty(nb, dtype=torch.uint8, device=dev)
-    _lib.check(L.pbl_gemm_image_build(C.byref(layer), colmax, data.data_ptr(), nb, st), "gemm_image_build")
+    _lib.check(L.pbl_gemm_image_build(C.byref(layer), geom, stats.data_ptr(), data.data_ptr(), nb, st), "gemm_image_build")
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    return GemmImage(data, colmax, ev)
+    return GemmImage(data, geom, ev)          # (stats is released behind the build kernel: the caching allocator is stream ordered)
 
 
 _CU_COUNT: dict = {}
@@ -302,7 +305,7 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
         # stream lookup, bf16 / fp32 handling, the autograd formula (dx = dy @ W) all live in the operator.  Python only decides
         # whether the GEMM regime multiplies from the layer's kept GEMM image.
         dense_f16 = dense_dtype in (None, torch.float16)
-        img, colmax, backend = None, None, GEMM_BACKEND
+        img, geom, backend = None, None, GEMM_BACKEND
         M = x.numel() // packed.K
         rows = 2 * M if x.dtype == torch.float32 else M
         ki = None
@@ -314,9 +317,9 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
             ki = _small_batch_image(packed)
         if ki is not None:
             torch.cuda.current_stream(x.device).wait_event(ki.ready)
-            img, colmax = ki.data, ki.colmax_list
+            img, geom = ki.data, ki.geom_list
         return nat(packed.blob, bias_f32, x, packed.N, packed.K, packed.P, packed.G, packed.NRB, packed.flags,
-                   packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, colmax, backend, BF16_RANGE_CHECK)
+                   packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, geom, backend, BF16_RANGE_CHECK)
     # the ctypes route (variant libraries through PBL_LIB, PBL_NATIVE=0, a dispatcher that did not build)
     if torch.is_grad_enabled() and x.requires_grad:
         return _PackedLinearFn.apply(x, (packed, bias_f32), out_f32, dense_dtype)

@@ -135,7 +135,7 @@ def test_gemm_regime_kernel(N, K, M, gs, lf, fp16, exc, metric):
         y1 = torch.empty(8, N, dtype=torch.float32, device=DEV)
         x8 = xt[:8].contiguous()
         _lib.check(_lib.lib().pbl_gemm_small_image_ws(C.byref(lay_s), x8.data_ptr(), y1.data_ptr(), 8, 1, img.data.data_ptr(), img.data.numel(),
-                                                      img.colmax, None, 0, torch.cuda.current_stream().cuda_stream), "gemm_small_image")
+                                                      img.geom, None, 0, torch.cuda.current_stream().cuda_stream), "gemm_small_image")
         assert_parity(y1[:, ridx], O.dense_linear(x[:8], W16[rows]), 3e-4)
     # the library backend on the unpacked layer: same operands, different summation order
     Wdev = Q.unpack_on_device(pd, torch.float16)
@@ -218,7 +218,7 @@ def test_kept_image_and_kept_list_follow_the_blob():
             Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = backend, False, True
             assert torch.equal(layer(x), ref)
             kimg = layer.packed._gemm_image
-            assert kimg[1] is not None and kimg[1].max_entries > 0
+            assert kimg[1] is not None and kimg[1].max_slot_kib >= 1
             assert torch.equal(layer(x[:40]), ref[:40]) and layer.packed._gemm_image is kimg      # one image, any M
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -252,7 +252,7 @@ def test_gemm_regime_fully_binarized_layer_in_list_mode():
     assert torch.equal(y, Q.fused_gemm_forward(pd, None, T(x), prepared=lst))
     assert torch.equal(y, Q.fused_gemm_forward(pd, None, T(x), workspace=False))
     img = Q.gemm_image(pd)
-    assert img is not None and img.max_entries == 0
+    assert img is not None and img.max_slot_kib == 1
     assert torch.equal(y, Q.fused_gemm_forward(pd, None, T(x), image=img))
 
 

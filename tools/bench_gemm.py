@@ -55,7 +55,7 @@ for shp, lf in SHAPES:
         img = Q.gemm_image(layer.packed)             # round 4: the kernel over the layer's GEMM image (built once, kept)
         if img is not None:
             res["fused_image_us"] = round(timeit(lambda: Q.fused_gemm_forward(layer.packed, None, x, image=img)), 1)
-            res["image_MB"] = round(img.data.numel() / 1e6, 2); res["image_max_entries"] = img.max_entries
+            res["image_MB"] = round(img.data.numel() / 1e6, 2); res["image_max_slot_KiB"] = img.max_slot_kib
     if ONLY in ("", "library"):
         Q.GEMM_BACKEND = "library"
         res["unpack_plus_library_us"] = round(timeit(lambda: layer(x)), 1)
