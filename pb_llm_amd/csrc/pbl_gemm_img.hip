@@ -718,8 +718,18 @@ struct SbArgs {
 #define SB_LDS (SB_X_OFF + 2 * 8192)
 
 typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;        // constant address space: scalar loads
+// Half slabs of slot requests in flight per wave (2 sets each).  Measured on 13824 x 5120, 20 % salients, 32 rows (calls r4-30 .. 32):
+// depth 2 at <= 128 VGPRs (four waves per SIMD: two 5-wave workgroups always find room on a CU) 21.9 us; depth 2 at <= 168 VGPRs
+// 28.7 us and depth 4 (164 VGPRs) 33.1 us -- three waves per SIMD are 12 slots, but a second 5-wave workgroup only fits when its
+// waves fall on the right SIMDs, and with one workgroup per CU the waves' own instruction streams (not the bytes in flight) bound
+// the kernel.  So: depth 2, and the register budget of four waves per SIMD wherever the sets allow it.
+#ifndef PBL_SB_DEPTH
+#define PBL_SB_DEPTH 2
+#endif
 template <int NVK, bool KT>
 __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_per_eu(NVK <= 3 ? 4 : 3, NVK <= 3 ? 4 : 3))) void pbl_sb_img_kernel(SbArgs a) {
+    constexpr int D = PBL_SB_DEPTH;
+    static_assert(D >= 2 && D % 2 == 0, "the x double buffer's parity is static in the unrolled loop");
     __shared__ __attribute__((aligned(16))) char smem_s[SB_LDS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -743,7 +753,8 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
             // the units of the LAST half slab beyond K would hold the next token row: pushed out of the descriptor's range, they read zeros
             if constexpr (KT) xvlast[q] = xvoff[q] + ((ktail_units && lu >= ktail_units) ? 0x40000000u : 0u);
         }
-        for (int h = h0; h <= h1; ++h) {                     // x of half slab h into buffer (h - h0) & 1, then the barrier the others open half slab h behind
+        const int h1p = h0 + (h1 - h0 + D - 1) / D * D;       // (the working waves run whole rounds of their slot ring: one barrier per half slab of those)
+        for (int h = h0; h <= h1p; ++h) {                    // x of half slab h into buffer (h - h0) & 1, then the barrier the others open half slab h behind
             if (h < h1) {
                 const uint32_t buf = uint32_t(h - h0) & 1u;
 #pragma unroll
@@ -785,12 +796,13 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
 #pragma unroll
         for (int r = 0; r < 16; ++r) hl[i][r] = lp[r];
     };
-    // ring of four slot sets: record-step t = 2 (h - h0) + i sits in set t & 3; nvs: the vectors of the slot a set holds
-    u32x4 e[4][NVK];
-    uint32_t nvs[4];
+    // ring of 2 D slot sets: record i of half slab h sits in set 2 ((h - h0) % D) + i, requested D half slabs ahead; nvs: the
+    // vectors of the slot a set holds
+    u32x4 e[2 * D][NVK];
+    uint32_t nvs[2 * D];
     const uint32_t lane16 = uint32_t(lane) * 16u;
     auto request = [&](int i, int h, u32x4 (&dst)[NVK], uint32_t& nv_out) {
-        const uint32_t t = slot_word(i, min(h, NH - 1));     // (past the end: a slot that exists, never used)
+        const uint32_t t = slot_word(i, min(h, h1 - 1));     // (past the split's end: its last slot again -- a cache hit, never used)
         const uint32_t nv = t >> 16;
         const uint8_t* sp = sbase[i] + size_t(t & 0xFFFFu) * 256 + lane16;
 #pragma unroll
@@ -832,30 +844,43 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
         const uint32_t g0 = (uint32_t(h0) * GI_HS) / gs;
         load_levels(0, g0); load_levels(1, g0);
     }
-    request(0, h0, e[0], nvs[0]); request(1, h0, e[1], nvs[1]);
-    request(0, h0 + 1, e[2], nvs[2]); request(1, h0 + 1, e[3], nvs[3]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        // (in THIS order: the compiler counts vmcnt for the loop's first use of a set from the loads issued behind it on every path
+        // into the loop; left free, the scheduler puts set 0's loads last in the prologue and the loop then waits for all but five)
+        request(0, h0 + j, e[2 * j], nvs[2 * j]);
+        asm volatile("" ::: "memory");
+        request(1, h0 + j, e[2 * j + 1], nvs[2 * j + 1]);
+        asm volatile("" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                            // barrier 0: x of the first half slab is in LDS
     asm volatile("" ::: "memory");
-    auto half_slab = [&](int h, uint32_t buf, u32x4 (&sa)[NVK], u32x4 (&sb)[NVK], uint32_t& nva, uint32_t& nvb) {
-        if (L.G > 1 && h > h0 && (uint32_t(h) * GI_HS) % gs == 0) { const uint32_t gg = (uint32_t(h) * GI_HS) / gs; load_levels(0, gg); load_levels(1, gg); }
-        expand(0, sa, nva); request(0, h + 2, sa, nva);
-        expand(1, sb, nvb); request(1, h + 2, sb, nvb);
+    // `live`: false for the half slabs that pad the split's last round of the ring (wave uniform).  They keep the round's shape --
+    // the same loads, the same barrier -- and skip the work: with the SAME number of loads on every path through the loop the
+    // compiler's vmcnt counts stay at "all younger sets in flight" (an early exit from the round, or a remainder behind the loop,
+    // made it size the round's first wait for the shortest path: vmcnt(5) instead of vmcnt(21)).
+    auto half_slab = [&](int h, uint32_t buf, u32x4 (&sa)[NVK], u32x4 (&sb)[NVK], uint32_t& nva, uint32_t& nvb, bool live) {
+        if (live && L.G > 1 && h > h0 && (uint32_t(h) * GI_HS) % gs == 0) { const uint32_t gg = (uint32_t(h) * GI_HS) / gs; load_levels(0, gg); load_levels(1, gg); }
+        if (live) expand(0, sa, nva);
+        request(0, h + D, sa, nva);
+        if (live) expand(1, sb, nvb);
+        request(1, h + D, sb, nvb);
+        if (live) {
 #pragma unroll
-        for (int k8 = 0; k8 < 8; ++k8) {
-            const v8h af = *reinterpret_cast<const v8h*>(As + aq[k8]);
-            const v8h bf = *reinterpret_cast<const v8h*>(smem_s + bq[k8] + buf * 8192u);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const v8h af = *reinterpret_cast<const v8h*>(As + aq[k8]);
+                const v8h bf = *reinterpret_cast<const v8h*>(smem_s + bq[k8] + buf * 8192u);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of the x tile are done; then everyone's, and the next tile is in
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    for (int h = h0; h < h1; h += 2) {
-        half_slab(h, 0u, e[0], e[1], nvs[0], nvs[1]);
-        if (h + 1 < h1) half_slab(h + 1, 1u, e[2], e[3], nvs[2], nvs[3]);
-        else break;
+    for (int h = h0; h < h1; h += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) half_slab(h + j, uint32_t(j & 1), e[2 * j], e[2 * j + 1], nvs[2 * j], nvs[2 * j + 1], h + j < h1);
     }
-    // (an odd number of half slabs leaves the buffers swapped for nobody: the kernel ends)
 
     // ---- the 32 x 32 tile: rows (reg & 3) + 8 (reg >> 2) + 4 g of the pair, token i32
     const uint32_t row0 = pair_raw * 32u;

@@ -4,7 +4,7 @@
 // C ABI (include/pbl.h); this file is the torch side of it in C++: ONE operator that does everything `module(x)` needs for any
 // row count and activation dtype --
 //   * decode / small batch (<= 32 rows): pbl_linear_f16_ws (GEMV passes or the matrix-core kernel, routed by the library), or --
-//     from 8 rows, when the caller hands the layer's GEMM image over -- the small-batch kernel over the image
+//     from 5 rows, when the caller hands the layer's GEMM image over -- the small-batch kernel over the image
 //     (pbl_gemm_small_image_ws);
 //     bf16 activations as one fp16 pass (exact inside fp16's range; per-token power-of-two scaling outside it, or the dense
 //     path when the range check finds out-of-range / non-finite values), fp32 activations as two fp16 terms;
@@ -34,7 +34,7 @@ namespace {
 
 constexpr int64_t MFMA_MAX = 32;        // rows the packed small-batch kernels take (pb_llm_amd/quant.py: MFMA_MAX)
 constexpr int64_t GEMM_THRESHOLD = 12;  // ... and where layers the matrix-core kernel refuses switch to the dense path
-constexpr int64_t SMALL_IMAGE_MIN = 8;  // rows from which the small-batch kernel over the GEMM image beats the one over the records (pb_llm_amd/quant.py)
+constexpr int64_t SMALL_IMAGE_MIN = 5;  // rows from which the small-batch kernel over the GEMM image beats the one over the records (pb_llm_amd/quant.py)
 
 pbl_layer make_layer(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, int64_t N, int64_t K, int64_t P, int64_t G,
                      int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool with_bias) {

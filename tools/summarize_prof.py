@@ -96,7 +96,7 @@ def main():
             print(f"\n## {sub}: kernel trace, un-instrumented timing (durations in us)")
             for s in kernel_stats(p)[:10]:
                 print(json.dumps(s))
-        want = "pbl_mfma_kernel" if sub.startswith("mfma") else ("pbl_gemm_img_kernel" if sub.startswith("gemmimg") else
+        want = "pbl_sb_img_kernel" if sub.startswith("sbimg") else "pbl_mfma_kernel" if sub.startswith("mfma") else ("pbl_gemm_img_kernel" if sub.startswith("gemmimg") else
                                                                 ("pbl_gemm_kernel" if sub.startswith("gemm") else "pbl_gemv"))
         if "pmc" in sub or "fetch" in sub or "write" in sub or "tcc" in sub:
             st = pmc_stats(p, want)
@@ -118,8 +118,9 @@ def main():
         for line in open(log):
             if line.startswith("{\"metric\""):
                 j = json.loads(line)
-                print(f"\n## bench line under {os.path.basename(log)}: value={j['value']:.0f} "
-                      f"achieved={j['roofline']['achieved']:.0f} GB/s us/launch={j['roofline']['us_per_launch']:.1f}")
+                r = j["roofline"]
+                print(f"\n## bench line under {os.path.basename(log)}: value={j['value']:.0f} achieved={r['achieved']:.0f} {r['unit']} "
+                      + (f"us/launch={r['us_per_launch']:.1f}" if "us_per_launch" in r else f"us/layer={r.get('us_per_layer', 0):.2f}"))
 
 
 if __name__ == "__main__":
