@@ -7,7 +7,7 @@
 // and BOTH roles need that long -- the eight MFMA waves (fragment reads: +16 us over the bare stream; their own x staging
 // by LDS-DMA: +10 us) and the four expanding waves (~330 instructions per half slab and wave: request addressing, range
 // look-ups, masked stores, branches around every one of them).  What this kernel changes:
-//   * the layer is re-laid ONCE (pbl_gemm_image_build, kept with the layer like round 3's salient list) into fixed-size slots,
+//   * the layer is re-laid ONCE (pbl_gemm_image_build, kept with the layer like round 3's salient list) into slots of 1 - 5 KiB,
 //     one per (16-row record, 128-column half slab): per lane the sign-plane dword and EW - 1 ready-to-store salient words
 //     {LDS offset : fp16 value}, padded with idempotent repeats -- so an expanding wave issues ONE 16-byte load per lane
 //     and record from an address that only moves by a scalar add, and stores every word unconditionally: no ranges, no
@@ -726,6 +726,9 @@ typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;        
 #ifndef PBL_SB_DEPTH
 #define PBL_SB_DEPTH 2
 #endif
+#ifndef PBL_SB_NT
+#define PBL_SB_NT 0                  // slot loads with the non-temporal hint (the image is read once)
+#endif
 template <int NVK, bool KT>
 __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_per_eu(NVK <= 3 ? 4 : 3, NVK <= 3 ? 4 : 3))) void pbl_sb_img_kernel(SbArgs a) {
     constexpr int D = PBL_SB_DEPTH;
@@ -806,7 +809,12 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
         const uint32_t nv = t >> 16;
         const uint8_t* sp = sbase[i] + size_t(t & 0xFFFFu) * 256 + lane16;
 #pragma unroll
-        for (int v = 0; v < NVK; ++v) dst[v] = *reinterpret_cast<const u32x4*>(sp + 1024u * min(uint32_t(v), nv - 1u));   // (a smaller slot: its last vector again, a cache hit; not stored)
+        for (int v = 0; v < NVK; ++v)                           // (a smaller slot: its last vector again, a cache hit; not stored)
+#if PBL_SB_NT
+            dst[v] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp + 1024u * min(uint32_t(v), nv - 1u)));
+#else
+            dst[v] = *reinterpret_cast<const u32x4*>(sp + 1024u * min(uint32_t(v), nv - 1u));
+#endif
         nv_out = nv;
     };
     const uint32_t v0 = (uint32_t(lane >> 2) << 4) + (uint32_t(lane & 3) << 2);
@@ -925,18 +933,19 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
     }
 }
 
-// y = the K splits' partial tiles added in split order; 4 elements per thread (MN % 4 == 0 whenever N % 4 == 0)
+// y = the K splits' partial tiles added in split order; 4 elements per thread (MN % 4 == 0 whenever N % 4 == 0).  All splits'
+// values are requested together (ONE memory latency: the kernel is nothing but latency), up to 16 at a time.
 __global__ __launch_bounds__(256) void sb_reduce_kernel(const float* __restrict__ part, void* __restrict__ y, int KS, size_t MN, int y_f32) {
     const size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * 4;
     if (i >= MN) return;
     if (!(MN & 3)) {
-        v4f sum = *reinterpret_cast<const v4f*>(part + i);
-        for (int k0 = 1; k0 < KS; k0 += 8) {
-            v4f v[8];
+        v4f sum = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < KS; k0 += 16) {
+            v4f v[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = k0 + j < KS ? *reinterpret_cast<const v4f*>(part + size_t(k0 + j) * MN + i) : v4f{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 16; ++j) v[j] = k0 + j < KS ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(part + size_t(k0 + j) * MN + i)) : v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (k0 + j < KS) sum += v[j];
+            for (int j = 0; j < 16; ++j) if (k0 + j < KS) sum = (k0 + j) ? sum + v[j] : v[j];
         }
         if (y_f32) *reinterpret_cast<v4f*>(static_cast<float*>(y) + i) = sum;
         else {
