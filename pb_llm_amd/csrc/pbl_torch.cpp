@@ -164,7 +164,11 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
         // see pb_llm_amd/quant.py (_pb_linear_forward, bf16): range check with one host sync (never under capture) -> dense path
         // for out-of-range / non-finite inputs; else per-token power-of-two scaling on the device, exact for all finite inputs
         const bool capturing = c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
-        if (bf16_range_check && !capturing && !x2.abs().le(65504.0).all().item<bool>()) return dense_path(at::kFloat);
+        if (bf16_range_check && !capturing) {
+            if (!x2.abs().le(65504.0).all().item<bool>()) return dense_path(at::kFloat);
+            // every value is finite and inside fp16's range: bf16 -> fp16 is exact, no scaling needed (bias in the kernel)
+            return run_small(L, x2.to(at::kHalf).contiguous(), M, true, iref).to(out_dt).reshape(shape);
+        }
         const at::Tensor xf = x2.to(at::kFloat);
         const at::Tensor amax = xf.abs().amax({1}, true);
         const at::Tensor e = amax.view(at::kInt).bitwise_right_shift(23).bitwise_and(0xFF).sub(127 + 14).clamp_min(0);

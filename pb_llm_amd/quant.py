@@ -394,6 +394,11 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
             W = unpack_on_device(packed, torch.float32)                       # (NaN compares false: caught as well)
             y = torch.nn.functional.linear(x2.float(), W, bias_f32)
             return (y if out_f32 else y.to(x.dtype)).reshape(*lead, packed.N)
+        if BF16_RANGE_CHECK and not torch.cuda.is_current_stream_capturing():
+            # checked: every value is finite and inside fp16's range -- bf16 -> fp16 is exact, no scaling needed (bias in the kernel)
+            y = torch.empty(M, packed.N, dtype=torch.float32, device=x.device)
+            run(layer, x2.half().contiguous(), y, M, True)
+            return (y if out_f32 else y.to(x.dtype)).reshape(*lead, packed.N)
         xf = x2.float()
         amax = xf.abs().amax(dim=1, keepdim=True)
         # 2^-e with e = max(0, exponent(amax) - 14): frexp-free, from the fp32 bit pattern (inf / NaN -> exponent 255 -> the
