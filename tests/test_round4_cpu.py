@@ -89,3 +89,34 @@ def test_from_quantizers_vectorised_host_path_against_the_reference_goldens(gs):
                                    groupsize=gs, dtype=torch.float16)
     assert a.packed.G == (1 if gs == -1 else 6)
     assert np.count_nonzero(a.weight.numpy() != g["W_fq"]) <= 8
+
+
+def test_gemm_image_sizing_of_the_c_abi_without_a_gpu():
+    """pbl_gemm_image_stats_bytes / _bytes / small-image workspace: pure functions of the layer and the two geometry words; the
+    argument checks answer before any launch"""
+    import ctypes as C
+    import __graft_entry__ as ge
+    from pb_llm_amd import _lib
+    ge.build()
+    L = _lib.lib()
+    lay = _lib.PblLayer(blob=None, bias=None, N=4096, K=4096, P=8, G=1, NRB=256, flags=0xE, max_nch=500, max_nexc=3)
+    sb = L.pbl_gemm_image_stats_bytes(C.byref(lay))
+    assert sb == 16 + 256 * 4 + 256 * 128 * 4                                  # geometry words, record starts, slot tables
+    geom = (C.c_uint32 * 2)(8192, 1)                                           # 32 one-KiB slots per record
+    nb = L.pbl_gemm_image_bytes(C.byref(lay), geom)
+    rtab_off = (64 + 256 * 4 + 255) & ~255
+    assert nb == rtab_off + 256 * 512 + 8192 * 256 + 256 * 64                  # header + starts, tables, slots, level rows
+    for bad in ((8192, 0), (8192, 6), (8192, 0xFFFFFFFF)):                     # no vectors / more than five / "a slot does not fit"
+        assert L.pbl_gemm_image_bytes(C.byref(lay), (C.c_uint32 * 2)(*bad)) == 0
+    assert L.pbl_gemm_image_bytes(C.byref(lay), None) == 0
+    lay.K, lay.P = 16512, 33                                                   # 129 half slabs: no image
+    assert L.pbl_gemm_image_stats_bytes(C.byref(lay)) == 0 and L.pbl_gemm_image_bytes(C.byref(lay), geom) == 0
+    lay.K, lay.P = 4096, 8
+    assert L.pbl_gemm_image_stats(C.byref(lay), None, None) == _lib.PBL_ERR_INVALID_ARG                       # no blob, no buffer
+    assert L.pbl_gemm_image_build(C.byref(lay), geom, None, None, 0, None) == _lib.PBL_ERR_INVALID_ARG
+    assert L.pbl_gemm_f16_image(C.byref(lay), None, None, 64, 0, None, 0, geom, None) == _lib.PBL_ERR_INVALID_ARG
+    assert L.pbl_gemm_small_image_ws(C.byref(lay), None, None, 8, 0, None, 0, geom, None, 0, None) == _lib.PBL_ERR_INVALID_ARG
+    # the small-batch kernel's K split: only for <= 32 rows; the workspace is KS x M x N floats
+    assert L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), 33) == 0 and L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), 0) == 0
+    w8, w32 = (L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), m) for m in (8, 32))
+    assert w8 > 0 and w32 == 4 * w8 and w8 % (8 * 4096 * 4) == 0 and 2 <= w8 // (8 * 4096 * 4) <= 8         # KS <= NH / 4 = 8
