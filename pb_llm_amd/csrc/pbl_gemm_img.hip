@@ -21,7 +21,6 @@
 // accumulator sums its k-steps in the same order as pbl_gemm_big.hip: the two kernels agree bit for bit.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <type_traits>
 
 #include "../../include/pbl.h"
@@ -711,7 +710,6 @@ struct SbArgs {
     const uint32_t* rbase;
     const uint32_t* rtab;
     const uint32_t* levels;
-    int dbg;
 };
 #define SB_WAVES 4                   // working waves of a workgroup (+ 1 that stages x)
 #define SB_X_OFF (SB_WAVES * 8192)
@@ -968,7 +966,6 @@ __global__ __launch_bounds__(256) void sb_reduce_kernel(const float* __restrict_
 // split is the LARGEST for which the workgroups still fit two per CU (13824 x 5120: 108 x 4 = 432 workgroups 22.6 us, 108 x 5 = 540
 // 29.9 us, 108 x 2 27.8 us), with at least four half slabs per split (the partial outputs cost 2 x 4 x M x N bytes per split).
 int g_sb_waves = 0;          // tools only: aim at this many working waves instead (0: the rule above)
-int g_sb_debug = 0;          // tools only: bit 0 skip the reduce launch (wrong results)
 int sb_cu_count() {
     static int cus[16] = {0};
     int dev = 0;
@@ -981,8 +978,7 @@ int sb_cu_count() {
     return cus[dev];
 }
 void sb_split(const pbl_layer* L, int& KS, int& hps) {
-    static const int env_waves = [] { const char* e = getenv("PBL_SB_WAVES_DEFAULT"); return e ? atoi(e) : 0; }();   // (tools/: sweeps through bench.py)
-    const int waves = g_sb_waves > 0 ? g_sb_waves : env_waves;
+    const int waves = g_sb_waves;
     const int NH = int((L->K + GI_HS - 1) / GI_HS), npairs = int((L->NRB + 1) / 2);
     const int cols = (npairs + SB_WAVES - 1) / SB_WAVES;
     int ks = waves > 0 ? (waves + npairs / 2) / npairs : int((2 * sb_cu_count() * 51LL / 50) / cols);
@@ -1110,7 +1106,6 @@ extern "C" int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y
 
 // tuning hook (tools/): the number of waves the small-batch kernel's K split aims at
 extern "C" void pbl_debug_set_small_image_waves(int n) { g_sb_waves = n > 0 ? n : 0; }
-extern "C" void pbl_debug_set_small_image_flags(int f) { g_sb_debug = f; }
 
 // Transient workspace of pbl_gemm_small_image_ws for M <= 32 rows: the K splits' fp32 partial outputs (0: one split).
 extern "C" size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, int M) {
@@ -1139,7 +1134,6 @@ extern "C" int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, vo
     a.slots = ib + g.slots_off; a.rbase = reinterpret_cast<const uint32_t*>(ib + sizeof(ImgHeader));
     a.rtab = reinterpret_cast<const uint32_t*>(ib + g.rtab_off); a.levels = reinterpret_cast<const uint32_t*>(ib + g.levels_off);
     sb_split(layer, a.KS, a.hps);
-    a.dbg = g_sb_debug;
     const uint32_t NH = (layer->K + GI_HS - 1) / GI_HS;
     if (a.KS > 1 && (!workspace || workspace_bytes < size_t(a.KS) * M * layer->N * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15))) { a.KS = 1; a.hps = int(NH); }
     a.part = a.KS > 1 ? static_cast<float*>(workspace) : nullptr;
@@ -1151,7 +1145,7 @@ extern "C" int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, vo
     void* argv[] = {&a};
     const uint32_t npairs = (layer->NRB + 1) / 2;
     if (hipLaunchKernel(k, dim3((npairs + SB_WAVES - 1) / SB_WAVES, uint32_t(a.KS)), dim3((SB_WAVES + 1) * GW), argv, 0, st) != hipSuccess) return PBL_ERR_LAUNCH;
-    if (a.KS > 1 && !(g_sb_debug & 1)) {
+    if (a.KS > 1) {
         const float* part = a.part;
         size_t MN = size_t(M) * layer->N;
         int KS = a.KS;

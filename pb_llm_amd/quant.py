@@ -96,7 +96,7 @@ def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32
     L = _lib.lib()
     if image is not None:                  # pbl_gemm_f16_image: the round-4 kernel over the layer's GEMM image
         cur = torch.cuda.current_stream(x2.device)
-        cur.wait_event(image.ready)        # (a no-op on the building stream; orders a call from any other stream behind the build)
+        _wait_image(cur, image)            # (a no-op on the building stream; orders a call from any other stream behind the build)
         _lib.check(L.pbl_gemm_f16_image(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), image.data.data_ptr(),
                                         image.data.numel(), image.geom, cur.cuda_stream), "gemm_f16_image")
         return y
@@ -111,6 +111,14 @@ def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32
     return y
 
 
+def _wait_image(stream, image: "GemmImage") -> None:
+    """order this stream behind the image's build.  Not while the stream is being captured into a hipGraph: an event recorded outside
+    the capture cannot be waited for there -- and need not be: the image was built before the capture began (a build reads two words
+    back, which a capture forbids; `_kept_image` never builds under capture), and torch synchronises the device when a capture starts."""
+    if not torch.cuda.is_current_stream_capturing():
+        stream.wait_event(image.ready)
+
+
 def small_image_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, image: "GemmImage", out_f32: bool = False) -> torch.Tensor:
     """pbl_gemm_small_image_ws: x2 [M <= 32, K] fp16 contiguous -> [M, N] over the layer's GEMM image (the small-batch kernel of
     csrc/pbl_gemm_img.hip); the K splits' partial outputs go through a transient workspace from the caching allocator."""
@@ -119,7 +127,7 @@ def small_image_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, image:
     layer = packed.layer_struct(bias_f32)
     L = _lib.lib()
     cur = torch.cuda.current_stream(x2.device)
-    cur.wait_event(image.ready)
+    _wait_image(cur, image)
     nb = int(L.pbl_gemm_small_image_workspace_bytes(C.byref(layer), M))
     ws = torch.empty(nb, dtype=torch.uint8, device=x2.device) if nb else None
     _lib.check(L.pbl_gemm_small_image_ws(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), image.data.data_ptr(), image.data.numel(),
@@ -316,7 +324,7 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
         elif rows >= SMALL_IMAGE_MIN and dense_f16:          # (the image holds fp16 weights: layers an fp16 checkpoint is exact for)
             ki = _small_batch_image(packed)
         if ki is not None:
-            torch.cuda.current_stream(x.device).wait_event(ki.ready)
+            _wait_image(torch.cuda.current_stream(x.device), ki)
             img, geom = ki.data, ki.geom_list
         return nat(packed.blob, bias_f32, x, packed.N, packed.K, packed.P, packed.G, packed.NRB, packed.flags,
                    packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, geom, backend, BF16_RANGE_CHECK)

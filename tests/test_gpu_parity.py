@@ -457,6 +457,33 @@ def test_hipgraph_capture_and_side_stream(llama7b_qproj):
         assert_parity(y_static, O.dense_linear(x, r["W_fq"]))
 
 
+def test_small_batch_image_kernel_under_hipgraph_capture(llama7b_qproj):
+    """a batch of 16 rows through the small-batch kernel over the layer's GEMM image, captured and replayed: the image is built by
+    an eager call first (a build reads two words back: never under capture), the captured call must not wait for the build's event"""
+    W, mask, r = llama7b_qproj
+    lay = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+    W16 = r["W_fq"].astype(np.float16).astype(np.float32)
+    xs = [synth.activations((16, 4096), 60 + i, 21) for i in range(3)]
+    x_static = T(xs[0]).clone()
+    old = Q.SMALL_BATCH_IMAGE
+    try:
+        Q.SMALL_BATCH_IMAGE = "1"
+        y_eager = lay(x_static)
+        img = lay.packed._gemm_image[1]
+        assert img is not None and torch.equal(y_eager, Q.small_image_forward(lay.packed, None, x_static, img))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g), torch.no_grad():
+            y_static = lay(x_static)
+        for x in xs:
+            x_static.copy_(T(x))
+            g.replay()
+            torch.cuda.synchronize()
+            assert_parity(y_static, O.dense_linear(x, W16))
+            assert torch.equal(y_static, Q.small_image_forward(lay.packed, None, x_static, img))
+    finally:
+        Q.SMALL_BATCH_IMAGE = old
+
+
 def test_misuse_raises():
     W = synth.llm_weight(16, 512, seed=1)
     m = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV)

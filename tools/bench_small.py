@@ -13,8 +13,6 @@ MS = [int(m) for m in os.environ.get("PBL_BENCH_MS", "32,16,8").split(",")]
 WAVES = [int(w) for w in os.environ.get("PBL_SB_WAVES", "2048").split(",")]
 L = _lib.lib()
 setw = L.pbl_debug_set_small_image_waves; setw.restype = None; setw.argtypes = [C.c_int]
-setf = L.pbl_debug_set_small_image_flags; setf.restype = None; setf.argtypes = [C.c_int]
-FLAGS = [int(f) for f in os.environ.get("PBL_SB_FLAGS", "").split(",") if f]      # bit 1: prologue only
 
 
 def timeit(fn, n=100):
@@ -57,9 +55,5 @@ for shp, lf in SHAPES:
                 y2 = Q.small_image_forward(layer.packed, None, x, img)
                 res[f"image_us_w{w}"] = round(timeit(lambda: Q.small_image_forward(layer.packed, None, x, img)), 2)
                 res[f"rel_err_w{w}"] = float(f"{err:.2e}"); res[f"repeat_w{w}"] = bool(torch.equal(y, y2))
-                for f in FLAGS:
-                    setf(f)
-                    res[f"image_us_w{w}_dbg{f}"] = round(timeit(lambda: Q.small_image_forward(layer.packed, None, x, img)), 2)
-                    setf(0)
             setw(0)
         print(json.dumps(res), flush=True)

@@ -1,5 +1,8 @@
 #!/bin/bash
-# r4-36: experiment: in-kernel reduce with 16-byte system-scope stores / loads
+# r4-37: capture test of the small-batch image path, bf16 tests, GEMM suite after the cleanup
 set -u
 export TMPDIR=/tmp
-PBL_BENCH_SHAPES=13824x5120:0.8,5120x13824:0.8,11008x4096:0.9 PBL_BENCH_MS=32 PBL_SB_WAVES=0 PBL_SB_FLAGS=4 timeout 800 python tools/bench_small.py 2>&1 | grep -v amdgpu.ids | cut -c1-500
+timeout 120 python __graft_entry__.py 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "capture or bf16 or native or llama13b" 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_gemm.py -x -q -m gpu 2>&1 | tail -3
+timeout 200 python tools/bench_host.py 2>&1 | tail -6 | cut -c1-300
