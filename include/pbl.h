@@ -353,11 +353,11 @@ size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* geom);
 int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, void* stream);
 int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
                        const uint32_t* geom, void* stream);
-/* The same product for 1 <= M <= 32 rows of x over the same image (HBM-bound: the image is read once; every wave owns 32 rows of W
- * and a range of 128-column half slabs, K is split over the grid).  workspace: pbl_gemm_small_image_workspace_bytes(layer, M) bytes,
+/* The same product for 1 <= M <= 64 rows of x over the same image (HBM-bound: the image is read once, also for 33 - 64 rows; every
+ * wave owns 32 rows of W and a range of 128-column half slabs, K is split over the grid).  workspace: pbl_gemm_small_image_workspace_bytes(layer, M) bytes,
  * 16-byte aligned, any content (the splits' fp32 partial outputs, added in split order by a second small kernel: deterministic);
  * NULL / too small: one split.
- * Replaces F.linear at a small serving batch (quant/outlier_quantizer.py:101-106 at <= 32 rows; BASELINE.json configs[3]). */
+ * Replaces F.linear at a small serving batch (quant/outlier_quantizer.py:101-106 at <= 64 rows; BASELINE.json configs[3]). */
 size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, int M);
 int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
                             const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream);

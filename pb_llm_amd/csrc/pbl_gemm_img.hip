@@ -713,7 +713,7 @@ struct SbArgs {
 };
 #define SB_WAVES 4                   // working waves of a workgroup (+ 1 that stages x)
 #define SB_X_OFF (SB_WAVES * 8192)
-#define SB_LDS (SB_X_OFF + 2 * 8192)
+#define SB_LDS(NTB_) (SB_X_OFF + 2 * 8192 * (NTB_))      // + the x tile's double buffer: 32 NTB tokens x 128 columns each
 
 typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;        // constant address space: scalar loads
 // Half slabs of slot requests in flight per wave (2 sets each).  Measured on 13824 x 5120, 20 % salients, 32 rows (calls r4-30 .. 32):
@@ -727,11 +727,13 @@ typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;        
 #ifndef PBL_SB_NT
 #define PBL_SB_NT 0                  // slot loads with the non-temporal hint (the image is read once)
 #endif
-template <int NVK, bool KT>
-__global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_per_eu(NVK <= 3 ? 4 : 3, NVK <= 3 ? 4 : 3))) void pbl_sb_img_kernel(SbArgs a) {
+// NTB: blocks of 32 rows of x (1: up to 32 rows, 2: up to 64 -- the image is still read once; twice the x tile, accumulators, MFMAs)
+template <int NVK, bool KT, int NTB>
+__global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_per_eu(NVK + NTB <= 4 ? 4 : 3, NVK + NTB <= 4 ? 4 : 3))) void pbl_sb_img_kernel(SbArgs a) {
     constexpr int D = PBL_SB_DEPTH;
     static_assert(D >= 2 && D % 2 == 0, "the x double buffer's parity is static in the unrolled loop");
-    __shared__ __attribute__((aligned(16))) char smem_s[SB_LDS];
+    __shared__ __attribute__((aligned(16))) char smem_s[SB_LDS(NTB)];
+    constexpr uint32_t XBUF = 8192u * NTB;                    // one x tile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const pbl_layer& L = a.L;
@@ -744,10 +746,10 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
         // 256 t + 16 (u ^ (t & 15)).  A DMA piece is 1 KiB = 4 token rows: lane l lands on unit (l & 15) of token 4 piece + (l >> 4),
         // which holds the LOGICAL unit (l & 15) ^ (token & 15).  Through a buffer descriptor over the M rows of x: tokens >= M read zeros.
         __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.x), 0, int(size_t(M) * size_t(K) * 2), 0x00020000);
-        uint32_t xvoff[8], xvlast[KT ? 8 : 1];
+        uint32_t xvoff[8 * NTB], xvlast[KT ? 8 * NTB : 1];
         const uint32_t ktail_units = uint32_t(K & (GI_HS - 1)) >> 3;               // valid units of the last half slab (0: no tail)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 8 * NTB; ++q) {
             const uint32_t tl = uint32_t(4 * q + (lane >> 4));
             const uint32_t lu = uint32_t(lane & 15) ^ (tl & 15);
             xvoff[q] = tl * uint32_t(K) * 2u + (lu << 4);
@@ -759,10 +761,10 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
             if (h < h1) {
                 const uint32_t buf = uint32_t(h - h0) & 1u;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < 8 * NTB; ++q) {
                     uint32_t vo = xvoff[q];
                     if constexpr (KT) vo = (h == NH - 1) ? xvlast[q] : vo;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_s + SB_X_OFF + buf * 8192u + uint32_t(q) * 1024u), 16, int(vo), h * (GI_HS * 2), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_s + SB_X_OFF + buf * XBUF + uint32_t(q) * 1024u), 16, int(vo), h * (GI_HS * 2), 0, 0);
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -842,9 +844,11 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
         aq[k8] = uint32_t(i32) * 256u + ((uint32_t(2 * k8 + g) ^ uint32_t(i32 & 15)) << 4);
         bq[k8] = SB_X_OFF + aq[k8];                           // (the x tile has the A tile's geometry: 32 rows of 256 bytes, the same swizzle)
     }
-    v16f acc;
+    v16f acc[NTB];
 #pragma unroll
-    for (int e_ = 0; e_ < 16; ++e_) acc[e_] = 0.f;
+    for (int b = 0; b < NTB; ++b)
+#pragma unroll
+        for (int e_ = 0; e_ < 16; ++e_) acc[b][e_] = 0.f;
 
     {
         const uint32_t g0 = (uint32_t(h0) * GI_HS) / gs;
@@ -875,8 +879,11 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8) {
                 const v8h af = *reinterpret_cast<const v8h*>(As + aq[k8]);
-                const v8h bf = *reinterpret_cast<const v8h*>(smem_s + bq[k8] + buf * 8192u);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < NTB; ++b) {
+                    const v8h bf = *reinterpret_cast<const v8h*>(smem_s + bq[k8] + buf * XBUF + uint32_t(b) * 8192u);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[b], 0, 0, 0);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of the x tile are done; then everyone's, and the next tile is in
@@ -888,45 +895,48 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
         for (int j = 0; j < D; ++j) half_slab(h + j, uint32_t(j & 1), e[2 * j], e[2 * j + 1], nvs[2 * j], nvs[2 * j + 1], h + j < h1);
     }
 
-    // ---- the 32 x 32 tile: rows (reg & 3) + 8 (reg >> 2) + 4 g of the pair, token i32
+    // ---- the 32 x 32 tiles: rows (reg & 3) + 8 (reg >> 2) + 4 g of the pair, token 32 b + i32
     const uint32_t row0 = pair_raw * 32u;
-    const int tok = i32;
     if (pair_raw >= npairs) return;
     const bool whole = row0 + 32 <= L.N && (L.N & 3) == 0;
-    float o[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const uint32_t row = row0 + uint32_t(8 * (q >> 2) + 4 * g + (q & 3));
-        o[q] = acc[q];
-        if (L.bias && ks == 0 && row < L.N) o[q] += L.bias[row];
-    }
-    if (tok >= M) return;
-    if (a.KS > 1) {                                           // this split's partial tile; sb_reduce_kernel adds the splits
-        float* dst = a.part + (size_t(ks) * M + tok) * L.N + row0 + 4 * g;
+    for (int b = 0; b < NTB; ++b) {
+        const int tok = 32 * b + i32;
+        if (tok >= M) continue;
+        float o[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const uint32_t row = row0 + uint32_t(8 * (q >> 2) + 4 * g + (q & 3));
+            o[q] = acc[b][q];
+            if (L.bias && ks == 0 && row < L.N) o[q] += L.bias[row];
+        }
+        if (a.KS > 1) {                                       // this split's partial tile; sb_reduce_kernel adds the splits
+            float* dst = a.part + (size_t(ks) * M + tok) * L.N + row0 + 4 * g;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                if (whole) *reinterpret_cast<v4f*>(dst + 8 * q4) = v4f{o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]};
+                else
+                    for (int r = 0; r < 4; ++r) if (row0 + 4 * g + 8 * q4 + r < L.N) dst[8 * q4 + r] = o[4 * q4 + r];
+            }
+            continue;
+        }
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            if (whole) *reinterpret_cast<v4f*>(dst + 8 * q4) = v4f{o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]};
-            else
-                for (int r = 0; r < 4; ++r) if (row0 + 4 * g + 8 * q4 + r < L.N) dst[8 * q4 + r] = o[4 * q4 + r];
-        }
-        return;
-    }
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-        const uint32_t row = row0 + uint32_t(8 * q4 + 4 * g);
-        if (a.y_f32) {
-            float* dst = static_cast<float*>(a.y) + size_t(tok) * L.N + row;
-            if (whole) *reinterpret_cast<v4f*>(dst) = v4f{o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]};
-            else
-                for (int r = 0; r < 4; ++r) if (row + r < L.N) dst[r] = o[4 * q4 + r];
-        } else {
-            _Float16* dst = static_cast<_Float16*>(a.y) + size_t(tok) * L.N + row;
-            if (whole) {
-                uint2 pk;
-                pk.x = h16(o[4 * q4]) | (h16(o[4 * q4 + 1]) << 16); pk.y = h16(o[4 * q4 + 2]) | (h16(o[4 * q4 + 3]) << 16);
-                *reinterpret_cast<uint2*>(dst) = pk;
-            } else
-                for (int r = 0; r < 4; ++r) if (row + r < L.N) dst[r] = _Float16(o[4 * q4 + r]);
+            const uint32_t row = row0 + uint32_t(8 * q4 + 4 * g);
+            if (a.y_f32) {
+                float* dst = static_cast<float*>(a.y) + size_t(tok) * L.N + row;
+                if (whole) *reinterpret_cast<v4f*>(dst) = v4f{o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]};
+                else
+                    for (int r = 0; r < 4; ++r) if (row + r < L.N) dst[r] = o[4 * q4 + r];
+            } else {
+                _Float16* dst = static_cast<_Float16*>(a.y) + size_t(tok) * L.N + row;
+                if (whole) {
+                    uint2 pk;
+                    pk.x = h16(o[4 * q4]) | (h16(o[4 * q4 + 1]) << 16); pk.y = h16(o[4 * q4 + 2]) | (h16(o[4 * q4 + 3]) << 16);
+                    *reinterpret_cast<uint2*>(dst) = pk;
+                } else
+                    for (int r = 0; r < 4; ++r) if (row + r < L.N) dst[r] = _Float16(o[4 * q4 + r]);
+            }
         }
     }
 }
@@ -1107,21 +1117,21 @@ extern "C" int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y
 // tuning hook (tools/): the number of waves the small-batch kernel's K split aims at
 extern "C" void pbl_debug_set_small_image_waves(int n) { g_sb_waves = n > 0 ? n : 0; }
 
-// Transient workspace of pbl_gemm_small_image_ws for M <= 32 rows: the K splits' fp32 partial outputs (0: one split).
+// Transient workspace of pbl_gemm_small_image_ws for M <= 64 rows: the K splits' fp32 partial outputs (0: one split).
 extern "C" size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, int M) {
-    if (!layer_ok(layer) || M < 1 || M > 32) return 0;
+    if (!layer_ok(layer) || M < 1 || M > 64) return 0;
     int KS, hps;
     sb_split(layer, KS, hps);
     return KS > 1 ? size_t(KS) * M * layer->N * sizeof(float) : 0;
 }
 
-// y[M, N] = x[M, K] . W^T (+ bias) for 1 <= M <= 32 rows over the GEMM image (the same image, the same geometry words as
+// y[M, N] = x[M, K] . W^T (+ bias) for 1 <= M <= 64 rows over the GEMM image (the same image, the same geometry words as
 // pbl_gemm_f16_image).  `workspace` (pbl_gemm_small_image_workspace_bytes(layer, M), 16-byte aligned; any content) holds the K
 // splits' partial outputs; NULL / too small: one split (slow for layers with few rows).  The same numbers as the other kernels up
 // to fp32 summation order (within the parity tolerance of tests/test_gpu_gemm.py); repeatable run to run.
 extern "C" int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
                                        const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!layer || !layer->blob || !x || !y || !image || !geom || M < 1 || M > 32) return PBL_ERR_INVALID_ARG;
+    if (!layer || !layer->blob || !x || !y || !image || !geom || M < 1 || M > 64) return PBL_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return PBL_ERR_MISALIGNED;
     if (!layer_ok(layer) || layer->K < 16) return PBL_ERR_UNSUPPORTED;
     ImgGeom g;
@@ -1139,9 +1149,11 @@ extern "C" int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, vo
     a.part = a.KS > 1 ? static_cast<float*>(workspace) : nullptr;
     const uint32_t nvk = geom[1];
     const bool kt = (layer->K & (GI_HS - 1)) != 0;
-#define SB_PICK(NV_) (kt ? reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, true>) : reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, false>))
+#define SB_PICK2(NV_, KT_) (M > 32 ? reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, KT_, 2>) : reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, KT_, 1>))
+#define SB_PICK(NV_) (kt ? SB_PICK2(NV_, true) : SB_PICK2(NV_, false))
     const void* k = nvk == 1 ? SB_PICK(1) : nvk == 2 ? SB_PICK(2) : nvk == 3 ? SB_PICK(3) : nvk == 4 ? SB_PICK(4) : SB_PICK(5);
 #undef SB_PICK
+#undef SB_PICK2
     void* argv[] = {&a};
     const uint32_t npairs = (layer->NRB + 1) / 2;
     if (hipLaunchKernel(k, dim3((npairs + SB_WAVES - 1) / SB_WAVES, uint32_t(a.KS)), dim3((SB_WAVES + 1) * GW), argv, 0, st) != hipSuccess) return PBL_ERR_LAUNCH;

@@ -34,6 +34,7 @@ namespace {
 
 constexpr int64_t MFMA_MAX = 32;        // rows the packed small-batch kernels take (pb_llm_amd/quant.py: MFMA_MAX)
 constexpr int64_t GEMM_THRESHOLD = 12;  // ... and where layers the matrix-core kernel refuses switch to the dense path
+constexpr int64_t SMALL_IMAGE_MAX = 64; // rows the small-batch kernel over the GEMM image takes (the image is read once for all of them)
 constexpr int64_t SMALL_IMAGE_MIN = 5;  // rows from which the small-batch kernel over the GEMM image beats the one over the records (pb_llm_amd/quant.py)
 
 pbl_layer make_layer(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, int64_t N, int64_t K, int64_t P, int64_t G,
@@ -76,17 +77,20 @@ struct ImageRef {
 
 // <= 32 rows of fp16 x [M, K] -> y [M, N] (fp16 / fp32); scratch from the caching allocator (stream ordered, graph safe).  With
 // the layer's GEMM image and SMALL_IMAGE_MIN rows or more: the small-batch kernel over the image (pbl_gemm_small_image_ws).
+// pbl_gemm_small_image_ws into y (<= 64 rows); false: a layer the kernel does not take
+bool run_small_image(const pbl_layer& L, const at::Tensor& xc, at::Tensor& y, int64_t M, bool f32, const ImageRef& img) {
+    const size_t nbi = pbl_gemm_small_image_workspace_bytes(&L, int(M));
+    at::Tensor wsi;
+    if (nbi) wsi = at::empty({int64_t(nbi)}, xc.options().dtype(at::kByte));
+    const int rc = pbl_gemm_small_image_ws(&L, xc.data_ptr(), y.data_ptr(), int(M), f32 ? 1 : 0, img.data, img.bytes, img.geom.data(),
+                                           nbi ? wsi.data_ptr() : nullptr, nbi, stream_of(xc));
+    TORCH_CHECK(rc == PBL_OK || rc == PBL_ERR_UNSUPPORTED, "libpbl gemm_small_image: ", pbl_status_string(rc), " (", rc, ")");
+    return rc == PBL_OK;
+}
+
 at::Tensor run_small(const pbl_layer& L, const at::Tensor& xc, int64_t M, bool f32, const ImageRef& img) {
     at::Tensor y = at::empty({M, int64_t(L.N)}, xc.options().dtype(f32 ? at::kFloat : at::kHalf));
-    if (img && M >= SMALL_IMAGE_MIN && (reinterpret_cast<uintptr_t>(xc.data_ptr()) & 15) == 0) {
-        const size_t nbi = pbl_gemm_small_image_workspace_bytes(&L, int(M));
-        at::Tensor wsi;
-        if (nbi) wsi = at::empty({int64_t(nbi)}, xc.options().dtype(at::kByte));
-        const int rc = pbl_gemm_small_image_ws(&L, xc.data_ptr(), y.data_ptr(), int(M), f32 ? 1 : 0, img.data, img.bytes, img.geom.data(),
-                                               nbi ? wsi.data_ptr() : nullptr, nbi, stream_of(xc));
-        if (rc == PBL_OK) return y;
-        TORCH_CHECK(rc == PBL_ERR_UNSUPPORTED, "libpbl gemm_small_image: ", pbl_status_string(rc), " (", rc, ")");   // (a layer it does not take: the records kernel)
-    }
+    if (img && M >= SMALL_IMAGE_MIN && (reinterpret_cast<uintptr_t>(xc.data_ptr()) & 15) == 0 && run_small_image(L, xc, y, M, f32, img)) return y;
     const size_t nb = M > 1 ? pbl_linear_workspace_bytes(&L, int(M)) : 0;      // one token is always one GEMV pass
     at::Tensor ws;
     if (nb) ws = at::empty({int64_t(nb)}, xc.options().dtype(at::kByte));
@@ -143,6 +147,7 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
                 const bool img = bool(iref);
                 if (img || backend == "fused") {
                     at::Tensor y = at::empty({M, N}, x.options().dtype(out_f32 ? at::kFloat : at::kHalf));
+                    if (img && M <= SMALL_IMAGE_MAX && run_small_image(L, xc, y, M, out_f32, iref)) return y.reshape(shape);   // 33 - 64 rows: one pass over the image
                     if (img) {
                         check(pbl_gemm_f16_image(&L, xc.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, iref.data, iref.bytes, iref.geom.data(),
                                                  stream_of(x)), "gemm_f16_image");

@@ -71,6 +71,7 @@ GEMM_KEEP_IMAGE = os.environ.get("PBL_GEMM_KEEP_IMAGE", "1") == "1"
 # already built is used; "1" builds it on the first small-batch call as well, "0" never uses it.
 SMALL_BATCH_IMAGE = os.environ.get("PBL_SMALL_BATCH_IMAGE", "auto")
 SMALL_IMAGE_MIN = 5
+SMALL_IMAGE_MAX = 64       # (33 - 64 rows are GEMM regime for everything else; with an image they are one more pass of the small-batch kernel)
 BF16_RANGE_CHECK = os.environ.get("PBL_BF16_RANGE_CHECK", "1") == "1"
 
 
@@ -120,7 +121,7 @@ def _wait_image(stream, image: "GemmImage") -> None:
 
 
 def small_image_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, image: "GemmImage", out_f32: bool = False) -> torch.Tensor:
-    """pbl_gemm_small_image_ws: x2 [M <= 32, K] fp16 contiguous -> [M, N] over the layer's GEMM image (the small-batch kernel of
+    """pbl_gemm_small_image_ws: x2 [M <= 64, K] fp16 contiguous -> [M, N] over the layer's GEMM image (the small-batch kernel of
     csrc/pbl_gemm_img.hip); the K splits' partial outputs go through a transient workspace from the caching allocator."""
     M = x2.shape[0]
     y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
@@ -318,9 +319,11 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
         rows = 2 * M if x.dtype == torch.float32 else M
         ki = None
         if rows > MFMA_MAX:
-            if backend != "library" and x.dtype == torch.float16 and dense_f16 and GEMM_KEEP_IMAGE \
-                    and fused_gemm_ok(packed) and (backend == "fused" or _image_fills_the_chip(packed.N, M, x.device)):
-                ki = _kept_image(packed)
+            if backend != "library" and x.dtype == torch.float16 and dense_f16 and GEMM_KEEP_IMAGE and fused_gemm_ok(packed):
+                if M <= SMALL_IMAGE_MAX:
+                    ki = _small_batch_image(packed)          # 33 - 64 rows: the small-batch kernel reads the image once for all of them
+                if ki is None and (backend == "fused" or _image_fills_the_chip(packed.N, M, x.device)):
+                    ki = _kept_image(packed)
         elif rows >= SMALL_IMAGE_MIN and dense_f16:          # (the image holds fp16 weights: layers an fp16 checkpoint is exact for)
             ki = _small_batch_image(packed)
         if ki is not None:
@@ -365,15 +368,18 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         # reference executes (F.linear over the dense fake-quant weight).  fp16 weights when
         # the layer is fp16-exact (packed from an fp16 checkpoint), else fp32.
         wdt = torch.float16 if (x.dtype == torch.float16 and dense_dtype in (None, torch.float16)) else torch.float32
-        if GEMM_BACKEND in ("auto", "fused") and wdt == torch.float16 and fused_gemm_ok(packed) and \
-                (GEMM_BACKEND == "fused" or _image_fills_the_chip(packed.N, M, x.device)):
+        if GEMM_BACKEND in ("auto", "fused") and wdt == torch.float16 and fused_gemm_ok(packed):
             xc = x2.contiguous()
             if xc.data_ptr() % 16 == 0:
-                img = _kept_image(packed) if GEMM_KEEP_IMAGE else None
-                if img is not None:
-                    return fused_gemm_forward(packed, bias_f32, xc, out_f32, image=img).reshape(*lead, packed.N)
-                if GEMM_BACKEND == "fused":
-                    return fused_gemm_forward(packed, bias_f32, xc, out_f32, prepared=_kept_list(packed) if GEMM_KEEP_LIST else None).reshape(*lead, packed.N)
+                simg = _small_batch_image(packed) if M <= SMALL_IMAGE_MAX else None       # 33 - 64 rows: one more pass of the small-batch kernel
+                if simg is not None:
+                    return small_image_forward(packed, bias_f32, xc, simg, out_f32).reshape(*lead, packed.N)
+                if GEMM_BACKEND == "fused" or _image_fills_the_chip(packed.N, M, x.device):
+                    img = _kept_image(packed) if GEMM_KEEP_IMAGE else None
+                    if img is not None:
+                        return fused_gemm_forward(packed, bias_f32, xc, out_f32, image=img).reshape(*lead, packed.N)
+                    if GEMM_BACKEND == "fused":
+                        return fused_gemm_forward(packed, bias_f32, xc, out_f32, prepared=_kept_list(packed) if GEMM_KEEP_LIST else None).reshape(*lead, packed.N)
         W = unpack_on_device(packed, wdt)
         y = torch.nn.functional.linear(x2.to(wdt), W, None if bias_f32 is None else bias_f32.to(wdt))
         y = y.float() if out_f32 else y.to(x.dtype)

@@ -122,7 +122,7 @@ def test_gemm_regime_kernel(N, K, M, gs, lf, fp16, exc, metric):
         assert torch.equal(y32[:33], Q.fused_gemm_forward(pd, None, xt[:33].contiguous(), out_f32=True, image=img))
         # ... and the small-batch kernel over the same image (<= 32 rows: pbl_gemm_small_image_ws; K split over the grid, partial
         # tiles added in split order): the oracle's numbers within the same tolerance, the same bits run after run
-        for ms in (1, 8, 32):
+        for ms in (1, 8, 32, 33, min(M, 64)):                     # (33 - 64 rows: two blocks of 32 rows of x, the image still read once)
             xs = xt[:ms].contiguous()
             ys = Q.small_image_forward(pd, T(b), xs, img)
             assert ys.shape == (ms, N) and ys.dtype == torch.float16
@@ -219,7 +219,11 @@ def test_kept_image_and_kept_list_follow_the_blob():
             assert torch.equal(layer(x), ref)
             kimg = layer.packed._gemm_image
             assert kimg[1] is not None and kimg[1].max_slot_kib >= 1
-            assert torch.equal(layer(x[:40]), ref[:40]) and layer.packed._gemm_image is kimg      # one image, any M
+            assert torch.equal(layer(x[:70]), ref[:70]) and layer.packed._gemm_image is kimg      # one image, any M
+            # ... and up to 64 rows the small-batch kernel over the same image (another summation order: the K split)
+            y40 = layer(x[:40])
+            assert torch.equal(y40, Q.small_image_forward(layer.packed, layer.pbl_bias, x[:40].contiguous(), kimg[1])) and layer.packed._gemm_image is kimg
+            assert_parity(y40, ref[:40].float().cpu().numpy().astype(np.float64), 2e-3)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):

@@ -312,6 +312,15 @@ def test_llama13b_ffn_shapes_m32():
             assert torch.equal(lay(x5), Q.small_image_forward(lay.packed, None, x5, img))  # 5 rows: still the image kernel
             assert_parity(lay(x5), g["y"][:5], 2e-3)
             assert_parity(lay(T(x)[:4]), g["y"][:4], 2e-3)                            # 4 rows: GEMV passes over the packed records
+            # 33 - 64 rows are GEMM regime for every other path; with an image they are one more pass of the small-batch kernel
+            x48 = synth.activations((48, K), seed + 1, 21)
+            y48 = lay(T(x48))
+            assert y48.shape == (48, N) and torch.equal(y48, Q.small_image_forward(lay.packed, None, T(x48), img))
+            rows = np.arange(0, N, 37)
+            W16 = r["W_fq"].astype(np.float16).astype(np.float32)
+            assert_parity(y48[:, torch.from_numpy(rows).to(DEV)], O.dense_linear(x48, W16[rows]))
+            Q.SMALL_BATCH_IMAGE = "0"
+            assert_parity(lay(T(x48)), y48.float().cpu().numpy().astype(np.float64), 2e-3)   # ... and without: unpack + library GEMM
         finally:
             Q.SMALL_BATCH_IMAGE = old
 

@@ -116,7 +116,7 @@ def test_gemm_image_sizing_of_the_c_abi_without_a_gpu():
     assert L.pbl_gemm_image_build(C.byref(lay), geom, None, None, 0, None) == _lib.PBL_ERR_INVALID_ARG
     assert L.pbl_gemm_f16_image(C.byref(lay), None, None, 64, 0, None, 0, geom, None) == _lib.PBL_ERR_INVALID_ARG
     assert L.pbl_gemm_small_image_ws(C.byref(lay), None, None, 8, 0, None, 0, geom, None, 0, None) == _lib.PBL_ERR_INVALID_ARG
-    # the small-batch kernel's K split: only for <= 32 rows; the workspace is KS x M x N floats
-    assert L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), 33) == 0 and L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), 0) == 0
-    w8, w32 = (L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), m) for m in (8, 32))
-    assert w8 > 0 and w32 == 4 * w8 and w8 % (8 * 4096 * 4) == 0 and 2 <= w8 // (8 * 4096 * 4) <= 8         # KS <= NH / 4 = 8
+    # the small-batch kernel's K split: only for <= 64 rows; the workspace is KS x M x N floats
+    assert L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), 65) == 0 and L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), 0) == 0
+    w8, w32, w64 = (L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), m) for m in (8, 32, 64))
+    assert w8 > 0 and w32 == 4 * w8 and w64 == 8 * w8 and w8 % (8 * 4096 * 4) == 0 and 2 <= w8 // (8 * 4096 * 4) <= 8         # KS <= NH / 4 = 8

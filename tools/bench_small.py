@@ -42,7 +42,7 @@ for shp, lf in SHAPES:
         x = torch.from_numpy(synth.activations((M, K), 3, 21)).cuda()
         res = dict(shape=shp, low_frac=lf, M=M, blob_MB=round(blob_mb, 2), image_MB=round(img.data.numel() / 1e6, 2) if img else None)
         Q.GEMM_KEEP_IMAGE = "0"
-        res["records_us"] = round(timeit(lambda: Q.mfma_forward(layer.packed, None, x)), 2)
+        res["records_us"] = round(timeit(lambda: Q.mfma_forward(layer.packed, None, x)), 2) if M <= 32 else None
         Q.SMALL_BATCH_IMAGE = "0"
         res["routed_us"] = round(timeit(lambda: Q._pb_linear_forward(layer.packed, None, x, False, None)), 2)      # pbl_linear_f16_ws: GEMV passes or the records kernel
         res["dense_us"] = round(timeit(lambda: torch.nn.functional.linear(x, Wd)), 2)
