@@ -684,7 +684,7 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
 }
 
 // ---- <= 32 rows of x over the same image ------------------------------------------------------------------------------------
-// Replaces the same call at 5 - 32 rows (quant/outlier_quantizer.py:101-106 under a small serving batch; BASELINE.json configs[3]).
+// Replaces the same call at 5 - 64 rows (quant/outlier_quantizer.py:101-106 under a small serving batch; BASELINE.json configs[3]).
 // HBM-bound: the image is read once, x (32 x K fp16) lives in L2.  No roles: every WAVE owns a pair of records (32 rows) and the
 // workgroup's range of half slabs, and per half slab
 //   * rebuilds its two records' 16 x 128 fp16 tiles in its PRIVATE 8 KiB of LDS from the slots (plane dword -> 16 stores, every

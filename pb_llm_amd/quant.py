@@ -65,7 +65,7 @@ GEMM_KEEP_LIST = os.environ.get("PBL_GEMM_KEEP_LIST", "0") == "1"
 # the layer (1 KiB per 16 rows x 128 columns: 8.4 MB for a 4096^2 layer at 5 % salients, a quarter of the dense fp16 weight).
 # "0": the round-3 kernel over the per-call (or kept) salient list.
 GEMM_KEEP_IMAGE = os.environ.get("PBL_GEMM_KEEP_IMAGE", "1") == "1"
-# 5 - 32 rows (a small serving batch; BASELINE.json configs[3]): the small-batch kernel over the same image
+# 5 - 64 rows (a small serving batch; BASELINE.json configs[3]): the small-batch kernel over the same image
 # (pbl_gemm_small_image_ws; 13824 x 5120 at 20 % salients and 32 rows: 24.7 us against 39.7 for the kernel over the packed
 # records).  The image costs memory (2.5 x the blob at 20 % salients), so by default ("auto") only an image that a prefill call
 # already built is used; "1" builds it on the first small-batch call as well, "0" never uses it.
@@ -222,7 +222,7 @@ def _kept_image(packed: PackedWeight) -> GemmImage | None:
 
 
 def _small_batch_image(packed: PackedWeight) -> GemmImage | None:
-    """the image the small-batch kernel (5 - 32 rows) multiplies from, by SMALL_BATCH_IMAGE: "auto" -- the kept image if an earlier
+    """the image the small-batch kernel (5 - 64 rows) multiplies from, by SMALL_BATCH_IMAGE: "auto" -- the kept image if an earlier
     GEMM-regime call built one; "1" -- built here on first use; "0" -- never (the kernel over the packed records runs)."""
     if SMALL_BATCH_IMAGE == "0" or not GEMM_KEEP_IMAGE or not fused_gemm_ok(packed):
         return None
