@@ -711,7 +711,12 @@ struct SbArgs {
     const uint32_t* rtab;
     const uint32_t* levels;
 };
+#ifndef SB_WAVES
 #define SB_WAVES 4                   // working waves of a workgroup (+ 1 that stages x)
+#endif
+#ifndef PBL_SB_WGS_PER_CU
+#define PBL_SB_WGS_PER_CU 2          // workgroups per CU the K split aims at
+#endif
 #define SB_X_OFF (SB_WAVES * 8192)
 #define SB_LDS(NTB_) (SB_X_OFF + 2 * 8192 * (NTB_))      // + the x tile's double buffer: 32 NTB tokens x 128 columns each
 
@@ -724,12 +729,15 @@ typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;        
 #ifndef PBL_SB_DEPTH
 #define PBL_SB_DEPTH 2
 #endif
+#ifndef PBL_SB_WPE
+#define PBL_SB_WPE(NVK_, NTB_) ((NVK_) + (NTB_) <= 4 ? 4 : 3)
+#endif
 #ifndef PBL_SB_NT
 #define PBL_SB_NT 0                  // slot loads with the non-temporal hint (the image is read once)
 #endif
 // NTB: blocks of 32 rows of x (1: up to 32 rows, 2: up to 64 -- the image is still read once; twice the x tile, accumulators, MFMAs)
 template <int NVK, bool KT, int NTB>
-__global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_per_eu(NVK + NTB <= 4 ? 4 : 3, NVK + NTB <= 4 ? 4 : 3))) void pbl_sb_img_kernel(SbArgs a) {
+__global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_per_eu(PBL_SB_WPE(NVK, NTB), PBL_SB_WPE(NVK, NTB)))) void pbl_sb_img_kernel(SbArgs a) {
     constexpr int D = PBL_SB_DEPTH;
     static_assert(D >= 2 && D % 2 == 0, "the x double buffer's parity is static in the unrolled loop");
     __shared__ __attribute__((aligned(16))) char smem_s[SB_LDS(NTB)];
@@ -991,7 +999,7 @@ void sb_split(const pbl_layer* L, int& KS, int& hps) {
     const int waves = g_sb_waves;
     const int NH = int((L->K + GI_HS - 1) / GI_HS), npairs = int((L->NRB + 1) / 2);
     const int cols = (npairs + SB_WAVES - 1) / SB_WAVES;
-    int ks = waves > 0 ? (waves + npairs / 2) / npairs : int((2 * sb_cu_count() * 51LL / 50) / cols);
+    int ks = waves > 0 ? (waves + npairs / 2) / npairs : int((PBL_SB_WGS_PER_CU * sb_cu_count() * 51LL / 50) / cols);
     if (ks > NH / 4) ks = NH / 4;
     if (ks < 1) ks = 1;
     hps = (NH + ks - 1) / ks;
