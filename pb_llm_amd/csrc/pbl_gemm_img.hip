@@ -683,19 +683,19 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
 #endif
 }
 
-// ---- <= 32 rows of x over the same image ------------------------------------------------------------------------------------
+// ---- <= 64 rows of x over the same image ------------------------------------------------------------------------------------
 // Replaces the same call at 5 - 64 rows (quant/outlier_quantizer.py:101-106 under a small serving batch; BASELINE.json configs[3]).
-// HBM-bound: the image is read once, x (32 x K fp16) lives in L2.  No roles: every WAVE owns a pair of records (32 rows) and the
-// workgroup's range of half slabs, and per half slab
+// HBM-bound: the image is read once, x (32 or 64 rows x K fp16) lives in L2.  No roles among the working waves: every WAVE owns a
+// pair of records (32 rows) and the workgroup's range of half slabs, and per half slab
 //   * rebuilds its two records' 16 x 128 fp16 tiles in its PRIVATE 8 KiB of LDS from the slots (plane dword -> 16 stores, every
 //     entry word one 2-byte store: the GEMM kernel's expansion), which arrive through a ring of four slot register sets requested
 //     two half slabs ahead (plain loads: the compiler counts vmcnt),
 //   * reads the A fragments back (a wave's LDS operations execute in order: no wait between the stores and the reads) and
-//     multiplies them with x's 32 x 128 tile, which a FIFTH wave of the workgroup stages by LDS-DMA (eight 1 KiB pieces per half
-//     slab, whole 128-byte lines of x; a fragment read straight from global memory touches 32 lines per instruction) into a
-//     double buffer: ONE workgroup barrier per half slab.  The staging wave exists so that the x pieces are not in the working
-//     waves' vmcnt queue: memory operations return in order, and waiting for a piece would also wait for every slot request
-//     issued before it -- the look-ahead of the slot ring would shrink to one half slab.
+//     multiplies them with x's 32 x 128 tile (two of them for 33 - 64 rows), which a FIFTH wave of the workgroup stages by LDS-DMA
+//     (eight 1 KiB pieces per tile, whole 128-byte lines of x; a fragment read straight from global memory touches 32 lines per
+//     instruction) into a double buffer: ONE workgroup barrier per half slab.  The staging wave keeps the x pieces out of the
+//     working waves' vmcnt queue (memory operations return in order: waiting for a piece also waits for every slot request issued
+//     before it).
 // K is split over gridDim.y; the splits' fp32 partial tiles are added in split order by sb_reduce_kernel (deterministic): a second
 // small launch, 2.9 us behind the first.  (Folding the sum into the LAST split to arrive was built and measured, call r4-23/24: with
 // release / acquire fences at agent scope -- a buffer_wbl2 per wave -- 44 - 110 us per launch instead of 25; with agent-scope
