@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle import pb_oracle as O
+from oracle import pb_image_ref as IMG
 from pb_llm_amd import _lib, synth
 from pb_llm_amd import quant as Q
 from pb_llm_amd.packing import pack_dense
@@ -130,6 +131,12 @@ def test_gemm_regime_kernel(N, K, M, gs, lf, fp16, exc, metric):
             ys32 = Q.small_image_forward(pd, None, xs, img, out_f32=True)
             assert_parity(ys32[:, ridx], O.dense_linear(x[:ms], W16[rows]), 3e-4)
             assert torch.equal(ys, Q.small_image_forward(pd, T(b), xs, img)) and torch.equal(ys32, Q.small_image_forward(pd, None, xs, img, out_f32=True))
+        # the image itself, decoded by the independent numpy reader (oracle/pb_image_ref.py): exactly the fp16 weights a dense
+        # fp16 copy of the layer holds (for an fp32-grid layer: its values rounded to fp16), every padding word idempotent
+        if N * K <= 4096 * 4096:
+            Wimg, st = IMG.decode(img.data.cpu().numpy())
+            np.testing.assert_array_equal(Wimg.astype(np.float32), W16)
+            assert st["bytes"] == img.data.numel() and sum(st["slots_by_kib"]) == ((N + 15) // 16) * ((K + 127) // 128)
         # one K split (no workspace): the same product
         lay_s = pd.layer_struct(None)
         y1 = torch.empty(8, N, dtype=torch.float32, device=DEV)
