@@ -66,9 +66,11 @@ GEMM_KEEP_LIST = os.environ.get("PBL_GEMM_KEEP_LIST", "0") == "1"
 # "0": the round-3 kernel over the per-call (or kept) salient list.
 GEMM_KEEP_IMAGE = os.environ.get("PBL_GEMM_KEEP_IMAGE", "1") == "1"
 # 5 - 64 rows (a small serving batch; BASELINE.json configs[3]): the small-batch kernel over the same image
-# (pbl_gemm_small_image_ws; 13824 x 5120 at 20 % salients and 32 rows: 24.7 us against 39.7 for the kernel over the packed
-# records).  The image costs memory (2.5 x the blob at 20 % salients), so by default ("auto") only an image that a prefill call
-# already built is used; "1" builds it on the first small-batch call as well, "0" never uses it.
+# (pbl_gemm_small_image_ws; 13824 x 5120 at 20 % salients and 32 rows: 22 us against 39.5 for the kernel over the packed
+# records, 33 - 64 rows 34 us against 66 for unpack + library).  The image costs memory ON TOP of the blob (1.7 x the blob's bytes
+# at 20 % salients, 2.4 x at 10 %), so by default ("auto") only an image that a prefill call already built is used -- with the
+# default prefill backend that is every layer whose 2048-row tiles fill the chip (q, k, v, o, down of a llama block; not gate /
+# up); "1" builds it on the first small-batch call as well (what `bench.py --workload cfg4` measures), "0" never uses it.
 SMALL_BATCH_IMAGE = os.environ.get("PBL_SMALL_BATCH_IMAGE", "auto")
 SMALL_IMAGE_MIN = 5
 SMALL_IMAGE_MAX = 64       # (33 - 64 rows are GEMM regime for everything else; with an image they are one more pass of the small-batch kernel)
