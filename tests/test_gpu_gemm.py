@@ -284,3 +284,34 @@ def test_image_kernel_repeatedly_against_the_round3_kernel_at_full_size():
     torch.cuda.synchronize()
     bad = [i for i, y in enumerate(outs) if not torch.equal(y, ref)]
     assert not bad, f"launches {bad} differ from the round-3 kernel"
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_small_batch_image_kernel_on_random_layers(seed):
+    """the small-batch kernel over the GEMM image on random small layers: ragged N (an odd record count, fewer rows than a pair of
+    records), K from one half slab to several with and without a tail, column groups, exceptions, every row count class (1, one
+    block of 32, two blocks), with and without a bias / fp32 result -- against the float64 oracle on the fp16 weights"""
+    rng = np.random.default_rng(1000 + seed)
+    gs = int(rng.choice([-1, -1, 128, 256]))
+    if gs == -1:
+        K = int(rng.choice([16, 72, 128, 200, 384, 1288, 2048]))
+    else:
+        K = gs * int(rng.integers(1, 9))
+    N = int(rng.choice([8, 16, 24, 40, 100, 130, 257, 512]))
+    lf = float(rng.choice([0.5, 0.8, 0.9, 0.97]))
+    p, Wd = rtn_layer(N, K, gs, seed=77 + seed, low_frac=lf, fp16=True, exceptions=int(rng.integers(0, 4)))
+    pd = p.to(DEV)
+    img = Q.gemm_image(pd)
+    assert img is not None
+    W16 = Wd.astype(np.float16).astype(np.float32)
+    np.testing.assert_array_equal(IMG.decode(img.data.cpu().numpy())[0].astype(np.float32), W16)
+    b = synth.normal((N,), 5, seed, 0.1)
+    for M in (1, int(rng.integers(2, 32)), 32, int(rng.integers(33, 64)), 64):
+        x = synth.activations((M, K), seed + M, 21)
+        xt = T(x)
+        y = Q.small_image_forward(pd, T(b), xt, img)
+        assert y.shape == (M, N)
+        assert_parity(y, O.dense_linear(x, W16, b))
+        y32 = Q.small_image_forward(pd, None, xt, img, out_f32=True)
+        assert_parity(y32, O.dense_linear(x, W16), 3e-4)
+        assert torch.equal(y32, Q.small_image_forward(pd, None, xt, img, out_f32=True))
