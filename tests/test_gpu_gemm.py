@@ -315,3 +315,31 @@ def test_small_batch_image_kernel_on_random_layers(seed):
         y32 = Q.small_image_forward(pd, None, xt, img, out_f32=True)
         assert_parity(y32, O.dense_linear(x, W16), 3e-4)
         assert torch.equal(y32, Q.small_image_forward(pd, None, xt, img, out_f32=True))
+
+
+def test_small_batch_image_kernel_repeatedly_at_full_size():
+    """the staging wave hands x tiles to the working waves through a double buffer and one barrier per half slab; a hand-over that
+    is too early shows as a result that differs from launch to launch: 100 launches each at 32 and 64 rows on the configs[3] shape,
+    other work (the image GEMM kernel) in between"""
+    N, K = 13824, 5120
+    p, Wd = rtn_layer(N, K, -1, seed=5, low_frac=0.8, fp16=True)
+    pd = p.to(DEV)
+    img = Q.gemm_image(pd)
+    assert img is not None
+    W16 = Wd.astype(np.float16).astype(np.float32)
+    rows = sample_rows(N)
+    ridx = torch.from_numpy(rows).to(DEV)
+    xbig = T(synth.activations((512, K), 4, 21))
+    for M in (32, 64):
+        x = synth.activations((M, K), 9 + M, 21)
+        xt = T(x)
+        ref = Q.small_image_forward(pd, None, xt, img)
+        assert_parity(ref[:, ridx], O.dense_linear(x, W16[rows]))
+        outs = []
+        for i in range(100):
+            if i % 25 == 0:
+                Q.fused_gemm_forward(pd, None, xbig, image=img)          # (another kernel's LDS contents and cache state in between)
+            outs.append(Q.small_image_forward(pd, None, xt, img))
+        torch.cuda.synchronize()
+        bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
+        assert not bad, f"M={M}: launches {bad[:10]} differ"
