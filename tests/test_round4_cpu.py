@@ -120,3 +120,70 @@ def test_gemm_image_sizing_of_the_c_abi_without_a_gpu():
     assert L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), 65) == 0 and L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), 0) == 0
     w8, w32, w64 = (L.pbl_gemm_small_image_workspace_bytes(C.byref(lay), m) for m in (8, 32, 64))
     assert w8 > 0 and w32 == 4 * w8 and w64 == 8 * w8 and w8 % (8 * 4096 * 4) == 0 and 2 <= w8 // (8 * 4096 * 4) <= 8         # KS <= NH / 4 = 8
+
+
+def test_which_calls_get_the_gemm_image_without_a_gpu(monkeypatch):
+    """pb_linear_forward's only decision left in Python: whether to hand the layer's GEMM image to the native operator.  Checked with
+    the operator, the image build and the device query replaced by stubs: 5 - 64 fp16 rows take a small-batch image by the
+    SMALL_BATCH_IMAGE policy; beyond 64 rows only shapes whose tiles fill the chip (or backend "fused"); never fp32-grid layers, the
+    library backend, bf16 / fp32 activations in the GEMM regime, or fewer than 5 rows"""
+    from pb_llm_amd import _lib
+    from pb_llm_amd.packing import PackedWeight
+
+    calls = []
+
+    class FakeTensor:                      # stands in for x: only what the routing reads
+        def __init__(self, M, K, dtype):
+            self.shape, self.dtype, self.is_cuda, self.device = (M, K), dtype, True, torch.device("cpu")
+
+        def numel(self):
+            return self.shape[0] * self.shape[1]
+
+    def fake_native(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, img, geom, backend, rc):
+        calls.append((x.shape[0], img is not None))
+        return None
+
+    class FakeImage:
+        data, geom_list, ready = object(), [8, 1], None
+
+    built = []
+    monkeypatch.setattr(_lib, "native_linear", lambda: fake_native)
+    monkeypatch.setattr(Q, "_wait_image", lambda stream, image: None)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: None)
+    monkeypatch.setattr(Q, "gemm_image", lambda packed: built.append(1) or FakeImage())
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setitem(Q._CU_COUNT, 0, 256)
+    monkeypatch.setattr(torch.Tensor, "_version", 0, raising=False)
+
+    def pw(N=4096, K=4096):
+        blob = torch.zeros(16, dtype=torch.uint8)
+        return PackedWeight(blob, N, K, (K + 511) // 512, 1, N // 16, 0xE, 8, 0, 0, 0)
+
+    def gets_image(M, dtype=torch.float16, dense_dtype=None, packed=None):
+        packed = packed or pw()
+        calls.clear()
+        Q.pb_linear_forward(packed, None, FakeTensor(M, packed.K, dtype), dense_dtype=dense_dtype)
+        return calls[-1][1]
+
+    monkeypatch.setattr(Q, "GEMM_BACKEND", "auto"); monkeypatch.setattr(Q, "GEMM_KEEP_IMAGE", True)
+    monkeypatch.setattr(Q, "SMALL_BATCH_IMAGE", "auto")
+    assert not gets_image(16) and not gets_image(48) and not built             # "auto": no image yet, none is built for a small batch
+    p = pw()
+    assert gets_image(2048, packed=p) and len(built) == 1                      # prefill at a chip-filling shape builds and keeps it ...
+    assert gets_image(16, packed=p) and gets_image(5, packed=p) and gets_image(64, packed=p) and len(built) == 1   # ... and small batches use it
+    assert not gets_image(4, packed=p)                                         # GEMV passes below 5 rows
+    assert not gets_image(300, packed=p)                                       # 2 x 32 tiles of 128 x 256: the library backend
+    assert not gets_image(16, dense_dtype=torch.float32, packed=p)             # an fp32-grid layer: the image holds fp16 weights
+    assert not gets_image(48, dtype=torch.bfloat16, packed=p)                  # GEMM regime with bf16 x: dense path
+    assert gets_image(8, dtype=torch.float32, packed=p) and not gets_image(2, dtype=torch.float32, packed=p)   # fp32 x = 2 M fp16 rows
+    monkeypatch.setattr(Q, "SMALL_BATCH_IMAGE", "1")
+    assert gets_image(16) and len(built) == 2                                  # "1": built on the first small-batch call
+    monkeypatch.setattr(Q, "SMALL_BATCH_IMAGE", "0")
+    assert not gets_image(16, packed=p) and not gets_image(48, packed=p) and gets_image(2048, packed=p)
+    monkeypatch.setattr(Q, "GEMM_BACKEND", "library")
+    assert not gets_image(2048, packed=p) and not gets_image(48, packed=p)
+    monkeypatch.setattr(Q, "GEMM_BACKEND", "fused"); monkeypatch.setattr(Q, "SMALL_BATCH_IMAGE", "auto")
+    assert gets_image(300, packed=p) and gets_image(48, packed=p)
+    assert gets_image(2048, packed=pw(11008, 4096))                            # "fused" always multiplies from the image ...
+    monkeypatch.setattr(Q, "GEMM_BACKEND", "auto")
+    assert not gets_image(2048, packed=pw(11008, 4096))                        # ... "auto" not at 2.69 rounds of tiles
