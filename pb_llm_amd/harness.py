@@ -223,6 +223,22 @@ def fuse_decode_(model: nn.Module, sets=FUSE_SETS) -> int:
     return n
 
 
+def build_gemm_images_(model: nn.Module) -> tuple[int, int]:
+    """Build and keep the GEMM image of every packed fp16-checkpoint linear of `model` NOW (quant._kept_image), instead of on its
+    first prefill call: afterwards calls with 5 - 64 rows run the small-batch kernel over the image under the default
+    quant.SMALL_BATCH_IMAGE = "auto" -- also inside a hipGraph capture, where an image cannot be built (the build reads two words
+    back).  Costs the images' memory on top of the blobs (1.7 - 2.4 x the blob's bytes).  Returns (layers with an image, bytes)."""
+    from . import quant as Q
+    n = nbytes = 0
+    for m in model.modules():
+        if isinstance(m, Q.PBLinear) and m.weight_dtype == torch.float16 and m.pbl_blob.is_cuda and Q.fused_gemm_ok(m.packed):
+            img = Q._kept_image(m.packed)
+            if img is not None:
+                n += 1
+                nbytes += img.data.numel()
+    return n, nbytes
+
+
 class GraphedForward:
     """One forward of `model` on a fixed input shape captured in a hipGraph (the C ABI launches are asynchronous and
     allocation free; torch's caching allocator serves the temporaries from the graph's private pool).  replay(ids) copies

@@ -493,6 +493,31 @@ def test_small_batch_image_kernel_under_hipgraph_capture(llama7b_qproj):
         Q.SMALL_BATCH_IMAGE = old
 
 
+def test_build_gemm_images_for_a_model_then_small_batches_use_them():
+    """harness.build_gemm_images_: every fp16 packed linear of a module tree gets its image up front; with the default policy
+    ("auto") a batch of 16 rows then runs the small-batch kernel over it -- also when the call is captured first thing"""
+    from pb_llm_amd import harness as H
+    import torch.nn as nn
+    W = synth.llm_weight(512, 1024, seed=3)
+    mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    mk = lambda: Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"])   # noqa: E731
+    model = nn.Sequential(mk(), nn.Sequential(mk())).to(DEV)
+    assert Q.SMALL_BATCH_IMAGE == "auto"
+    x = T(synth.activations((16, 1024), 5, 21))
+    y_rec = model[0](x)
+    assert getattr(model[0].packed, "_gemm_image", None) is None                    # no image yet: the kernel over the records ran
+    n, nbytes = H.build_gemm_images_(model)
+    assert n == 2 and nbytes > 0
+    img = model[0].packed._gemm_image[1]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g), torch.no_grad():
+        y_cap = model[0](x)
+    g.replay(); torch.cuda.synchronize()
+    assert torch.equal(y_cap, Q.small_image_forward(model[0].packed, None, x, img))
+    assert_parity(y_cap, y_rec.float().cpu().numpy().astype(np.float64), 2e-3)
+
+
 def test_misuse_raises():
     W = synth.llm_weight(16, 512, seed=1)
     m = Q.BinaryLinear(torch.from_numpy(W), None).to(DEV)
