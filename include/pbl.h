@@ -353,6 +353,13 @@ size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* geom);
 int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, void* stream);
 int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
                        const uint32_t* geom, void* stream);
+/* The same with the result's type named (PBL_DTYPE_F16 / PBL_DTYPE_F32: exactly the call above) and, for bf16 activations
+ * (qat/run_qat.py:120 `bf16=True`; F.linear(x_bf16, w, b), quant/outlier_quantizer.py:101-106 under bf16 autocast),
+ * PBL_DTYPE_BF16 with tok_scale [M] (device, fp32): x is the fp16 copy pbl_act_bf16_prepare made of the bf16 activations and
+ * y[t, r] = bf16(acc[t, r] * tok_scale[t] + bias[r]) is scaled and cast in the kernel's epilogue.  tok_scale must be NULL for
+ * the other two types. */
+int pbl_gemm_f16_image_ex(const pbl_layer* layer, const void* x, void* y, int M, int out_dtype, const float* tok_scale,
+                          const void* image, size_t image_bytes, const uint32_t* geom, void* stream);
 /* The same product for 1 <= M <= 64 rows of x over the same image (HBM-bound: the image is read once, also for 33 - 64 rows; every
  * wave owns 32 rows of W and a range of 128-column half slabs, K is split over the grid).  workspace: pbl_gemm_small_image_workspace_bytes(layer, M) bytes,
  * 16-byte aligned, any content (the splits' fp32 partial outputs, added in split order by a second small kernel: deterministic);
@@ -361,6 +368,24 @@ int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, in
 size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, int M);
 int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
                             const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream);
+
+/* bf16 activations (round 5; csrc/pbl_act.hip).  The reference's QAT and evaluation run under bf16 (qat/run_qat.py:120; HF LLaMA
+ * checkpoints), i.e. F.linear(x_bf16, w, b).  The packed kernels multiply fp16 tiles with fp32 accumulation; bf16 -> fp16 is exact
+ * inside fp16's range and a token's row may be scaled by a power of two without changing a product's significand:
+ *   pbl_act_bf16_prepare  x [M, K] bf16 (rows ldx elements apart) -> x_f16 [M, K] fp16 contiguous and tok_scale [M] fp32 with
+ *                         x_f16[t, :] = x[t, :] / tok_scale[t], tok_scale[t] = 2^max(0, exponent(amax_t) - 14): exact for every
+ *                         finite bf16 input (what falls under fp16's subnormals is > 2^-38 below the token's maximum).  A token
+ *                         that holds inf / NaN becomes the indicator row (finite -> 0, +-inf -> +-1, NaN -> NaN) with
+ *                         tok_scale[t] = +inf: y = (W . indicator) * inf gives +-inf by the sign of the weight an infinity
+ *                         meets, NaN where that weight is 0 and NaN rows for NaN inputs, as F.linear does (deviation: several
+ *                         infinities in ONE token whose products disagree in sign give +-inf by the weights' sum, not NaN).
+ *   pbl_act_finish        y_out [M, N] (PBL_DTYPE_F32 / _F16 / _BF16) = cast(y_f32[t, r] * tok_scale[t] + bias[r]); tok_scale and
+ *                         bias may be NULL.  Behind the kernels that serve <= 64 rows (they write fp32); the GEMM-regime kernel
+ *                         scales and casts in its own epilogue (pbl_gemm_f16_image_ex).
+ * One small streaming kernel each: no host synchronisation, the same behaviour eagerly and under hipGraph capture. */
+int pbl_act_bf16_prepare(const void* x_bf16, int M, uint32_t K, size_t ldx, void* x_f16, float* tok_scale, void* stream);
+int pbl_act_finish(const float* y_f32, const float* tok_scale, const float* bias, int M, uint32_t N, void* y_out, int out_dtype,
+                   void* stream);
 
 /* Decode-time FUSED projections (q/k/v, gate/up: layers that read the same activation): L layers, ONE x [M, K] (fp16,
  * 16-B aligned rows are not required), ONE output matrix y [M, ldy] in which layer l owns the columns
@@ -470,6 +495,10 @@ int pbl_p2p_allreduce_f32_dev(void* const* peer_bufs, int rank, int world, float
  * rank 0's partial only. */
 int pbl_linear_f16_push(const pbl_layer* layer, const void* x, int M, void* const* peer_bufs, int rank, int world, size_t max_elems,
                         void* stream);
+/* The largest M pbl_linear_f16_push takes for THIS shard (0: never -- column groups).  It depends on the shard's own data
+ * (its fullest record sizes the LDS): the ranks of a K-split layer must agree on ONE limit (the minimum over the ranks) before
+ * they choose between the fused pair and GEMV + all-reduce, or one rank waits on counters while its peer waits on flags. */
+int pbl_linear_push_max_tokens(const pbl_layer* layer);
 int pbl_p2p_reduce_f32_dev(void* const* peer_bufs, int rank, int world, float* y_f32, void* y_f16, size_t n, size_t max_elems,
                            uint32_t expect_records, void* stream);
 

@@ -282,12 +282,13 @@ __global__ __launch_bounds__(1024) void img_scan_kernel(uint32_t* __restrict__ g
 struct ImgArgs {
     pbl_layer L;
     const _Float16* x;      // [M, K]
-    void* y;                // [M, N] fp16 / fp32
+    void* y;                // [M, N] fp16 / fp32 / bf16
     int M, y_f32;
     const uint8_t* slots;   // the image's slots, its record starts, slot tables and level rows
     const uint32_t* rbase;
     const uint32_t* rtab;
     const uint32_t* levels;
+    const float* tok_scale; // OM == 2: [M] fp32, the power of two (or +inf) every token's row of y is multiplied with (pbl_act_bf16_prepare)
 #if PBL_TRACE
     uint64_t* trace;
 #endif
@@ -295,8 +296,19 @@ struct ImgArgs {
 
 struct Frag { v8h a[4], b[2]; };
 
-template <bool Y32, bool KT>
+// fp32 -> bf16 bits, round to nearest even; NaN stays NaN (csrc/pbl_act.hip)
+__device__ __forceinline__ uint32_t bf16_bits(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x0040u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// OM: the result's type -- 0 fp16, 1 fp32 (both exactly round 4's kernel), 2 bf16 with the per-token scale of bf16 activations:
+// y[t, r] = bf16(acc * tok_scale[t] + bias[r]) (round 5: bf16 activations of the reference's perplexity / QAT loops,
+// qat/run_qat.py:120, no longer leave the hand-written kernel for an unpack + library GEMM)
+template <int OM, bool KT>
 __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kernel(ImgArgs a) {
+    constexpr bool Y32 = OM == 1;
     extern __shared__ __attribute__((aligned(16))) char smem_i[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -656,6 +668,8 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
     }
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
+        float sc = 1.f;                                           // OM == 2: this lane's token of the block (tokens >= M are never stored)
+        if constexpr (OM == 2) { const int tok = tok0 + 64 * c + 32 * tt + i32; sc = tok < M ? a.tok_scale[tok] : 0.f; }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -663,15 +677,20 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
                 const int rloc = rt * 32 + 8 * q4 + 4 * g;        // 4 consecutive rows held by this lane: D row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
                 v4f b4 = {0.f, 0.f, 0.f, 0.f};
                 if (L.bias) b4 = *reinterpret_cast<const v4f*>(smem_i + YBIAS + uint32_t(rloc) * 4u);
-                yt h[4];
+                float o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = yt(acc[rt][tt][4 * q4 + r] + b4[r]);
+                for (int r = 0; r < 4; ++r) o[r] = OM == 2 ? __builtin_fmaf(acc[rt][tt][4 * q4 + r], sc, b4[r]) : acc[rt][tt][4 * q4 + r] + b4[r];
                 char* dst = smem_i + uint32_t(64 * c + 32 * tt + i32) * YSTR + uint32_t(rloc) * sizeof(yt);
-                if (Y32) *reinterpret_cast<v4f*>(dst) = v4f{float(h[0]), float(h[1]), float(h[2]), float(h[3])};
+                if (Y32) *reinterpret_cast<v4f*>(dst) = v4f{o[0], o[1], o[2], o[3]};
                 else {
                     uint2 pk;
-                    pk.x = uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[0]))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[1]))) << 16);
-                    pk.y = uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[2]))) | (uint32_t(__builtin_bit_cast(uint16_t, _Float16(h[3]))) << 16);
+                    if constexpr (OM == 2) {
+                        pk.x = bf16_bits(o[0]) | (bf16_bits(o[1]) << 16);
+                        pk.y = bf16_bits(o[2]) | (bf16_bits(o[3]) << 16);
+                    } else {
+                        pk.x = h16(o[0]) | (h16(o[1]) << 16);
+                        pk.y = h16(o[2]) | (h16(o[3]) << 16);
+                    }
                     *reinterpret_cast<uint2*>(dst) = pk;
                 }
             }
@@ -730,7 +749,7 @@ typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;        
 #define PBL_SB_DEPTH 2
 #endif
 #ifndef PBL_SB_WPE
-#define PBL_SB_WPE(NVK_, NTB_) ((NVK_) + (NTB_) <= 4 ? 4 : 3)
+#define PBL_SB_WPE(NVK_, NTB_) ((NTB_) == 1 && (NVK_) <= 3 ? 4 : 3)   // (what the register allocator reaches: 33 - 64 rows hold two accumulator blocks)
 #endif
 #ifndef PBL_SB_NT
 #define PBL_SB_NT 0                  // slot loads with the non-temporal hint (the image is read once)
@@ -1096,30 +1115,41 @@ extern "C" int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom
 }
 
 // y[M, N] = x[M, K] . W^T (+ bias) over an image pbl_gemm_image_build made for THIS layer, with the same geometry words (any
-// M >= 1).  Bit-identical to pbl_gemm_f16_ws / _prepared.
-extern "C" int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
-                                  const uint32_t* geom, void* stream) {
+// M >= 1).  out_dtype: PBL_DTYPE_F16 / PBL_DTYPE_F32 -- bit-identical to pbl_gemm_f16_ws / _prepared -- or PBL_DTYPE_BF16 with
+// tok_scale [M] (device, fp32; pbl_act_bf16_prepare wrote it next to the fp16 copy of the bf16 activations):
+// y[t, r] = bf16(acc[t, r] * tok_scale[t] + bias[r]), scaled and cast in the kernel's epilogue.
+extern "C" int pbl_gemm_f16_image_ex(const pbl_layer* layer, const void* x, void* y, int M, int out_dtype, const float* tok_scale,
+                                     const void* image, size_t image_bytes, const uint32_t* geom, void* stream) {
     if (!layer || !layer->blob || !x || !y || !image || !geom || M < 1) return PBL_ERR_INVALID_ARG;
-    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return PBL_ERR_MISALIGNED;
+    if (out_dtype != PBL_DTYPE_F16 && out_dtype != PBL_DTYPE_F32 && out_dtype != PBL_DTYPE_BF16) return PBL_ERR_INVALID_ARG;
+    if ((out_dtype == PBL_DTYPE_BF16) != (tok_scale != nullptr)) return PBL_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(image) & 15) ||
+        (reinterpret_cast<uintptr_t>(tok_scale) & 3)) return PBL_ERR_MISALIGNED;
     if (!layer_ok(layer)) return PBL_ERR_UNSUPPORTED;
     ImgGeom g;
     if (!make_geom(layer, geom, g)) return PBL_ERR_UNSUPPORTED;
     if (image_bytes < g.total) return PBL_ERR_CAPACITY;
     ImgArgs a;
     const uint8_t* ib = static_cast<const uint8_t*>(image);
-    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32;
+    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = out_dtype == PBL_DTYPE_F32; a.tok_scale = tok_scale;
     a.slots = ib + g.slots_off; a.rbase = reinterpret_cast<const uint32_t*>(ib + sizeof(ImgHeader));
     a.rtab = reinterpret_cast<const uint32_t*>(ib + g.rtab_off); a.levels = reinterpret_cast<const uint32_t*>(ib + g.levels_off);
 #if PBL_TRACE
     a.trace = g_img_trace;
 #endif
     const bool kt = (layer->K & (GI_XC - 1)) != 0;
-    const void* k = y_f32 ? (kt ? reinterpret_cast<const void*>(pbl_gemm_img_kernel<true, true>) : reinterpret_cast<const void*>(pbl_gemm_img_kernel<true, false>))
-                          : (kt ? reinterpret_cast<const void*>(pbl_gemm_img_kernel<false, true>) : reinterpret_cast<const void*>(pbl_gemm_img_kernel<false, false>));
+#define GI_PICK(OM_) (kt ? reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, true>) : reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, false>))
+    const void* k = out_dtype == PBL_DTYPE_F32 ? GI_PICK(1) : (out_dtype == PBL_DTYPE_BF16 ? GI_PICK(2) : GI_PICK(0));
+#undef GI_PICK
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(GI_LDS)) != hipSuccess) return PBL_ERR_LAUNCH;
     void* argv[] = {&a};
     const dim3 grid(((layer->NRB + 7) / 8) * uint32_t((M + GI_TOK - 1) / GI_TOK));
     return hipLaunchKernel(k, grid, dim3((GI_NCONS + GI_NPROD) * GW), argv, GI_LDS, static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+extern "C" int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
+                                  const uint32_t* geom, void* stream) {
+    return pbl_gemm_f16_image_ex(layer, x, y, M, y_f32 ? PBL_DTYPE_F32 : PBL_DTYPE_F16, nullptr, image, image_bytes, geom, stream);
 }
 
 // tuning hook (tools/): the number of waves the small-batch kernel's K split aims at

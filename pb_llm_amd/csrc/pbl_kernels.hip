@@ -385,6 +385,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     // register of a load issued at the top of the same iteration, hipcc waits vmcnt(0) in front of it, and the "two panels
     // ahead" prefetch was in fact one panel deep -- 1 KiB per wave in flight.)
     u32x4 t0 = {0, 0, 0, 0}, t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+    (void)t2;                   // (only the three-set ring uses it)
     uint32_t s_c0 = 0;
     u32x4 s_d4 = {0, 0, 0, 0}, s_q4 = {0, 0, 0, 0};
     uint32_t abl = 0;
@@ -1232,6 +1233,13 @@ int pbl_linear_f16_push(const pbl_layer* layer, const void* x, int M, void* cons
         case 2: return launch_split<2>(M, sf, a, grid, lds, st);
         default: return wpb == 4 ? launch_mb<4>(M, sf, a, grid, lds, st) : launch_mb<1>(M, sf, a, grid, lds, st);
     }
+}
+
+// The largest M pbl_linear_f16_push takes for this shard: route_of's one-pass limit, which follows the shard's fullest record
+// (LDS: x tile + chunk partials).  The ranks of a K-split layer agree on the minimum (pb_llm_amd/parallel.py).
+int pbl_linear_push_max_tokens(const pbl_layer* layer) {
+    if (!layer || layer->G != 1) return 0;
+    return route_of(layer, PBL_MAX_TOKENS_PER_LAUNCH, true).mb_max;
 }
 
 int pbl_unpack_dev(const pbl_layer* layer, void* W_out, int out_f32, void* stream) {

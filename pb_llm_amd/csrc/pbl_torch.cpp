@@ -6,11 +6,13 @@
 //   * decode / small batch (<= 32 rows): pbl_linear_f16_ws (GEMV passes or the matrix-core kernel, routed by the library), or --
 //     from 5 rows, when the caller hands the layer's GEMM image over -- the small-batch kernel over the image
 //     (pbl_gemm_small_image_ws);
-//     bf16 activations as one fp16 pass (exact inside fp16's range; per-token power-of-two scaling outside it, or the dense
-//     path when the range check finds out-of-range / non-finite values), fp32 activations as two fp16 terms;
+//     bf16 activations as one fp16 pass over a per-token power-of-two-scaled copy made ON THE DEVICE (pbl_act_bf16_prepare /
+//     pbl_act_finish, round 5: no host sync, +-inf / NaN as F.linear gives them, the same eagerly and under capture), fp32
+//     activations as two fp16 terms;
 //   * GEMM regime (> 32 rows: prefill, the reference's perplexity loops gptq_pb/eval_ppl_utils.py:55-64): the hand-written
-//     kernel over the layer's GEMM image (pbl_gemm_f16_image) when the caller hands one over, pbl_gemm_f16_ws for
-//     backend "fused", else pbl_unpack_dev + a library GEMM on the transient dense weight;
+//     kernel over the layer's GEMM image (pbl_gemm_f16_image_ex) when the caller hands one over, pbl_gemm_f16_ws otherwise --
+//     for fp16, bf16 AND fp32 activations of every fp16-exact layer (round 5; backends "auto" / "fused"); pbl_unpack_dev + a
+//     library GEMM only for backend "library", for "tuned" without an image, and for fp32-grid layers;
 //   * a Meta kernel (shapes and dtypes without touching a GPU: torch.compile, fake tensors) and an Autograd kernel (the packed
 //     weight is frozen, dx = dy @ W with W re-unpacked in the backward -- what the reference's fake-quant nn.Linear gives
 //     prompt tuning / input-gradient analysis).
@@ -26,6 +28,8 @@
 #include <torch/library.h>
 
 #include <string>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 #include "../../include/pbl.h"
@@ -106,10 +110,30 @@ at::Tensor unpack(const pbl_layer& L, const at::Tensor& like, at::ScalarType dt)
     return W;
 }
 
+// bf16 activations [M, K] -> (fp16 copy scaled per token by a power of two, tok_scale [M]): pbl_act_bf16_prepare, one small kernel,
+// no host synchronisation (csrc/pbl_act.hip)
+std::pair<at::Tensor, at::Tensor> prepare_bf16(const at::Tensor& x2, int64_t M, int64_t K) {
+    const at::Tensor xs = x2.stride(-1) == 1 && x2.stride(0) >= K ? x2 : x2.contiguous();
+    at::Tensor xh = at::empty({M, K}, x2.options().dtype(at::kHalf));
+    at::Tensor sc = at::empty({M}, x2.options().dtype(at::kFloat));
+    check(pbl_act_bf16_prepare(xs.data_ptr(), int(M), uint32_t(K), size_t(xs.stride(0)), xh.data_ptr(), sc.data_ptr<float>(), stream_of(x2)),
+          "act_bf16_prepare");
+    return {xh, sc};
+}
+
+// y_out = cast(y32 * tok_scale[t] + bias[r]) (pbl_act_finish); tok_scale / bias may be undefined
+at::Tensor finish(const at::Tensor& y32, const at::Tensor& tok_scale, const float* bias, int64_t M, int64_t N, at::ScalarType out_dt) {
+    at::Tensor y = at::empty({M, N}, y32.options().dtype(out_dt));
+    const int dt = out_dt == at::kFloat ? PBL_DTYPE_F32 : (out_dt == at::kHalf ? PBL_DTYPE_F16 : PBL_DTYPE_BF16);
+    check(pbl_act_finish(y32.data_ptr<float>(), tok_scale.defined() ? tok_scale.data_ptr<float>() : nullptr, bias, int(M), uint32_t(N), y.data_ptr(), dt,
+                         stream_of(y32)), "act_finish");
+    return y;
+}
+
 at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                        int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
                        const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
-                       bool bf16_range_check) {
+                       bool small_image) {
     TORCH_CHECK(x.is_cuda() && blob.is_cuda(), "pbllm_native.linear: GPU tensors only (the HIP kernels are the only compute path)");
     const auto xt = x.scalar_type();
     TORCH_CHECK(xt == at::kHalf || xt == at::kBFloat16 || xt == at::kFloat, "pbllm_native.linear: fp16, bf16 or fp32 activations");
@@ -133,70 +157,79 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
         iref.data = image->data_ptr(); iref.bytes = size_t(image->numel());
         iref.geom.assign(geom->begin(), geom->end());
     }
+    ImageRef isml;                                         // the image as the small-batch kernel (<= 64 rows) may use it
+    if (small_image) isml = iref;
     auto dense_path = [&](at::ScalarType wdt) {
         const at::Tensor W = unpack(L, x, wdt);
         at::Tensor y = at::linear(x2.to(wdt), W, has_bias ? c10::optional<at::Tensor>(bias->to(wdt)) : c10::nullopt);
         return y.to(out_dt).reshape(shape);
     };
-    if (mok ? rows > MFMA_MAX : M >= GEMM_THRESHOLD) {
-        // GEMM regime.  fp16 weights when the layer is fp16-exact (packed from an fp16 checkpoint) and x is fp16, else fp32.
-        const auto wdt = (xt == at::kHalf && dense_f16) ? at::kHalf : at::kFloat;
-        if (backend != "library" && wdt == at::kHalf && fused_ok(K, G, flags)) {
-            const at::Tensor xc = x2.contiguous();
-            if ((reinterpret_cast<uintptr_t>(xc.data_ptr()) & 15) == 0) {
-                const bool img = bool(iref);
-                if (img || backend == "fused") {
-                    at::Tensor y = at::empty({M, N}, x.options().dtype(out_f32 ? at::kFloat : at::kHalf));
-                    if (img && M <= SMALL_IMAGE_MAX && run_small_image(L, xc, y, M, out_f32, iref)) return y.reshape(shape);   // 33 - 64 rows: one pass over the image
-                    if (img) {
-                        check(pbl_gemm_f16_image(&L, xc.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, iref.data, iref.bytes, iref.geom.data(),
-                                                 stream_of(x)), "gemm_f16_image");
-                    } else {
-                        const size_t nb = pbl_gemm_workspace_bytes(&L, int(M));
-                        at::Tensor ws;
-                        if (nb) ws = at::empty({int64_t(nb)}, x.options().dtype(at::kByte));
-                        check(pbl_gemm_f16_ws(&L, xc.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, nb ? ws.data_ptr() : nullptr, nb, stream_of(x)),
-                              "gemm_f16");
-                    }
-                    return y.reshape(shape);
-                }
-            }
-        }
-        return dense_path(wdt);
-    }
-    if (xt == at::kHalf) return run_small(L, x2.contiguous(), M, out_f32, iref).reshape(shape);
-    if (xt == at::kBFloat16) {
-        // see pb_llm_amd/quant.py (_pb_linear_forward, bf16): range check with one host sync (never under capture) -> dense path
-        // for out-of-range / non-finite inputs; else per-token power-of-two scaling on the device, exact for all finite inputs
-        const bool capturing = c10::hip::currentStreamCaptureStatusMayInitCtx() != c10::hip::CaptureStatus::None;
-        if (bf16_range_check && !capturing) {
-            if (!x2.abs().le(65504.0).all().item<bool>()) return dense_path(at::kFloat);
-            // every value is finite and inside fp16's range: bf16 -> fp16 is exact, no scaling needed (bias in the kernel)
-            return run_small(L, x2.to(at::kHalf).contiguous(), M, true, iref).to(out_dt).reshape(shape);
-        }
-        const at::Tensor xf = x2.to(at::kFloat);
-        const at::Tensor amax = xf.abs().amax({1}, true);
-        const at::Tensor e = amax.view(at::kInt).bitwise_right_shift(23).bitwise_and(0xFF).sub(127 + 14).clamp_min(0);
-        const at::Tensor sc = at::ldexp(at::ones_like(amax), e.neg());
-        at::Tensor y = run_small(Lnb, xf.mul(sc).to(at::kHalf).contiguous(), M, true, iref).div(sc);
-        y = at::where(at::isfinite(amax), y, at::full_like(y, std::numeric_limits<float>::quiet_NaN()));
-        if (has_bias) y = y.add(*bias);
-        return y.to(out_dt).reshape(shape);
-    }
     // fp32 activations: x = x_hi + x_lo with both terms fp16; the kernels are linear in x, so y = W x_hi + W x_lo accumulated in
     // fp32 (bias added once)
-    const at::Tensor x_hi = x2.to(at::kHalf);
-    const at::Tensor x_lo = x2.sub(x_hi.to(at::kFloat)).to(at::kHalf);
-    const at::Tensor yy = run_small(Lnb, at::cat({x_hi, x_lo}, 0).contiguous(), 2 * M, true, iref);
-    at::Tensor y = yy.narrow(0, 0, M).add(yy.narrow(0, M, M));
-    if (has_bias) y = y.add(*bias);
-    return y.to(out_dt).reshape(shape);
+    auto split_f32 = [&]() {
+        const at::Tensor x_hi = x2.to(at::kHalf);
+        const at::Tensor x_lo = x2.sub(x_hi.to(at::kFloat)).to(at::kHalf);
+        return at::cat({x_hi, x_lo}, 0).contiguous();
+    };
+    auto join_f32 = [&](const at::Tensor& yy) {
+        at::Tensor y = yy.narrow(0, 0, M).add(yy.narrow(0, M, M));
+        if (has_bias) y = y.add(*bias);
+        return y.to(out_dt).reshape(shape);
+    };
+    if (mok ? rows > MFMA_MAX : M >= GEMM_THRESHOLD) {
+        // GEMM regime.  Round 5: every layer an fp16 checkpoint is exact for runs on the hand-written kernels whatever the
+        // activation dtype ("auto" / "fused"): fp16 directly, bf16 as its per-token-scaled fp16 copy with the scale and the bf16
+        // cast in the GEMM's epilogue, fp32 as two fp16 terms.  Only fp32-grid layers (the reference's fp32-only module classes,
+        // quant/quantizer.py:78,175) keep the fp32 library GEMM on the unpacked weight: fp16 tiles cannot meet their 2e-5 bar.
+        if (backend != "library" && dense_f16 && fused_ok(K, G, flags)) {
+            at::Tensor xin, tsc;
+            if (xt == at::kHalf) xin = x2.contiguous();
+            else if (xt == at::kBFloat16) std::tie(xin, tsc) = prepare_bf16(x2, M, K);
+            else xin = split_f32();
+            const int64_t R = xin.size(0);
+            const bool img = bool(iref);
+            if ((reinterpret_cast<uintptr_t>(xin.data_ptr()) & 15) == 0 && (img || backend != "tuned")) {
+                // the kernel's own output type: what the caller wants when it can produce it, else fp32 + pbl_act_finish / the join
+                const bool direct = xt == at::kHalf || (xt == at::kBFloat16 && !out_f32 && img && R > SMALL_IMAGE_MAX);
+                const bool k32 = xt == at::kHalf ? out_f32 : !direct;
+                const pbl_layer& Lk = (xt == at::kHalf || direct) ? L : Lnb;     // (bias: in the kernel, or once behind it)
+                at::Tensor y = at::empty({R, N}, x.options().dtype(k32 ? at::kFloat : (xt == at::kBFloat16 ? at::kBFloat16 : at::kHalf)));
+                bool done = false;
+                if (img && R <= SMALL_IMAGE_MAX && small_image) done = run_small_image(Lk, xin, y, R, k32, iref);   // 33 - 64 rows: one pass over the image
+                if (!done && img) {
+                    check(pbl_gemm_f16_image_ex(&Lk, xin.data_ptr(), y.data_ptr(), int(R), k32 ? PBL_DTYPE_F32 : (direct && xt == at::kBFloat16 ? PBL_DTYPE_BF16 : PBL_DTYPE_F16),
+                                                direct && xt == at::kBFloat16 ? tsc.data_ptr<float>() : nullptr, iref.data, iref.bytes, iref.geom.data(), stream_of(x)),
+                          "gemm_f16_image");
+                } else if (!done) {
+                    const size_t nb = pbl_gemm_workspace_bytes(&Lk, int(R));
+                    at::Tensor ws;
+                    if (nb) ws = at::empty({int64_t(nb)}, x.options().dtype(at::kByte));
+                    check(pbl_gemm_f16_ws(&Lk, xin.data_ptr(), y.data_ptr(), int(R), k32 ? 1 : 0, nb ? ws.data_ptr() : nullptr, nb, stream_of(x)), "gemm_f16");
+                }
+                if (xt == at::kHalf || direct) return y.reshape(shape);
+                if (xt == at::kBFloat16) return finish(y, tsc, L.bias, M, N, out_dt).reshape(shape);
+                return join_f32(y);
+            }
+        }
+        return dense_path((xt == at::kHalf && dense_f16) ? at::kHalf : at::kFloat);
+    }
+    if (xt == at::kHalf) return run_small(L, x2.contiguous(), M, out_f32, isml).reshape(shape);
+    if (xt == at::kBFloat16) {
+        // <= 32 rows: prepare (scaled fp16 copy + per-token scale, on the device) -> the packed kernels with an fp32 result ->
+        // scale, bias and cast in pbl_act_finish.  The same three launches eagerly and under stream capture; +-inf / NaN inputs come
+        // out as F.linear's do (csrc/pbl_act.hip).
+        at::Tensor xh, tsc;
+        std::tie(xh, tsc) = prepare_bf16(x2, M, K);
+        const at::Tensor y32 = run_small(Lnb, xh, M, true, isml);
+        return finish(y32, tsc, L.bias, M, N, out_dt).reshape(shape);
+    }
+    return join_f32(run_small(Lnb, split_f32(), 2 * M, true, isml));
 }
 
 at::Tensor linear_meta(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                        int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
                        const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
-                       bool bf16_range_check) {
+                       bool small_image) {
     TORCH_CHECK(x.dim() >= 1 && x.size(-1) == K, "pbllm_native.linear: in_features mismatch: x has ", x.size(-1), ", layer has ", K);
     std::vector<int64_t> shape(x.sizes().begin(), x.sizes().end());
     shape.back() = N;
@@ -209,7 +242,7 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& blob, const c10::optional<at::Tensor>& bias,
                               int64_t N, int64_t K, int64_t P, int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32,
                               bool dense_f16, const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, std::string backend,
-                              bool bf16_range_check) {
+                              bool small_image) {
         ctx->saved_data["blob"] = blob;
         ctx->saved_data["meta"] = std::vector<int64_t>{N, K, P, G, NRB, flags, max_nch, max_nexc};
         ctx->saved_data["xdt"] = int64_t(x.scalar_type());
@@ -218,7 +251,7 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
                              .typed<at::Tensor(const at::Tensor&, const c10::optional<at::Tensor>&, const at::Tensor&, int64_t, int64_t, int64_t, int64_t,
                                                int64_t, int64_t, int64_t, int64_t, bool, bool, const c10::optional<at::Tensor>&,
                                                c10::OptionalArrayRef<int64_t>, c10::string_view, bool)>();
-        return op.call(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, backend, bf16_range_check);
+        return op.call(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, backend, small_image);
     }
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
         const at::Tensor dy = grads[0];
@@ -241,16 +274,16 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
 at::Tensor linear_autograd(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                            int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
                            const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
-                           bool bf16_range_check) {
+                           bool small_image) {
     return PBLinearFn::apply(x, blob, bias, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, std::string(backend),
-                             bf16_range_check);
+                             small_image);
 }
 
 }  // namespace
 
 TORCH_LIBRARY(pbllm_native, m) {
     m.def("linear(Tensor blob, Tensor? bias, Tensor x, int N, int K, int P, int G, int NRB, int flags, int max_nch, int max_nexc, bool out_f32, "
-          "bool dense_f16=True, Tensor? image=None, int[]? geom=None, str backend=\"auto\", bool bf16_range_check=True) -> Tensor");
+          "bool dense_f16=True, Tensor? image=None, int[]? geom=None, str backend=\"auto\", bool small_image=True) -> Tensor");
 }
 TORCH_LIBRARY_IMPL(pbllm_native, CUDA, m) { m.impl("linear", linear_cuda); }
 TORCH_LIBRARY_IMPL(pbllm_native, Meta, m) { m.impl("linear", linear_meta); }

@@ -182,7 +182,9 @@ class P2PAllReduce:
     def fused_linear_(self, packed, bias_f32, x2: torch.Tensor, out: torch.Tensor) -> bool:
         """K-split layer with the push fused into the GEMV's epilogue (pbl_linear_f16_push) + the reduce (pbl_p2p_reduce_f32_dev):
         x2 [M, K_shard] fp16 contiguous, out [M, N] fp16 or fp32 receives the all-reduced result.  False: this call is not one GEMV
-        pass (more than 4 tokens, column groups) -- the caller runs the unfused pair; nothing was launched."""
+        pass (more than 4 tokens, column groups) -- the caller runs the unfused pair; nothing was launched.  EVERY rank must make the
+        same choice for a call (PBLinearKSplit.push_max_tokens is agreed over the group for that reason); a caller of its own keeps M
+        at or under the minimum of pbl_linear_push_max_tokens over the ranks."""
         if self._own is None:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.PblError("P2PAllReduce: run one all-reduce eagerly before capturing (the buffers are mapped on first use)")
@@ -220,6 +222,17 @@ class P2PAllReduce:
         for k, v in list(P2PAllReduce._shared.items()):
             if v[1] is self:
                 del P2PAllReduce._shared[k]
+
+
+def agree_min(value: int, group=None, device=None) -> int:
+    """the minimum of `value` over the ranks of `group` (collective).  The tensor lives where the group's backend wants it:
+    on the GPU for RCCL ("nccl"), on the host for gloo."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(value)
+    on_gpu = "nccl" in str(dist.get_backend(group))
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
 
 
 class PBLinearNSplit(nn.Module):
@@ -263,10 +276,17 @@ class PBLinearKSplit(nn.Module):
         # a timed-out peer wait poisons the output with NaN and sets the communicator's status word; the word is polled
         # (synchronously) every `check_every` eager forwards, so a dead peer surfaces as an exception, not only as NaN logits
         self.check_every, self._calls = 256, 0
-        self.fuse_push = True       # <= 4 fp16 rows: pbl_linear_f16_push + pbl_p2p_reduce_f32_dev instead of GEMV + all-reduce
+        self.fuse_push = True       # <= push_max_tokens fp16 rows: pbl_linear_f16_push + pbl_p2p_reduce_f32_dev instead of GEMV + all-reduce
+        self.push_max_tokens = 0
         if collective == "p2p":
             # ONE communicator per (device, group) for all K-split layers, sized to the largest message
             self.comm = P2PAllReduce.shared(shard.pbl_blob.device, group, max_tokens * shard.out_features)
+            # The fused pair and GEMV + all-reduce wait on DIFFERENT words of the peers' buffers (record counters / flags): every
+            # rank must take the same one for a given M.  How many tokens one push pass takes depends on the rank's OWN shard (its
+            # fullest record sizes the LDS: pbl_linear_push_max_tokens), so the ranks agree on the minimum here, once
+            # (collective: every rank constructs its K-split layers in the same order).
+            self.push_max_tokens = agree_min(_lib.lib().pbl_linear_push_max_tokens(C.byref(shard.packed.layer_struct(None))),
+                                             group, shard.pbl_blob.device)
 
     def local_forward(self, x_local):
         """fp32 partial y of this rank's column slice (bias lives on rank 0 only)."""
@@ -278,7 +298,7 @@ class PBLinearKSplit(nn.Module):
             # decode: ONE GEMV pass whose epilogue pushes the partial to every rank + the reduce (round 4): no all-reduce launch
             # that first reads the partial back from local HBM
             x2 = xl.reshape(-1, xl.shape[-1]).contiguous()
-            if 0 < x2.shape[0] <= _lib.PBL_MAX_TOKENS_PER_LAUNCH:
+            if 0 < x2.shape[0] <= self.push_max_tokens:
                 self._calls += 1
                 if self.check_every and self._calls % self.check_every == 0 and not torch.cuda.is_current_stream_capturing():
                     self.comm.check()

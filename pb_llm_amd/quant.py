@@ -41,22 +41,24 @@ class BinaryInterface:
 # Layers the matrix-core kernel cannot take (odd group sizes, K % 8) switch to the dense path at GEMM_THRESHOLD.
 MFMA_MAX = 32
 GEMM_THRESHOLD = 12
-# GEMM regime backend (rows > 32: prefill).  Two complete implementations; `GEMM_BACKEND` picks:
-#   "auto"     (default since round 4) the hand-written kernel over the layer's GEMM image (pbl_gemm_f16_image,
-#              csrc/pbl_gemm_img.hip) wherever the layer has one, the library backend for the rest (a slot with more than 448
-#              entries -- ~20 % salients --, more than 127 half slabs, odd group sizes).  4096^2 x 2048, low_frac 0.95: 64 - 70 us
-#              against 72.5 for unpack + library and 59.7 for the dense library GEMM (profiles/r04_gemm.md).
-#   "fused"    always hand-written: the image kernel, and pbl_gemm_f16_ws (csrc/pbl_gemm_big.hip, round 3; per-call or kept
-#              salient list) for layers without an image.  Never materialises the dense weight.
+# GEMM regime backend (rows > 32: prefill).  `GEMM_BACKEND` picks:
+#   "auto"     (default) ALWAYS hand-written (round 5): the kernel over the layer's GEMM image (pbl_gemm_f16_image_ex,
+#              csrc/pbl_gemm_img.hip; the image is built on the first call and kept) for every layer that has one, the round-3
+#              kernel (pbl_gemm_f16_ws, csrc/pbl_gemm_big.hip) for the rest (a slot with more than 1216 entries, more than 127
+#              half slabs).  fp16, bf16 (per-token power-of-two scaling on the device, scale + cast in the GEMM's epilogue) and
+#              fp32 (two fp16 terms) activations alike.  Never materialises the dense weight.  "fused" is the same.
+#   "tuned"    round 4's default: the image kernel where its 128 x 256 tiles fill the chip (>= 92 % of the last round of 256
+#              CUs), pbl_unpack_dev + library GEMM elsewhere -- a few per cent faster on shapes with a thin last round
+#              (11008 x 4096 at 2048 rows: 2.69 rounds, 199.7 us hand-written against 190.6; profiles/r04_gemm.md, r05_gemm.md).
 #   "library"  pbl_unpack_dev expands the packed layer into a transient dense buffer (2 B per weight, from the caching
 #              allocator) and a library GEMM runs on it (the default through round 3).
-# fp32 / bf16 activations, an fp32 dense dtype, odd group sizes and K % 8 != 0 always take the library path.
+# Layers that are not fp16-exact (fp32 code grids: the reference's fp32-only classes, quant/quantizer.py:78,175), odd group
+# sizes and K % 8 != 0 always take the library path: fp16 tiles cannot meet the 2e-5 bar of an fp32 F.linear.
 GEMM_BACKEND = os.environ.get("PBL_GEMM_BACKEND", "auto")
-# bf16 activations at <= 32 rows run as ONE fp16 pass (bf16 -> fp16 is exact inside fp16's range).  BF16_RANGE_CHECK (default
-# since round 4): check the range first (one device -> host sync per call, ~10 us) and send out-of-range / non-finite inputs
-# through the dense path, so that large values and inf / NaN behave exactly as in the reference's bf16 F.linear at every token
-# count; off (or under stream capture): per-token power-of-two scaling on the device, exact for all finite inputs (see
-# _pb_linear_forward).
+# bf16 activations (qat/run_qat.py:120; HF LLaMA checkpoints): bf16 -> fp16 is exact inside fp16's range and a token's row may
+# be scaled by a power of two, so every row count runs the packed kernels on a scaled fp16 copy made ON THE DEVICE
+# (pbl_act_bf16_prepare): exact for all finite inputs, +-inf / NaN as F.linear gives them, no host sync -- the same eagerly and
+# under hipGraph capture (round 4's BF16_RANGE_CHECK, one device -> host sync per call, is gone).
 # fused backend: keep each layer's salient list (pbl_gemm_prepare, 4 B per salient entry -- a fifth of the dense weight at 5 %
 # salients, 2.6 GB for a 7B model at 10 %) next to its blob instead of rebuilding it on every call: the perplexity loops call the
 # same linears batch after batch (gptq_pb/eval_ppl_utils.py:55-64).  4096^2 x 2048: 81 us instead of 90 (profiles/r03_gemm.md).
@@ -68,13 +70,12 @@ GEMM_KEEP_IMAGE = os.environ.get("PBL_GEMM_KEEP_IMAGE", "1") == "1"
 # 5 - 64 rows (a small serving batch; BASELINE.json configs[3]): the small-batch kernel over the same image
 # (pbl_gemm_small_image_ws; 13824 x 5120 at 20 % salients and 32 rows: 22 us against 39.5 for the kernel over the packed
 # records, 33 - 64 rows 34 us against 66 for unpack + library).  The image costs memory ON TOP of the blob (1.7 x the blob's bytes
-# at 20 % salients, 2.4 x at 10 %), so by default ("auto") only an image that a prefill call already built is used -- with the
-# default prefill backend that is every layer whose 2048-row tiles fill the chip (q, k, v, o, down of a llama block; not gate /
-# up); "1" builds it on the first small-batch call as well (what `bench.py --workload cfg4` measures), "0" never uses it.
-SMALL_BATCH_IMAGE = os.environ.get("PBL_SMALL_BATCH_IMAGE", "auto")
+# at 20 % salients, 2.4 x at 10 %; 3.4 GB for a 7B model at 10 % -- of 288 GB).  "1" (default since round 5: out of the box a
+# BASELINE configs[3] call runs the fast kernel) builds the image on the first small-batch call, "auto" only uses an image a
+# GEMM-regime call already built, "0" never uses it (the kernel over the packed records runs).
+SMALL_BATCH_IMAGE = os.environ.get("PBL_SMALL_BATCH_IMAGE", "1")
 SMALL_IMAGE_MIN = 5
 SMALL_IMAGE_MAX = 64       # (33 - 64 rows are GEMM regime for everything else; with an image they are one more pass of the small-batch kernel)
-BF16_RANGE_CHECK = os.environ.get("PBL_BF16_RANGE_CHECK", "1") == "1"
 
 
 def fused_gemm_ok(packed: PackedWeight) -> bool:
@@ -86,23 +87,29 @@ def fused_gemm_ok(packed: PackedWeight) -> bool:
 
 
 def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False, workspace: bool = True,
-                       prepared: torch.Tensor | None = None, image: "GemmImage | None" = None) -> torch.Tensor:
+                       prepared: torch.Tensor | None = None, image: "GemmImage | None" = None,
+                       tok_scale: torch.Tensor | None = None) -> torch.Tensor:
     """pbl_gemm_f16_ws: x2 [M, K] fp16 contiguous -> [M, N] fp16 (fp32 with out_f32); raises PblError(UNSUPPORTED) for layers
     it does not take.  workspace: hand the kernel the transient scratch it asks for (more than one 256-token tile: the
     salient entries are decoded once per call by a small kernel ahead of the GEMM; 4 B per entry from the caching allocator,
     stream ordered) -- False decodes inside the GEMM kernel; the results are identical bit for bit.
     prepared: a salient list pbl_gemm_prepare already built for this layer (gemm_list): pbl_gemm_f16_prepared, no per-call
-    preparation."""
+    preparation.  tok_scale (image only; bf16 activations): [M] fp32 from act_bf16_prepare -- the result is
+    bf16(acc * tok_scale[t] + bias), scaled and cast in the kernel's epilogue (pbl_gemm_f16_image_ex)."""
     M = x2.shape[0]
-    y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
     layer = packed.layer_struct(bias_f32)
     L = _lib.lib()
-    if image is not None:                  # pbl_gemm_f16_image: the round-4 kernel over the layer's GEMM image
+    if image is not None:                  # pbl_gemm_f16_image_ex: the round-4 kernel over the layer's GEMM image
         cur = torch.cuda.current_stream(x2.device)
         _wait_image(cur, image)            # (a no-op on the building stream; orders a call from any other stream behind the build)
-        _lib.check(L.pbl_gemm_f16_image(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), image.data.data_ptr(),
-                                        image.data.numel(), image.geom, cur.cuda_stream), "gemm_f16_image")
+        odt = torch.bfloat16 if tok_scale is not None else (torch.float32 if out_f32 else torch.float16)
+        y = torch.empty(M, packed.N, dtype=odt, device=x2.device)
+        code = _lib.PBL_DTYPE_BF16 if tok_scale is not None else (_lib.PBL_DTYPE_F32 if out_f32 else _lib.PBL_DTYPE_F16)
+        _lib.check(L.pbl_gemm_f16_image_ex(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, code,
+                                           tok_scale.data_ptr() if tok_scale is not None else None, image.data.data_ptr(),
+                                           image.data.numel(), image.geom, cur.cuda_stream), "gemm_f16_image")
         return y
+    y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
     if prepared is not None:
         _lib.check(L.pbl_gemm_f16_prepared(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, int(out_f32), prepared.data_ptr(), prepared.numel(),
                                            torch.cuda.current_stream(x2.device).cuda_stream), "gemm_f16_prepared")
@@ -114,12 +121,49 @@ def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32
     return y
 
 
+def act_bf16_prepare(x2: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """pbl_act_bf16_prepare: x2 [M, K] bf16 on the GPU -> (fp16 copy scaled per token by a power of two -- exact --, tok_scale [M]
+    fp32); a token holding inf / NaN becomes its indicator row with scale +inf (csrc/pbl_act.hip).  One small kernel, no host sync."""
+    M, K = x2.shape
+    if x2.stride(1) != 1 or x2.stride(0) < K:
+        x2 = x2.contiguous()
+    xh = torch.empty(M, K, dtype=torch.float16, device=x2.device)
+    sc = torch.empty(M, dtype=torch.float32, device=x2.device)
+    _lib.check(_lib.lib().pbl_act_bf16_prepare(x2.data_ptr(), M, K, x2.stride(0), xh.data_ptr(), sc.data_ptr(),
+                                               torch.cuda.current_stream(x2.device).cuda_stream), "act_bf16_prepare")
+    return xh, sc
+
+
+def act_finish(y32: torch.Tensor, tok_scale: torch.Tensor | None, bias_f32: torch.Tensor | None, out_dtype) -> torch.Tensor:
+    """pbl_act_finish: cast(y32 [M, N] * tok_scale[t] + bias[r]) -> out_dtype (fp32 / fp16 / bf16); one small kernel."""
+    M, N = y32.shape
+    y = torch.empty(M, N, dtype=out_dtype, device=y32.device)
+    code = {torch.float32: _lib.PBL_DTYPE_F32, torch.float16: _lib.PBL_DTYPE_F16, torch.bfloat16: _lib.PBL_DTYPE_BF16}[out_dtype]
+    _lib.check(_lib.lib().pbl_act_finish(y32.data_ptr(), tok_scale.data_ptr() if tok_scale is not None else None,
+                                         bias_f32.data_ptr() if bias_f32 is not None else None, M, N, y.data_ptr(), code,
+                                         torch.cuda.current_stream(y32.device).cuda_stream), "act_finish")
+    return y
+
+
 def _wait_image(stream, image: "GemmImage") -> None:
-    """order this stream behind the image's build.  Not while the stream is being captured into a hipGraph: an event recorded outside
-    the capture cannot be waited for there -- and need not be: the image was built before the capture began (a build reads two words
-    back, which a capture forbids; `_kept_image` never builds under capture), and torch synchronises the device when a capture starts."""
-    if not torch.cuda.is_current_stream_capturing():
-        stream.wait_event(image.ready)
+    """order this stream behind the image's build, and keep the image's memory from being recycled under a reader on another
+    stream.  Not while the stream is being captured into a hipGraph: an event recorded outside the capture cannot be waited for
+    there -- and need not be: the image was built before the capture began (a build reads two words back, which a capture
+    forbids; `_kept_image` never builds under capture), and torch synchronises the device when a capture starts.
+    The building stream needs nothing (stream order), and once the build has completed nobody does (`done`: no wait on every
+    decode call); a reader on ANOTHER stream is recorded with the caching allocator (`record_stream`, once per stream), so that a
+    dropped image -- the blob's version changed -- is not handed out again while that stream still reads it."""
+    if stream.cuda_stream == image.build_stream:
+        return
+    if stream.cuda_stream not in image.readers:
+        image.readers.add(stream.cuda_stream)
+        image.data.record_stream(stream)
+    if image.done or torch.cuda.is_current_stream_capturing():
+        return
+    if image.ready.query():
+        image.done = True
+        return
+    stream.wait_event(image.ready)
 
 
 def small_image_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, image: "GemmImage", out_f32: bool = False) -> torch.Tensor:
@@ -156,12 +200,13 @@ class GemmImage:
     """The per-layer GEMM image of a packed weight (csrc/pbl_gemm_img.hip, pbl_gemm_image_build): what the prefill path and the
     small-batch kernel multiply from.  `data`: uint8 tensor on the blob's device; `geom`: the two geometry words (all slots in
     256-byte units, the largest slot in KiB; host array: it travels with every call); `ready`: an event recorded on the building
-    stream behind the build kernel -- a call from another stream waits on it."""
-    __slots__ = ("data", "geom", "ready", "geom_list")
+    stream behind the build kernel -- a call from another stream waits on it (see _wait_image: `build_stream`, `done`, `readers`)."""
+    __slots__ = ("data", "geom", "ready", "geom_list", "build_stream", "done", "readers")
 
-    def __init__(self, data, geom, ready):
+    def __init__(self, data, geom, ready, build_stream=0):
         self.data, self.geom, self.ready = data, geom, ready
         self.geom_list = list(geom)                      # (the native operator takes an int list)
+        self.build_stream, self.done, self.readers = build_stream, False, set()
 
     @property
     def max_slot_kib(self) -> int:
@@ -171,27 +216,31 @@ class GemmImage:
 def gemm_image(packed: PackedWeight) -> GemmImage | None:
     """Build the layer's GEMM image: pbl_gemm_image_stats (two small kernels + ONE read-back of two words, the only host sync),
     then pbl_gemm_image_build.  None: the layer has no image (K % 8, more than 127 half slabs, odd group size, a slot with more
-    than 1216 entries) -- pbl_gemm_f16_ws serves it."""
+    than 1216 entries -- PBL_ERR_UNSUPPORTED / a zero size) -- pbl_gemm_f16_ws serves it.  Any OTHER status (a failed launch, a
+    misaligned buffer) raises: a genuine failure must not turn into a silent, permanent fallback."""
     layer = packed.layer_struct(None)
     L = _lib.lib()
     dev = packed.blob.device
-    st = torch.cuda.current_stream(dev).cuda_stream
+    cur = torch.cuda.current_stream(dev)
+    st = cur.cuda_stream
     sb = int(L.pbl_gemm_image_stats_bytes(C.byref(layer)))
     if not sb:
         return None
     stats = torch.empty(sb, dtype=torch.uint8, device=dev)
-    if L.pbl_gemm_image_stats(C.byref(layer), stats.data_ptr(), st) != 0:
+    rc = L.pbl_gemm_image_stats(C.byref(layer), stats.data_ptr(), st)
+    if rc == _lib.PBL_ERR_UNSUPPORTED:
         return None
+    _lib.check(rc, "gemm_image_stats")
     g = stats[:8].view(torch.int32).cpu().tolist()
     geom = (C.c_uint32 * 2)(g[0] & 0xFFFFFFFF, g[1] & 0xFFFFFFFF)
     nb = int(L.pbl_gemm_image_bytes(C.byref(layer), geom))
     if not nb:
-        return None
+        return None                                  # (geom[1] == 0xFFFFFFFF: some slot holds more than 1216 entries)
     data = torch.empty(nb, dtype=torch.uint8, device=dev)
     _lib.check(L.pbl_gemm_image_build(C.byref(layer), geom, stats.data_ptr(), data.data_ptr(), nb, st), "gemm_image_build")
     ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    return GemmImage(data, geom, ev)          # (stats is released behind the build kernel: the caching allocator is stream ordered)
+    ev.record(cur)
+    return GemmImage(data, geom, ev, st)      # (stats is released behind the build kernel: the caching allocator is stream ordered)
 
 
 _CU_COUNT: dict = {}
@@ -303,6 +352,30 @@ def _mfma_ok(packed: PackedWeight) -> bool:
             and packed.K % 8 == 0 and bool(packed.flags & _lib.PBL_FLAG_SLABS))
 
 
+def _route_image(packed: PackedWeight, M: int, x_dtype, dense_f16: bool, device) -> "tuple[GemmImage | None, bool]":
+    """Which image a forward of M rows multiplies from, and whether the small-batch kernel (<= 64 rows) may use it -- the ONE
+    place this is decided, for the native operator and the ctypes route alike:
+      * only fp16-exact layers the GEMM-regime kernels take have an image (dense_f16, fused_gemm_ok, GEMM_KEEP_IMAGE);
+      * 5 - 64 kernel rows (fp32 activations count twice: two fp16 terms): the image SMALL_BATCH_IMAGE grants -- "1" builds it here,
+        "auto" only finds one an earlier GEMM-regime call built, "0" none;
+      * beyond 32 rows (GEMM regime), if the small-batch policy granted none: the kept image, built on first use -- always for
+        backends "auto" / "fused", only where the 128 x 256 tiles fill the chip for "tuned", never for "library".
+    An image granted by the second rule only is NOT handed to the small-batch kernel (33 - 64 rows then run the GEMM kernel):
+    SMALL_BATCH_IMAGE = "0" means the small-batch kernel over the image never runs, whatever a prefill call built earlier."""
+    if not (dense_f16 and GEMM_KEEP_IMAGE and fused_gemm_ok(packed)):
+        return None, False
+    rows = 2 * M if x_dtype == torch.float32 else M
+    if rows > MFMA_MAX and GEMM_BACKEND == "library":
+        return None, False
+    if SMALL_IMAGE_MIN <= rows <= SMALL_IMAGE_MAX:
+        ki = _small_batch_image(packed)
+        if ki is not None:
+            return ki, True
+    if rows > MFMA_MAX and (GEMM_BACKEND in ("auto", "fused") or (GEMM_BACKEND == "tuned" and _image_fills_the_chip(packed.N, rows, device))):
+        return _kept_image(packed), False
+    return None, False
+
+
 def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: torch.Tensor,
                       out_f32: bool = False, dense_dtype=None) -> torch.Tensor:
     """y = F.linear(x, w_sim, bias) through libpbl (pbl_linear_f16).  x [..., K] on
@@ -314,25 +387,16 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
             and packed.blob.device == x.device:
         # ONE native call (csrc/pbl_torch.cpp) for every row count and activation dtype: routing, output / workspace allocation,
         # stream lookup, bf16 / fp32 handling, the autograd formula (dx = dy @ W) all live in the operator.  Python only decides
-        # whether the GEMM regime multiplies from the layer's kept GEMM image.
+        # which image (if any) the call multiplies from (_route_image).
         dense_f16 = dense_dtype in (None, torch.float16)
-        img, geom, backend = None, None, GEMM_BACKEND
         M = x.numel() // packed.K
-        rows = 2 * M if x.dtype == torch.float32 else M
-        ki = None
-        if rows > MFMA_MAX:
-            if backend != "library" and x.dtype == torch.float16 and dense_f16 and GEMM_KEEP_IMAGE and fused_gemm_ok(packed):
-                if M <= SMALL_IMAGE_MAX:
-                    ki = _small_batch_image(packed)          # 33 - 64 rows: the small-batch kernel reads the image once for all of them
-                if ki is None and (backend == "fused" or _image_fills_the_chip(packed.N, M, x.device)):
-                    ki = _kept_image(packed)
-        elif rows >= SMALL_IMAGE_MIN and dense_f16:          # (the image holds fp16 weights: layers an fp16 checkpoint is exact for)
-            ki = _small_batch_image(packed)
+        ki, small_ok = _route_image(packed, M, x.dtype, dense_f16, x.device)
+        img = geom = None
         if ki is not None:
             _wait_image(torch.cuda.current_stream(x.device), ki)
             img, geom = ki.data, ki.geom_list
         return nat(packed.blob, bias_f32, x, packed.N, packed.K, packed.P, packed.G, packed.NRB, packed.flags,
-                   packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, geom, backend, BF16_RANGE_CHECK)
+                   packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, geom, GEMM_BACKEND, small_ok)
     # the ctypes route (variant libraries through PBL_LIB, PBL_NATIVE=0, a dispatcher that did not build)
     if torch.is_grad_enabled() and x.requires_grad:
         return _PackedLinearFn.apply(x, (packed, bias_f32), out_f32, dense_dtype)
@@ -365,83 +429,81 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
                                        ws.data_ptr() if ws is not None else None, nb, stream), "linear")
 
     rows = 2 * M if x.dtype == torch.float32 else M     # fp32 x runs as two fp16 terms (bf16 converts exactly)
-    if (rows > MFMA_MAX) if mfma_ok else (M >= GEMM_THRESHOLD):
-        # GEMM regime: dense weight in the workspace + library GEMM, i.e. exactly what the
-        # reference executes (F.linear over the dense fake-quant weight).  fp16 weights when
-        # the layer is fp16-exact (packed from an fp16 checkpoint), else fp32.
-        wdt = torch.float16 if (x.dtype == torch.float16 and dense_dtype in (None, torch.float16)) else torch.float32
-        if GEMM_BACKEND in ("auto", "fused") and wdt == torch.float16 and fused_gemm_ok(packed):
-            xc = x2.contiguous()
-            if xc.data_ptr() % 16 == 0:
-                simg = _small_batch_image(packed) if M <= SMALL_IMAGE_MAX else None       # 33 - 64 rows: one more pass of the small-batch kernel
-                if simg is not None:
-                    return small_image_forward(packed, bias_f32, xc, simg, out_f32).reshape(*lead, packed.N)
-                if GEMM_BACKEND == "fused" or _image_fills_the_chip(packed.N, M, x.device):
-                    img = _kept_image(packed) if GEMM_KEEP_IMAGE else None
-                    if img is not None:
-                        return fused_gemm_forward(packed, bias_f32, xc, out_f32, image=img).reshape(*lead, packed.N)
-                    if GEMM_BACKEND == "fused":
-                        return fused_gemm_forward(packed, bias_f32, xc, out_f32, prepared=_kept_list(packed) if GEMM_KEEP_LIST else None).reshape(*lead, packed.N)
+    dense_f16 = dense_dtype in (None, torch.float16)
+    gemm_regime = (rows > MFMA_MAX) if mfma_ok else (M >= GEMM_THRESHOLD)
+    img, small_ok = _route_image(packed, M, x.dtype, dense_f16, x.device)
+
+    def small(xin, layer_s, bias_s, nrows):
+        """<= 32 (64 over an image) rows of fp16 xin -> fp32 [nrows, N]: the small-batch kernel over the image, or pbl_linear_f16_ws"""
+        if img is not None and small_ok and nrows >= SMALL_IMAGE_MIN and xin.data_ptr() % 16 == 0:
+            return small_image_forward(packed, bias_s, xin, img, True)
+        y = torch.empty(nrows, packed.N, dtype=torch.float32, device=x.device)
+        run(layer_s, xin, y, nrows, True)
+        return y
+
+    def split_f32():
+        # fp32 activations: x = x_hi + x_lo with both terms fp16; the kernels are linear in x, so y = W x_hi + W x_lo accumulated
+        # in fp32 (bias added once)
+        xf = x2.float()
+        x_hi = xf.half()
+        return torch.cat([x_hi, (xf - x_hi.float()).half()], 0).contiguous()
+
+    def join_f32(yy):
+        out = yy[:M] + yy[M:]
+        if bias_f32 is not None:
+            out = out + bias_f32
+        return (out if out_f32 else out.to(x.dtype)).reshape(*lead, packed.N)
+
+    if gemm_regime:
+        # GEMM regime (same routing as csrc/pbl_torch.cpp).  Every fp16-exact layer runs on the hand-written kernels whatever
+        # the activation dtype (backends "auto" / "fused"; "tuned": where an image was granted); fp32-grid layers, "library" and
+        # K % 8 / odd group sizes: dense weight in the workspace + library GEMM, i.e. what the reference executes.
+        if GEMM_BACKEND != "library" and dense_f16 and fused_gemm_ok(packed) and (img is not None or GEMM_BACKEND != "tuned"):
+            tsc = None
+            if x.dtype == torch.float16:
+                xin = x2.contiguous()
+            elif x.dtype == torch.bfloat16:
+                xin, tsc = act_bf16_prepare(x2)
+            else:
+                xin = split_f32()
+            R = xin.shape[0]
+            if xin.data_ptr() % 16 == 0:
+                direct = x.dtype == torch.float16 or (tsc is not None and not out_f32 and img is not None and R > SMALL_IMAGE_MAX)
+                k32 = out_f32 if x.dtype == torch.float16 else not direct
+                bias_k = bias_f32 if (x.dtype == torch.float16 or direct) else None
+                if img is not None and small_ok and R <= SMALL_IMAGE_MAX:
+                    y = small_image_forward(packed, bias_k, xin, img, k32)                # 33 - 64 rows: one more pass of the small-batch kernel
+                elif img is not None:
+                    y = fused_gemm_forward(packed, bias_k, xin, k32, image=img, tok_scale=tsc if direct else None)
+                else:
+                    y = fused_gemm_forward(packed, bias_k, xin, k32, prepared=_kept_list(packed) if GEMM_KEEP_LIST else None)
+                if x.dtype == torch.float16 or direct:
+                    return y.reshape(*lead, packed.N)
+                if tsc is not None:
+                    return act_finish(y, tsc, bias_f32, torch.float32 if out_f32 else x.dtype).reshape(*lead, packed.N)
+                return join_f32(y)
+        wdt = torch.float16 if (x.dtype == torch.float16 and dense_f16) else torch.float32
         W = unpack_on_device(packed, wdt)
         y = torch.nn.functional.linear(x2.to(wdt), W, None if bias_f32 is None else bias_f32.to(wdt))
         y = y.float() if out_f32 else y.to(x.dtype)
         return y.reshape(*lead, packed.N)
     if x.dtype == torch.float16:
         xc = x2.contiguous()
-        simg = _small_batch_image(packed) if M >= SMALL_IMAGE_MIN and xc.data_ptr() % 16 == 0 and dense_dtype in (None, torch.float16) else None
-        if simg is not None:
-            return small_image_forward(packed, bias_f32, xc, simg, out_f32).reshape(*lead, packed.N)
+        if img is not None and small_ok and M >= SMALL_IMAGE_MIN and xc.data_ptr() % 16 == 0:
+            return small_image_forward(packed, bias_f32, xc, img, out_f32).reshape(*lead, packed.N)
         y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x.device)
         run(layer, xc, y, M, out_f32)
         return y.reshape(*lead, packed.N)
     if x.dtype == torch.bfloat16:
-        # bf16 -> fp16 is exact (8 significand bits into 11) inside fp16's range: ONE pass, fp32 accumulation, bf16 result;
-        # magnitudes below 2^-24 round to fp16 subnormals (absolute error < 3e-8).  Outside fp16's range the reference's bf16
-        # F.linear keeps computing (finite values up to 3.4e38) and propagates inf / NaN, and the GEMM regime (33 rows and more)
-        # does the same, so the packed path must not silently saturate:
-        #  * BF16_RANGE_CHECK (default; one device -> host sync per call, ~10 us; impossible under stream capture): inputs with
-        #    an out-of-range or non-finite value take the dense path -- the reference's result whatever the token count;
-        #  * otherwise (PBL_BF16_RANGE_CHECK=0, or while a hipGraph is being captured): every token is scaled by a power of two
-        #    chosen ON THE DEVICE so that its largest magnitude fits fp16 (exact; what falls below fp16's subnormals after the
-        #    scaling is more than 2^-39 below the token's maximum -- under the fp32 accumulation's own resolution) and the result
-        #    is scaled back: all FINITE bf16 inputs are exact; a token holding inf / NaN yields NaN in its whole output row,
-        #    where the reference distinguishes +-inf from NaN by the weights' signs (documented deviation of the sync-free mode).
-        if BF16_RANGE_CHECK and not torch.cuda.is_current_stream_capturing() and not bool((x2.abs() <= 65504.0).all()):
-            W = unpack_on_device(packed, torch.float32)                       # (NaN compares false: caught as well)
-            y = torch.nn.functional.linear(x2.float(), W, bias_f32)
-            return (y if out_f32 else y.to(x.dtype)).reshape(*lead, packed.N)
-        if BF16_RANGE_CHECK and not torch.cuda.is_current_stream_capturing():
-            # checked: every value is finite and inside fp16's range -- bf16 -> fp16 is exact, no scaling needed (bias in the kernel)
-            y = torch.empty(M, packed.N, dtype=torch.float32, device=x.device)
-            run(layer, x2.half().contiguous(), y, M, True)
-            return (y if out_f32 else y.to(x.dtype)).reshape(*lead, packed.N)
-        xf = x2.float()
-        amax = xf.abs().amax(dim=1, keepdim=True)
-        # 2^-e with e = max(0, exponent(amax) - 14): frexp-free, from the fp32 bit pattern (inf / NaN -> exponent 255 -> the
-        # row becomes NaN below)
-        e = ((amax.view(torch.int32) >> 23) & 0xFF) - 127 - 14
-        sc = torch.ldexp(torch.ones_like(amax), -e.clamp_(min=0))
-        xc = (xf * sc).half().contiguous()
-        y = torch.empty(M, packed.N, dtype=torch.float32, device=x.device)
-        run(packed.layer_struct(None), xc, y, M, True)
-        y = y / sc                                                              # exact (power of two); inf rows: 0 * inf = NaN
-        y = torch.where(torch.isfinite(amax), y, torch.full_like(y, float("nan")))
-        if bias_f32 is not None:
-            y = y + bias_f32
-        return (y if out_f32 else y.to(x.dtype)).reshape(*lead, packed.N)
-    # fp32 activations: x = x_hi + x_lo with both terms fp16; the kernel is
-    # linear in x, so y = W x_hi + W x_lo accumulated in fp32 (bias added once).
-    xf = x2.float()
-    x_hi = xf.half()
-    x_lo = (xf - x_hi.float()).half()
-    xx = torch.cat([x_hi, x_lo], 0).contiguous()
-    y = torch.empty(2 * M, packed.N, dtype=torch.float32, device=x.device)
-    layer_nb = packed.layer_struct(None)
-    run(layer_nb, xx, y, 2 * M, True)
-    out = y[:M] + y[M:]
-    if bias_f32 is not None:
-        out = out + bias_f32
-    return (out if out_f32 else out.to(x.dtype)).reshape(*lead, packed.N)
+        # bf16 -> fp16 is exact (8 significand bits into 11) inside fp16's range, and a token's row may be scaled by a power of
+        # two: pbl_act_bf16_prepare makes the scaled fp16 copy and the per-token scale ON THE DEVICE (exact for every finite
+        # input; a token holding inf / NaN becomes its indicator row with scale +inf, so +-inf / NaN come out as F.linear gives
+        # them -- csrc/pbl_act.hip), the packed kernels run once with an fp32 result, pbl_act_finish scales back, adds the bias
+        # and casts.  Three launches, no host sync: the same eagerly and under hipGraph capture.
+        xh, tsc = act_bf16_prepare(x2)
+        y = small(xh, packed.layer_struct(None), None, M)
+        return act_finish(y, tsc, bias_f32, torch.float32 if out_f32 else x.dtype).reshape(*lead, packed.N)
+    return join_f32(small(split_f32(), packed.layer_struct(None), None, 2 * M))
 
 
 # The forward as a registered operator (SURVEY 8(b): "forward-only op ... with a Meta/fake impl so torch.compile /
@@ -569,7 +631,7 @@ class PBLinear(nn.Module, BinaryInterface):
             if _lib.native_linear() is not None:     # the native operator has a Meta kernel: traced as one node
                 return torch.ops.pbllm_native.linear(self.pbl_blob, self.pbl_bias, x, m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch,
                                                      m.max_nexc, False, self.weight_dtype == torch.float16, None, None,
-                                                     "library" if GEMM_BACKEND == "auto" else GEMM_BACKEND, BF16_RANGE_CHECK)
+                                                     "library" if GEMM_BACKEND == "tuned" else GEMM_BACKEND, True)
             return torch.ops.pbllm.linear(self.pbl_blob, self.pbl_bias, x,
                                           [m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch, m.max_nexc, m.nnz, m.nexc],
                                           self.weight_dtype == torch.float16, False)

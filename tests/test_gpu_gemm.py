@@ -17,6 +17,7 @@ from pb_llm_amd import _lib, synth
 from pb_llm_amd import quant as Q
 from pb_llm_amd.packing import pack_dense
 from cfg_shapes import hessian_layer
+from op_trace import LIBRARY_GEMM_OPS, called_ops
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -173,10 +174,18 @@ def test_module_routes_the_gemm_regime_to_the_fused_kernel():
     finally:
         Q.GEMM_BACKEND = old
     assert_parity(y, y_lib.float().cpu().numpy().astype(np.float64), 2e-3)
-    # bf16 activations take the library backend (fp32 dense weight); the result is rounded to bf16 (8 significand bits)
+    # bf16 activations (round 5): the same hand-written kernels on the per-token-scaled fp16 copy, scale + bf16 cast in the GEMM's
+    # epilogue; the result is rounded to bf16 (8 significand bits).  fp32 activations: two fp16 terms through the same kernel.
+    ops = called_ops(lambda: layer(xt.bfloat16()))
+    assert not (ops & LIBRARY_GEMM_OPS), ops
     yb = layer(xt.bfloat16())
     refb = O.dense_linear(xt.bfloat16().float().cpu().numpy().reshape(-1, 1024), Wd, layer.pbl_bias.cpu().numpy()).reshape(3, 40, 512)
     assert yb.dtype == torch.bfloat16 and O.parity_errors(yb.float().cpu().numpy(), refb)[0] < 1e-2
+    assert torch.equal(yb, layer(xt.bfloat16()))
+    yf = layer(xt.float())
+    assert yf.dtype == torch.float32
+    assert_parity(yf, ref, 1e-3)
+    assert not (called_ops(lambda: layer(xt.float())) & LIBRARY_GEMM_OPS)
 
 
 def test_gemm_regime_properties_at_full_size():
@@ -215,13 +224,14 @@ def test_kept_image_and_kept_list_follow_the_blob():
         assert torch.equal(run(x[:40]), ref[:40]) and layer.packed._gemm_list is kept               # one list, any M
         layer.pbl_blob.add_(0)                                                                     # written in place
         assert torch.equal(run(x), ref) and layer.packed._gemm_list[0] != kept[0]
-        # backend "auto" sends a shape whose tiles do not fill the chip (here 8 of 256) to the library: same weights, other
-        # summation order; a chip-filling shape takes the image kernel
-        Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = "auto", False, True
+        # backend "tuned" (round 4's default) sends a shape whose tiles do not fill the chip (here 8 of 256) to the library: same
+        # weights, other summation order; a chip-filling shape takes the image kernel.  "auto" (the default) never does.
+        Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = "tuned", False, True
         assert not Q._image_fills_the_chip(512, 300, DEV) and Q._image_fills_the_chip(4096, 2048, DEV) and not Q._image_fills_the_chip(11008, 2048, DEV)
         assert_parity(layer(x), ref.float().cpu().numpy().astype(np.float64), 2e-3)
         assert getattr(layer.packed, "_gemm_image", None) is None
-        for backend in ("fused",):
+        assert called_ops(lambda: layer(x)) & LIBRARY_GEMM_OPS
+        for backend in ("auto",):
             Q.GEMM_BACKEND, Q.GEMM_KEEP_LIST, Q.GEMM_KEEP_IMAGE = backend, False, True
             assert torch.equal(layer(x), ref)
             kimg = layer.packed._gemm_image

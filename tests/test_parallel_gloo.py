@@ -84,6 +84,16 @@ def _worker(rank, world, port, results):
         # pre-sharded input (output of an N-split layer feeding a K-split layer, Megatron style)
         y2 = PPw.PBLinearKSplit(shard, cols, input_is_sharded=True)(xt[..., cols[0]:cols[1]])
         assert torch.equal(y, y2)
+        # fused-push eligibility (round 5): how many tokens one push pass takes follows the rank's OWN shard; the
+        # ranks must agree on the minimum or one waits on counters while its peer waits on flags
+        assert PPw.agree_min(4 - rank) == 4 - (world - 1)
+        import ctypes as C
+        from pb_llm_amd import _lib
+        ks = PPw.PBLinearKSplit(shard, cols, collective="p2p")
+        own = _lib.lib().pbl_linear_push_max_tokens(C.byref(shard.packed.layer_struct(None)))
+        owns = [None] * world
+        dist.all_gather_object(owns, own)
+        assert 1 <= min(owns) <= 4 and ks.push_max_tokens == min(owns)
         results[rank] = out
     finally:
         dist.destroy_process_group()
@@ -99,3 +109,21 @@ def test_tensor_parallel_world2_gloo():
         for rank in range(world):
             for k, v in results[rank].items():
                 assert v < 1e-3, (rank, k, v)
+
+
+def test_push_limit_depends_on_the_shards_own_data():
+    """pbl_linear_push_max_tokens (= one GEMV pass within the LDS budget) is a function of the shard's width AND of its fullest
+    record: two shards of one layer can answer differently -- which is why PBLinearKSplit agrees on the minimum over the ranks"""
+    import ctypes as C
+    from pb_llm_amd import _lib
+    L = _lib.lib()
+
+    def lim(K, max_nch, NRB=256, G=1):
+        lay = _lib.PblLayer(None, None, NRB * 16, K, (K + 511) // 512, G, NRB, 0xC, max_nch, 0)
+        return L.pbl_linear_push_max_tokens(C.byref(lay))
+
+    assert lim(4096, 420) == 4 and lim(512, 60) == 4
+    a, b = lim(5504, 600), lim(5504, 700)                 # tp2 shards of an 11008-wide layer at ~20 % salients, one a little fuller
+    assert 1 <= b < a <= 4, (a, b)
+    assert lim(4096, 420, G=32) == 0                      # column groups: never fused
+    assert [lim(5504, n) for n in (100, 400, 800, 1600, 3200)] == sorted((lim(5504, n) for n in (100, 400, 800, 1600, 3200)), reverse=True)

@@ -123,10 +123,11 @@ def test_gemm_image_sizing_of_the_c_abi_without_a_gpu():
 
 
 def test_which_calls_get_the_gemm_image_without_a_gpu(monkeypatch):
-    """pb_linear_forward's only decision left in Python: whether to hand the layer's GEMM image to the native operator.  Checked with
-    the operator, the image build and the device query replaced by stubs: 5 - 64 fp16 rows take a small-batch image by the
-    SMALL_BATCH_IMAGE policy; beyond 64 rows only shapes whose tiles fill the chip (or backend "fused"); never fp32-grid layers, the
-    library backend, bf16 / fp32 activations in the GEMM regime, or fewer than 5 rows"""
+    """pb_linear_forward's only decision left in Python (quant._route_image): which image, if any, the native operator multiplies
+    from, and whether the small-batch kernel may use it.  Checked with the operator, the image build and the device query replaced
+    by stubs.  Round 5 policy: backend "auto" is ALWAYS the hand-written kernel -- every fp16-exact layer gets its image in the
+    GEMM regime, whatever the shape and the activation dtype; "tuned" keeps round 4's fills-the-chip rule; 5 - 64 kernel rows take
+    the small-batch kernel by SMALL_BATCH_IMAGE; never fp32-grid layers, the library backend, or fewer than 5 rows"""
     from pb_llm_amd import _lib
     from pb_llm_amd.packing import PackedWeight
 
@@ -139,8 +140,8 @@ def test_which_calls_get_the_gemm_image_without_a_gpu(monkeypatch):
         def numel(self):
             return self.shape[0] * self.shape[1]
 
-    def fake_native(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, img, geom, backend, rc):
-        calls.append((x.shape[0], img is not None))
+    def fake_native(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, img, geom, backend, small_ok):
+        calls.append((x.shape[0], img is not None, small_ok, backend))
         return None
 
     class FakeImage:
@@ -159,31 +160,41 @@ def test_which_calls_get_the_gemm_image_without_a_gpu(monkeypatch):
         blob = torch.zeros(16, dtype=torch.uint8)
         return PackedWeight(blob, N, K, (K + 511) // 512, 1, N // 16, 0xE, 8, 0, 0, 0)
 
-    def gets_image(M, dtype=torch.float16, dense_dtype=None, packed=None):
+    def route(M, dtype=torch.float16, dense_dtype=None, packed=None):
         packed = packed or pw()
         calls.clear()
         Q.pb_linear_forward(packed, None, FakeTensor(M, packed.K, dtype), dense_dtype=dense_dtype)
-        return calls[-1][1]
+        return calls[-1][1], calls[-1][2]          # (image handed over, the small-batch kernel may use it)
 
+    def gets_image(*a, **k):
+        return route(*a, **k)[0]
+
+    assert Q.GEMM_BACKEND == "auto" and Q.SMALL_BATCH_IMAGE == "1"              # the shipped defaults (unless the environment says otherwise)
     monkeypatch.setattr(Q, "GEMM_BACKEND", "auto"); monkeypatch.setattr(Q, "GEMM_KEEP_IMAGE", True)
     monkeypatch.setattr(Q, "SMALL_BATCH_IMAGE", "auto")
-    assert not gets_image(16) and not gets_image(48) and not built             # "auto": no image yet, none is built for a small batch
+    assert not gets_image(16) and not built                                    # small batch "auto": no image yet, none is built for it
+    assert route(48) == (True, False) and len(built) == 1                      # 33 - 64 rows are GEMM regime: the GEMM kernel over a fresh image
     p = pw()
-    assert gets_image(2048, packed=p) and len(built) == 1                      # prefill at a chip-filling shape builds and keeps it ...
-    assert gets_image(16, packed=p) and gets_image(5, packed=p) and gets_image(64, packed=p) and len(built) == 1   # ... and small batches use it
+    assert gets_image(2048, packed=p) and len(built) == 2                      # prefill builds and keeps it ...
+    assert route(16, packed=p) == (True, True) and route(5, packed=p) == (True, True) and route(64, packed=p) == (True, True) and len(built) == 2   # ... and small batches use it
     assert not gets_image(4, packed=p)                                         # GEMV passes below 5 rows
-    assert not gets_image(300, packed=p)                                       # 2 x 32 tiles of 128 x 256: the library backend
-    assert not gets_image(16, dense_dtype=torch.float32, packed=p)             # an fp32-grid layer: the image holds fp16 weights
-    assert not gets_image(48, dtype=torch.bfloat16, packed=p)                  # GEMM regime with bf16 x: dense path
+    assert route(300, packed=p) == (True, False)                               # 2 x 32 tiles of 128 x 256: still hand-written under "auto"
+    assert not gets_image(16, dense_dtype=torch.float32, packed=p) and not gets_image(2048, dense_dtype=torch.float32, packed=p)   # an fp32-grid layer: the image holds fp16 weights
+    assert route(48, dtype=torch.bfloat16, packed=p) == (True, True) and route(2048, dtype=torch.bfloat16, packed=p) == (True, False)   # bf16 x: the same kernels (round 5)
+    assert gets_image(2048, dtype=torch.float32, packed=p)                     # fp32 x: two fp16 terms through the GEMM kernel
     assert gets_image(8, dtype=torch.float32, packed=p) and not gets_image(2, dtype=torch.float32, packed=p)   # fp32 x = 2 M fp16 rows
+    assert gets_image(2048, packed=pw(11008, 4096)) and gets_image(2048, packed=pw(5120, 5120)) and gets_image(2048, packed=pw(13824, 5120)) \
+        and gets_image(2048, packed=pw(5120, 13824))                           # "auto" never leaves the hand-written kernel: gate / up and every llama-13b shape
     monkeypatch.setattr(Q, "SMALL_BATCH_IMAGE", "1")
-    assert gets_image(16) and len(built) == 2                                  # "1": built on the first small-batch call
+    n0 = len(built)
+    assert route(16) == (True, True) and len(built) == n0 + 1                  # "1": built on the first small-batch call
     monkeypatch.setattr(Q, "SMALL_BATCH_IMAGE", "0")
-    assert not gets_image(16, packed=p) and not gets_image(48, packed=p) and gets_image(2048, packed=p)
+    assert not gets_image(16, packed=p) and route(48, packed=p) == (True, False) and gets_image(2048, packed=p)   # "0": the small-batch kernel never runs over the image
     monkeypatch.setattr(Q, "GEMM_BACKEND", "library")
     assert not gets_image(2048, packed=p) and not gets_image(48, packed=p)
     monkeypatch.setattr(Q, "GEMM_BACKEND", "fused"); monkeypatch.setattr(Q, "SMALL_BATCH_IMAGE", "auto")
     assert gets_image(300, packed=p) and gets_image(48, packed=p)
-    assert gets_image(2048, packed=pw(11008, 4096))                            # "fused" always multiplies from the image ...
-    monkeypatch.setattr(Q, "GEMM_BACKEND", "auto")
-    assert not gets_image(2048, packed=pw(11008, 4096))                        # ... "auto" not at 2.69 rounds of tiles
+    assert gets_image(2048, packed=pw(11008, 4096))                            # "fused" = "auto"
+    monkeypatch.setattr(Q, "GEMM_BACKEND", "tuned")                            # round 4's default: the image kernel only where its tiles fill the chip
+    assert gets_image(2048, packed=p) and not gets_image(300, packed=p) and not gets_image(2048, packed=pw(11008, 4096))
+    assert calls[-1][3] == "tuned"

@@ -118,7 +118,7 @@ IMG_SRC = os.path.join(REPO, "pb_llm_amd", "csrc", "pbl_gemm_img.hip")
 
 def img_kernel_bodies(asm):
     out = {}
-    for m in re.finditer(r"^(_ZN\S*pbl_gemm_img_kernelILb[01]ELb[01]E\S*):.*?\n(.*?)\.end_amdhsa_kernel", asm, re.S | re.M):
+    for m in re.finditer(r"^(_ZN\S*pbl_gemm_img_kernelILi[0-9]ELb[01]E\S*):.*?\n(.*?)\.end_amdhsa_kernel", asm, re.S | re.M):
         out[m.group(1)] = m.group(2).split("\n")
     return out
 
@@ -189,8 +189,9 @@ def audit_img(lines):
             return st
         if op == "s_waitcnt" and "vmcnt(0)" in t:
             return {}
-        if a and op == "s_waitcnt" and "vmcnt(10)" in t:
-            return {r: g for r, g in st.items() if g < 10}
+        mw = re.search(r"vmcnt\((\d+)\)", t) if (a and op == "s_waitcnt") else None
+        if mw:                                                  # the step's ONE counted wait (vmcnt(10) in the shipped kernel)
+            return {r: g for r, g in st.items() if g < int(mw.group(1))}
         if op == "s_barrier":
             # the barrier publishes the x pieces issued BEFORE the previous barrier: they must have landed by now (the race the
             # config-3 test found with a wait that was too lax); this step's pieces become "the previous step's"
@@ -241,6 +242,189 @@ def audit_img(lines):
     return problems, nreq
 
 
+# ---- round 5: a generic soundness check of the vector-memory / LDS waits, for the small-batch kernel and every other kernel ------
+# pbl_sb_img_kernel keeps a ring of slot register sets in flight with plain loads (the compiler counts vmcnt: the source shapes the
+# loop so that every path issues the same number of loads) and hands the x tile over at a workgroup barrier (the staging wave's
+# LDS-DMA pieces, the working waves' fragment reads).  Whoever does the counting, the invariants are the same and can be checked on
+# the ISA by forward dataflow over the control-flow graph:
+#   V  no instruction names a VGPR whose vector-memory load may still be in flight.  State {register: age}, age = vector-memory
+#      operations (loads, stores, atomics, LDS-DMA pieces: one vmcnt each, returned in order) issued since the load that writes it;
+#      `s_waitcnt vmcnt(N)` lands everything of age >= N.  A NEW load into a register in flight is fine (in-order return).
+#   D  no LDS-DMA piece (`buffer_load ... lds`) is in flight at an s_barrier: the barrier publishes the tile it writes.
+#   L  no LDS operation of this wave is in flight at an s_barrier (`s_waitcnt lgkmcnt(0)` in front of it): a fragment read that has
+#      not returned may see the NEXT tile, a tile store that has not landed is not there for the others.
+# Joins keep the youngest age (conservative).  `mutate` rewrites one wait of the listing before the walk -- how the tests prove the
+# audit is not vacuous: the vmcnt(13) build of the image kernel and a one-too-lax wait in the small-batch kernel must both be found.
+VMEM = re.compile(r"^(global|buffer|flat|scratch)_(load|store|atomic)")
+
+
+def parse_cfg(lines):
+    ins, label_at = [], {}
+    for l in lines:
+        t = l.strip()
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            label_at[m.group(1)] = len(ins)
+            continue
+        if not t or t[0] in ";." or re.match(r"^\d+:", t):
+            continue
+        if re.match(r"^[a-z_]+[a-z0-9_]*\b", t):
+            ins.append(t.split(";")[0].strip())
+    succ = [[] for _ in ins]
+    for i, t in enumerate(ins):
+        op = t.split()[0]
+        m = re.search(r"(\.LBB\d+_\d+)", t)
+        if op == "s_endpgm":
+            continue
+        if op == "s_branch" and m:
+            succ[i].append(label_at[m.group(1)])
+            continue
+        if op.startswith("s_cbranch") and m:
+            succ[i].append(label_at[m.group(1)])
+        if i + 1 < len(ins):
+            succ[i].append(i + 1)
+    return ins, succ
+
+
+def audit_waits(lines, cap=40, dma_rule=True):
+    """-> (findings, number of vector-memory loads walked).  A finding: (instruction index, text, what).  dma_rule=False: rule D off
+    (pbl_gemm_img_kernel keeps the CURRENT step's pieces in flight across the barrier by design: audit_img checks its own rule)"""
+    ins, succ = parse_cfg(lines)
+    n = len(ins)
+    DMA, LDS = "LDS-DMA piece", "LDS operation"
+
+    def step(i, st):
+        t = ins[i]
+        op = t.split()[0]
+        if VMEM.match(op):
+            st = {r: (min(cap, g + 1) if (r != LDS and not isinstance(r, tuple)) else g) for r, g in st.items()}
+            if "_load" in op and " lds" in t:
+                st[DMA] = 0
+            elif "_load" in op or ("_atomic" in op and " glc" in t or " sc0" in t and "_atomic" in op):
+                for r in regs(t[len(op):].split(",")[0]):
+                    st[r] = 0
+            return st
+        if op.startswith("ds_"):
+            # rule F: LDS operations return in order among themselves; a ds_read's destination is in flight until a
+            # `s_waitcnt lgkmcnt(N)` with N <= (LDS operations issued since).  Scalar loads share the counter and return out of
+            # order, which only makes a wait stricter than this model: a read with `a` younger LDS operations outstanding needs
+            # a + 1 <= N outstanding events.  Keys ("l", register).
+            st = {r: ((min(cap, g + 1)) if isinstance(r, tuple) else g) for r, g in st.items()}
+            st[LDS] = 0
+            if op.startswith("ds_read") or op.startswith("ds_load"):
+                for r in regs(t[len(op):].split(",")[0]):
+                    st[("l", r)] = 0
+            return st
+        if op == "s_waitcnt":
+            mv = re.search(r"vmcnt\((\d+)\)", t)
+            if mv:
+                k = int(mv.group(1))
+                st = {r: g for r, g in st.items() if r == LDS or isinstance(r, tuple) or g < k}
+            ml = re.search(r"lgkmcnt\((\d+)\)", t)
+            if ml:
+                k = int(ml.group(1))
+                st = {r: g for r, g in st.items() if not (isinstance(r, tuple) and g >= k) and not (r == LDS and k == 0)}
+            return st
+        return st
+
+    state = [None] * n
+    state[0] = {}
+    work = [0]
+    while work:
+        i = work.pop()
+        out = step(i, state[i])
+        for j in succ[i]:
+            if state[j] is None:
+                state[j] = dict(out)
+                work.append(j)
+            else:
+                new, changed = dict(state[j]), False
+                for r, g in out.items():
+                    if r not in new or g < new[r]:
+                        new[r] = g
+                        changed = True
+                if changed:
+                    state[j] = new
+                    work.append(j)
+    findings, nloads = [], 0
+    for i, t in enumerate(ins):
+        if state[i] is None:
+            continue
+        op = t.split()[0]
+        st = state[i]
+        if op == "s_barrier":
+            for key in ((DMA, LDS) if dma_rule else (LDS,)):
+                if key in st:
+                    findings.append((i, t, f"{key} in flight at the barrier"))
+            continue
+        if op == "s_waitcnt":
+            continue
+        named_v = named_l = regs(t)
+        if VMEM.match(op) and "_load" in op and " lds" not in t:
+            nloads += 1
+            named_v = regs(",".join(t[len(op):].split(",")[1:]))                 # a NEW vector-memory load into a register whose load is in flight
+        elif op.startswith("ds_read") or op.startswith("ds_load"):               # is fine (in-order return), likewise a new ds_read over a ds_read;
+            named_l = regs(",".join(t[len(op):].split(",")[1:]))                 # ACROSS the two pipes it is a write-after-write hazard
+        bad = sorted(r for r in named_v if r in st)
+        badl = sorted(r for r in named_l if ("l", r) in st)
+        if bad:
+            findings.append((i, t, f"touches v{bad} in flight"))
+        if badl:
+            findings.append((i, t, f"touches v{badl} whose ds_read is in flight"))
+    return findings, nloads
+
+
+def kernel_bodies_named(asm, pattern):
+    out = {}
+    for m in re.finditer(r"^(_Z\S*" + pattern + r"\S*):.*?\n(.*?)\.end_amdhsa_kernel", asm, re.S | re.M):
+        out[m.group(1)] = m.group(2).split("\n")
+    return out
+
+
+_ASM_CACHE = {}
+
+
+def compile_asm(src):
+    if src not in _ASM_CACHE:
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            subprocess.check_call([HIPCC, "-std=c++17", "-O3", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", out],
+                                  stderr=subprocess.DEVNULL)
+            _ASM_CACHE[src] = open(out).read()
+    return _ASM_CACHE[src]
+
+
+def mutate_wait(lines, which, delta=1, counter="vmcnt", only_in_loop=True):
+    """a copy of the listing with the `which`-th counted wait (counter(N), N >= 1 when `delta` > 0) made `delta` laxer; None when
+    there are fewer such waits"""
+    idx = [i for i, l in enumerate(lines) if re.search(r"s_waitcnt.*" + counter + r"\((\d+)\)", l) and
+           (delta < 0 or int(re.search(counter + r"\((\d+)\)", l).group(1)) >= 1)]
+    if which >= len(idx):
+        return None
+    out = list(lines)
+    i = idx[which]
+    out[i] = re.sub(counter + r"\((\d+)\)", lambda m: f"{counter}({int(m.group(1)) + delta})", out[i], count=1)
+    return out
+
+
+def main_waits(src=None, pattern="pbl_sb_img_kernel", verbose=True, dma_rule=True):
+    """audit_waits over every kernel of `src` whose mangled name contains `pattern`; 0 = clean"""
+    asm = compile_asm(src or IMG_SRC)
+    bodies = kernel_bodies_named(asm, pattern)
+    if not bodies:
+        print(f"no kernel matching {pattern} in the assembly")
+        return 1
+    rc = 0
+    for name, lines in sorted(bodies.items()):
+        findings, nloads = audit_waits(lines, dma_rule=dma_rule)
+        if verbose:
+            print(f"{name[:70]}...: {nloads} vector-memory loads walked, {len(findings)} findings")
+        for f in findings[:20]:
+            print("   ", f)
+            rc = 1
+    return rc
+
+
 def main_img():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
@@ -282,4 +466,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main() | main_img())
+    sys.exit(main() | main_img() | main_waits() | main_waits(pattern="pbl_gemm_img_kernel", dma_rule=False))
