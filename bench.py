@@ -18,12 +18,17 @@ uint8 code and 8-bit index per salient + row params + row pointers + fp16 x and 
 --gpus N > 1 (BASELINE configs[4]): the SAME L layers are sharded over N ranks with the
 LLaMA tensor-parallel mapping -- layer i plays role i % 7 of a decoder layer: q, k, v, gate, up are
 N-split (each rank owns a slice of the output rows, no exchange), o and down are K-split (each rank
-owns a slice of the input columns; the fp32 partial outputs of the K-split layers are summed by one
-all-reduce per K-split layer -- 64 per step, as a decoder runs them; --tp-collectives stacked: ONE for all of them --:
-RCCL, or the library's one-shot peer-to-peer all-reduce with --collective p2p).
-Total work is fixed: strong scaling.  `--parallel dp` keeps round 1's independent streams per rank.
-Run directly, `bench.py --gpus N` starts the N ranks itself (torch.distributed.run); started by
-torch.distributed.run it checks WORLD_SIZE == N.
+owns a slice of the input columns; the fp32 partial outputs of the K-split layers are summed over the
+ranks -- 64 dependent exchanges per step, as a decoder runs them).  Round 5 defaults (`--collective auto
+--tp-collectives fused --tp-graph 1`): every K-split layer is ONE GEMV whose epilogue pushes the partial
+straight into every peer's buffer over xGMI + a reduce kernel (libpbl's peer-to-peer path), the whole step
+(N-split launch + 64 x [push GEMV + reduce]) captured in one hipGraph; validated against an RCCL all-reduce
+of the same partials before anything is timed, with an automatic, group-wide fallback -- fused -> p2p
+all-reduce per layer -> RCCL per layer -- if the peer mapping, the validation or the capture fails.  The
+RCCL per-layer path `north_star` names is ALSO timed (outside the K steps the line reports) and printed in
+the same JSON line as `rccl_per_layer_baseline`.  Total work is fixed: strong scaling.  `--parallel dp`
+keeps round 1's independent streams per rank.  Run directly, `bench.py --gpus N` starts the N ranks itself
+(torch.distributed.run); started by torch.distributed.run it checks WORLD_SIZE == N.
 
 Clock pre-heat: a cold MI355X needs ~1 s of load before its clocks settle (20 timed steps are 6 ms);
 the SAME launch is therefore repeated for --preheat-s seconds (default 2.0, reported as `preheat_s`)
@@ -171,9 +176,12 @@ def run_side_workload(a):
             base = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
             for _ in range(6):                                                    # 6 device copies each: beyond the Infinity Cache
                 layers.append(Q.PBLinear(base.packed.to(dev), None))
-    Q.GEMM_BACKEND = a.gemm_backend
-    if a.workload == "cfg4":
-        Q.SMALL_BATCH_IMAGE = a.small_batch_image        # "1": the small-batch kernel over the layers' GEMM images (built on first use)
+    if a.gemm_backend != "default":
+        Q.GEMM_BACKEND = a.gemm_backend
+    a.gemm_backend = Q.GEMM_BACKEND                      # (what ran: reported in the line)
+    if a.workload == "cfg4" and a.small_batch_image != "default":
+        Q.SMALL_BATCH_IMAGE = a.small_batch_image
+    a.small_batch_image = Q.SMALL_BATCH_IMAGE
     xs = {K: torch.from_numpy(synth.activations((M, K), 3, 21)).to(dev) for K in {l.in_features for l in layers}}
     alg = sum(l.packed.algorithmic_bytes(M) for l in layers)
 
@@ -202,7 +210,7 @@ def run_side_workload(a):
         roof = {"bound": "mfma", "achieved": flops / dev_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "traffic": None,
                 "kernel": ("pbl_unpack_kernel + library GEMM" if a.gemm_backend == "library" else
                            f"pbl_gemm_img_kernel ({n_img} of {len(layers)} layers have a GEMM image; the rest: " +
-                           ("pbl_gemm_kernel)" if a.gemm_backend == "fused" else "pbl_unpack_kernel + library GEMM)")),
+                           ("pbl_gemm_kernel)" if a.gemm_backend in ("fused", "auto") else "pbl_unpack_kernel + library GEMM)")),
                 "us_per_step": 1e6 * dev_s}
         value, unit = M / (32 * wall / a.steps), "tokens/s (linears of a 32-layer stack)"
         work = "llama-7b decoder-layer linears (q,k,v,o 4096x4096; gate,up 11008x4096; down 4096x11008), low_frac 0.95 hessian, M=2048"
@@ -250,20 +258,26 @@ def main():
                     help="auto: tp when --gpus > 1; tp: LLaMA tensor-parallel mapping of the layer stream + one "
                          "all-reduce of the K-split partial outputs per step (strong scaling); dp: independent "
                          "layer streams per rank (weak scaling, no collective)")
-    ap.add_argument("--collective", choices=["rccl", "p2p"], default="rccl",
-                    help="tp all-reduce: RCCL (torch.distributed) or libpbl's one-shot peer-to-peer all-reduce")
-    ap.add_argument("--tp-collectives", choices=["per-layer", "stacked", "fused"], default="per-layer",
-                    help="tp: per-layer = one all-reduce of [M, N] fp32 per K-split layer (64 per step, 16 KB each at M = 1: what a "
-                         "decoder executes); stacked = ONE all-reduce of all K-split partials per step (the easy case)")
-    ap.add_argument("--small-batch-image", choices=["auto", "0", "1"], default="1",
-                    help="cfg4: 1 = the small-batch kernel over the layers' GEMM images (built on the first call; 2.5 x the blob's bytes at "
-                         "20 %% salients), 0 = the kernel over the packed records, auto = the library default (an image only if a prefill call built one)")
+    ap.add_argument("--collective", choices=["auto", "rccl", "p2p"], default="auto",
+                    help="tp exchange: auto (default) = libpbl's peer-to-peer path over IPC-mapped buffers, RCCL if the mapping or its "
+                         "validation fails on any rank; p2p = the same without the fallback; rccl = torch.distributed all_reduce")
+    ap.add_argument("--tp-collectives", choices=["per-layer", "stacked", "fused"], default="fused",
+                    help="tp: fused (default) = every K-split layer is ONE GEMV whose epilogue pushes the partial to every rank + a reduce "
+                         "kernel (p2p only; falls back to per-layer); per-layer = GEMV launch + one all-reduce of [M, N] fp32 per K-split "
+                         "layer (64 per step, 16 KB each at M = 1); stacked = ONE all-reduce of all K-split partials per step (the easy case)")
+    ap.add_argument("--tp-graph", type=int, choices=[0, 1], default=1,
+                    help="tp fused: capture the whole step (N-split launch + 64 x [push GEMV + reduce]) in one hipGraph and replay it")
+    ap.add_argument("--small-batch-image", choices=["default", "auto", "0", "1"], default="default",
+                    help="cfg4: default = the library's own setting (quant.SMALL_BATCH_IMAGE, \"1\" since round 5: the small-batch kernel over the "
+                         "layers' GEMM images, built on the first call; 1.7 x the blob's bytes at 20 %% salients); 0 = the kernel over the packed "
+                         "records; auto = an image only if a prefill call built one")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
                     help="cfg2 = BASELINE configs[1], the headline GEMV stream (default, what the driver runs); cfg3 / cfg4: "
                          "configs[2] / configs[3] as side lines (see run_side_workload)")
-    ap.add_argument("--gemm-backend", choices=["auto", "library", "fused"], default="auto",
-                    help="cfg3: quant.GEMM_BACKEND -- auto (default): the hand-written kernel over each layer's GEMM image "
-                         "(pbl_gemm_f16_image), library for layers without one; library: pbl_unpack_dev + library GEMM")
+    ap.add_argument("--gemm-backend", choices=["default", "auto", "tuned", "library", "fused"], default="default",
+                    help="cfg3: quant.GEMM_BACKEND -- default = the library's own setting (\"auto\": always the hand-written kernel over each "
+                         "layer's GEMM image, round 5); tuned = round 4's routing (library GEMM where the 128 x 256 tiles leave a thin last "
+                         "round); library: pbl_unpack_dev + library GEMM")
     a = ap.parse_args()
     if a.workload != "cfg2":
         assert a.gpus == 1, "side workloads are single-GPU lines"
@@ -329,10 +343,6 @@ def main():
         for t, i in zip(gk.x, k_ids):
             t.copy_(torch.from_numpy(np.ascontiguousarray(xs_host[i][:, c0:c1])))
         groups = [(gn, False), (gk, True)]
-        comm = None
-        if a.collective == "p2p":
-            from pb_llm_amd.parallel import P2PAllReduce
-            comm = P2PAllReduce(gk.y_all.numel(), dev)
     else:
         full = [pack_slice(b) for b in base]
         packed = [full[i % a.distinct].to(dev) for i in range(a.layers)]
@@ -347,57 +357,145 @@ def main():
     singles = None
     if a.mode != "grouped":
         singles = [(PBLinear(p, None), x) for g, _ in groups for p, x in zip(g.packed, g.x)]
-    kev = []            # (start, end) events around the GEMV launches of a step (tp only: the timed region also holds the collective)
+    kev = []            # (start, end) events around the GEMV launches of a step (tp, eager: the timed region also holds the collective)
 
-    fused_tp = tp and a.tp_collectives == "fused" and comm is not None
-    if fused_tp:   # every K-split layer as its own push GEMV + reduce (pbl_linear_f16_push / pbl_p2p_reduce_f32_dev), as a decoder runs them
-        gkq = groups[1][0]
-        yk16 = [torch.empty(a.M, a.N, dtype=torch.float16, device=dev) for _ in gkq.packed]
+    # ---- tensor parallel: which exchange runs.  Decided ONCE, group-wide (every rank must take the same path: the fused pair, the
+    # p2p all-reduce and RCCL wait on different things), validated against the baseline collective before anything is timed.
+    comm, tp_path, tp_notes = None, None, []
+
+    def base_all_reduce(t):
+        """the baseline collective north_star names: RCCL on a node; in plumbing mode (ranks share a device, gloo) through the host"""
+        if backend == "nccl":
+            dist.all_reduce(t)
+        else:
+            c = t.cpu()
+            dist.all_reduce(c)
+            t.copy_(c)
+
+    if tp:
+        import ctypes as C
+        from pb_llm_amd import _lib
+        from pb_llm_amd.parallel import P2PAllReduce, agree_min
+        gn, gk = groups[0][0], groups[1][0]
+        yk16 = [torch.empty(a.M, a.N, dtype=torch.float16, device=dev) for _ in gk.packed]
+        if a.collective in ("auto", "p2p"):
+            try:
+                comm = P2PAllReduce(gk.y_all.numel(), dev)       # collective: raises on EVERY rank if any rank cannot map its peers
+            except _lib.PblError as e:
+                if a.collective == "p2p":
+                    raise
+                tp_notes.append(f"p2p unavailable ({e}); RCCL")
+        want = a.tp_collectives
+        if comm is None and want == "fused":
+            want = "per-layer"
+        if want == "fused":
+            lim = min(_lib.lib().pbl_linear_push_max_tokens(C.byref(p.layer_struct(None))) for p in gk.packed)
+            if agree_min(lim, None, dev) < a.M:                  # one GEMV pass on every rank, or not fused at all
+                tp_notes.append(f"fused push takes {lim} tokens per pass here, M = {a.M}: per-layer")
+                want = "per-layer"
+
+        def step_tp(path, record=False):
+            """one step on `path`: 'fused' | 'p2p-per-layer' | 'p2p-stacked' | 'rccl-per-layer' | 'rccl-stacked'"""
+            if record:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            gn.launch()
+            if path == "fused":
+                if record:
+                    e1.record()
+                    kev.append((e0, e1))
+                for pk, xk, yk in zip(gk.packed, gk.x, yk16):
+                    if not comm.fused_linear_(pk, None, xk, yk):
+                        raise SystemExit("--tp-collectives fused: the K-split shard is not one GEMV pass")
+                return
+            gk.launch()
+            if record:
+                e1.record()
+                kev.append((e0, e1))
+            parts = gk.y if path.endswith("per-layer") else [gk.y_all]
+            for t in parts:
+                if path.startswith("p2p"):
+                    comm.all_reduce_(t)
+                else:
+                    base_all_reduce(t)
+
+        # reference sums through the baseline collective, once
+        gk.launch()
+        ref = gk.y_all.clone()
+        base_all_reduce(ref)
+        torch.cuda.synchronize()
+
+        def valid(path):
+            """does `path` reproduce the baseline collective's sums on every rank?  (collective; never raises on one rank only)"""
+            ok = 1
+            try:
+                for _ in range(3):                               # more calls than slot sets
+                    step_tp(path)
+                torch.cuda.synchronize()
+                if path == "fused":
+                    got = torch.cat([y.reshape(-1).float() for y in yk16])
+                    tol = 2e-3 * float(ref.abs().max())          # fp16 outputs
+                else:
+                    got, tol = gk.y_all.float(), 1e-5 * float(ref.abs().max())
+                err = float((got - ref).abs().max())
+                ok = int(err == err and err <= tol)
+                if comm is not None:
+                    comm.check()
+            except (_lib.PblError, RuntimeError) as e:
+                tp_notes.append(f"{path}: {str(e)[:120]}")
+                ok = 0
+            return bool(agree_min(ok, None, dev))
+
+        chain = (["fused"] if want == "fused" else []) + ([f"p2p-{want if want != 'fused' else 'per-layer'}"] if comm is not None else []) \
+            + [f"rccl-{want if want != 'fused' else 'per-layer'}"]
+        for cand in chain:
+            if cand.startswith("rccl") or valid(cand):
+                tp_path = cand
+                break
+            tp_notes.append(f"{cand} failed its validation against the baseline collective: falling back")
+
+    fused_tp = tp_path == "fused"
 
     def step(record=False):
-        if fused_tp:
-            if record:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            groups[0][0].launch()
-            if record:
-                e1.record()
-                kev.append((e0, e1))
-            for pk, xk, yk in zip(gkq.packed, gkq.x, yk16):
-                if not comm.fused_linear_(pk, None, xk, yk):
-                    raise SystemExit("--tp-collectives fused: the K-split shard is not one GEMV pass")
-            return
+        if tp:
+            return step_tp(tp_path, record)
         if a.mode == "grouped":
-            if record:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
             for g, _ in groups:
                 g.launch()
-            if record:
-                e1.record()
-                kev.append((e0, e1))
-            if tp:
-                gk = groups[1][0]
-                parts = gk.y if a.tp_collectives == "per-layer" else [gk.y_all]
-                for t in parts:
-                    if comm is not None:
-                        comm.all_reduce_(t)
-                    else:
-                        dist.all_reduce(t)
         else:
             for m, x in singles:
                 m(x)
 
-    graph = None
-    if a.mode == "graph":
-        s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
-            step()
+    def capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            fn()
+        return gr
+
+    graph = None
+    tp_graphed = False
+    if a.mode == "graph" and not tp:
+        graph = capture(step)
         run = graph.replay
+    elif fused_tp and a.tp_graph:
+        # the whole step in ONE hipGraph: the call number of the push / reduce pair lives in the peers' buffers, so a replay advances
+        # it like an eager call.  A failed capture is agreed over the group (all ranks replay, or all ranks launch eagerly).
+        ok = 1
+        try:
+            graph = capture(step)
+        except (RuntimeError, _lib.PblError) as e:
+            tp_notes.append(f"hipGraph capture of the fused step failed ({str(e)[:100]}): eager launches")
+            ok, graph = 0, None
+        if agree_min(ok, None, dev) and graph is not None:
+            run, tp_graphed = graph.replay, True
+        else:
+            run = step
     else:
         run = step
 
@@ -423,33 +521,64 @@ def main():
             break
     preheat_s = time.perf_counter() - t_pre if a.preheat_s > 0 else 0.0
 
-    for _ in range(a.warmup):
-        run()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
+    def timed(run_fn, record):
+        """W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; max over the ranks"""
+        kev.clear()
+        for _ in range(a.warmup):
+            run_fn()
         torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    rec = tp and a.mode == "grouped"
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(a.steps):
-        if rec:
-            step(True)
-        else:
-            run()
-    e1.record()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(a.steps):
+            if record:
+                step(True)
+            else:
+                run_fn()
+        e1.record()
         torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev_s = e0.elapsed_time(e1) * 1e-3
-    kern_s = sum(s.elapsed_time(e) for s, e in kev) * 1e-3 if kev else dev_s
-    if use_dist:
-        tt = torch.tensor([wall, dev_s, kern_s], device=ctl, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, dev_s, kern_s = tt.tolist()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+        wall_ = time.perf_counter() - t0
+        dev_ = e0.elapsed_time(e1) * 1e-3
+        kern_ = sum(s_.elapsed_time(e_) for s_, e_ in kev) * 1e-3 if kev else dev_
+        if use_dist:
+            tt = torch.tensor([wall_, dev_, kern_], device=ctl, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall_, dev_, kern_ = tt.tolist()
+        return wall_, dev_, kern_
+
+    rec = tp and not tp_graphed
+    wall, dev_s, kern_s = timed(run, rec)
+    tp_valid_after = None
+    if tp and comm is not None and tp_path != "rccl-per-layer" and not tp_path.startswith("rccl"):
+        # a peer wait that timed out poisons the sums with NaN and sets the buffer's status word: the number above would describe a
+        # broken exchange.  Agreed over the group; the line then carries the RCCL measurement instead and says so.
+        ok = 1
+        try:
+            comm.check()
+        except _lib.PblError as e:
+            tp_notes.append(str(e)[:120])
+            ok = 0
+        tp_valid_after = bool(agree_min(ok, None, dev))
+    rccl_base = None
+    if tp and (tp_path != "rccl-per-layer") and (backend == "nccl" or os.environ.get("PBL_BENCH_BASELINE") == "1"):
+        # the baseline north_star names, timed the same way OUTSIDE the K steps reported above: GEMV launches + one RCCL all-reduce per
+        # K-split layer (64 eager 16 KB collectives per step)
+        main_path, tp_path = tp_path, "rccl-per-layer"
+        bw, bd, bk = timed(step, True)
+        tp_path = main_path
+        rccl_base = {"value": a.layers * a.M * a.steps / bw, "unit": "layer-tokens/s", "ms_per_step": 1e3 * bw / a.steps,
+                     "us_per_step_device": 1e6 * bd / a.steps, "collective_us_per_step": 1e6 * (bd - bk) / a.steps,
+                     "what": f"grouped GEMV launches + {len(groups[1][0].packed)} torch.distributed all_reduce calls of [{a.M},{a.N}] fp32 per step "
+                             f"({'RCCL' if backend == 'nccl' else 'gloo through the host: plumbing only'}), eager"}
+        if tp_valid_after is False:
+            tp_notes.append(f"{main_path} reported a timed-out peer wait: the line carries the RCCL per-layer measurement")
+            wall, dev_s, kern_s, tp_path, tp_graphed = bw, bd, bk, "rccl-per-layer", False
 
     traffic, traffic_source = None, None
     key = f"N{a.N}_K{a.K}_L{a.layers}_M{a.M}_lf{a.low_frac}_{a.mode}"
@@ -476,10 +605,11 @@ def main():
             sus_us = 1e3 * sum(late) / sus_n
         if tp:
             nk = len(groups[1][0].packed)
-            coll = 'libpbl one-shot p2p' if a.collective == 'p2p' else 'RCCL'
+            coll = 'libpbl one-shot p2p' if tp_path.startswith('p2p') else ('RCCL' if backend == 'nccl' else 'gloo (plumbing run: ranks share a device)')
             par = (f"tp{world}: llama mapping, q/k/v/gate/up N-split (no exchange), o/down K-split + " +
-                   (f"{nk} fused K-split layers per step (GEMV epilogue pushes the partial to every rank + reduce kernel)" if a.tp_collectives == "fused" else
-                    f"{nk} {coll} all-reduces of [{a.M},{a.N}] fp32 per step (one per K-split layer)" if a.tp_collectives == "per-layer"
+                   (f"{nk} fused K-split layers per step (GEMV epilogue pushes the partial to every rank over peer-mapped buffers + reduce kernel)"
+                    + (", the whole step replayed as ONE hipGraph" if tp_graphed else ", eager launches") if tp_path == "fused" else
+                    f"{nk} {coll} all-reduces of [{a.M},{a.N}] fp32 per step (one per K-split layer)" if tp_path.endswith("per-layer")
                     else f"one {coll} all-reduce of [{nk},{a.M},{a.N}] fp32 per step"))
         else:
             par = f"dp{world} (independent layer streams, no collective)"
@@ -507,10 +637,20 @@ def main():
                          "us_per_layer": 1e6 * kern_s / (a.steps * a.layers),
                          "us_per_step": 1e6 * dev_s / a.steps,
                          "collective_us_per_step": (1e6 * (dev_s - kern_s) / a.steps) if tp else 0.0,
-                         "note": ("per rank: bytes of rank 0's shards / the GEMV launches of a step; us_per_step is the whole step "
-                                  "on the device, collectives included (max over ranks)" if tp else
+                         "note": (("per rank: bytes of rank 0's shards / the WHOLE graph-replayed step (GEMVs + exchange: a lower bound on the "
+                                   "kernels' rate)" if tp_graphed else
+                                   "per rank: bytes of rank 0's shards / the GEMV launches of a step; us_per_step is the whole step "
+                                   "on the device, collectives included (max over ranks)") if tp else
                                   "one grouped launch = the whole stream")},
         }
+        if tp:
+            out["config"]["tp_path"] = tp_path + ("+graph" if tp_graphed else "")
+            out["config"]["tp_requested"] = f"--collective {a.collective} --tp-collectives {a.tp_collectives} --tp-graph {a.tp_graph}"
+            out["config"]["tp_validated_against_baseline_collective"] = True if not tp_path.startswith("rccl") else None
+            if tp_notes:
+                out["config"]["tp_notes"] = tp_notes
+            if rccl_base is not None:
+                out["rccl_per_layer_baseline"] = rccl_base
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline([b["W"] for b in base], a.K, a.M)
         print(json.dumps(out), flush=True)

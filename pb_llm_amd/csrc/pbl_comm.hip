@@ -42,6 +42,7 @@ struct P2PArgs {
 
 __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
     __shared__ uint32_t s_seq, s_timeout;
+    __shared__ uint64_t s_limit;
     const int b = blockIdx.x;
     uint32_t* ctl = ctl_ptr(a.peer[a.rank]);
     if (threadIdx.x == 0) {
@@ -50,6 +51,9 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
         uint32_t q = a.seq ? a.seq : __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         s_seq = q ? q : 1u;                                                      // 0 is the flags' idle value
         s_timeout = 0;
+        // once a wait has timed out on this buffer (status word set: a peer is gone, pbl_p2p_check raises) later calls give up
+        // after 1 ms instead of 3 s each -- a dead peer costs one long wait, not one per layer and token
+        s_limit = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 100000ull : 300000000ull;
     }
     __syncthreads();
     const uint32_t seq = s_seq;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
         const uint64_t t0 = wall_clock64();                                          // 100 MHz
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
             __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > 300000000ull) {                                  // 3 s
+            if (wall_clock64() - t0 > s_limit) {                                          // 3 s (1 ms once the buffer has seen a time-out)
                 atomicExch(ctl, 1u);
                 s_timeout = 1;
                 break;
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(256) void p2p_allreduce_kernel(P2PArgs a) {
 // has seen THIS rank's push of the next call, which comes after this kernel (same argument as for the slots).
 __global__ __launch_bounds__(256) void p2p_reduce_kernel(P2PArgs a, uint32_t expect) {
     __shared__ uint32_t s_seq, s_timeout;
+    __shared__ uint64_t s_limit;
     const int b = blockIdx.x;
     uint8_t* own = a.peer[a.rank];
     uint32_t* ctl = ctl_ptr(own);
@@ -129,6 +134,7 @@ __global__ __launch_bounds__(256) void p2p_reduce_kernel(P2PArgs a, uint32_t exp
         const uint32_t q = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         s_seq = q ? q : 1u;
         s_timeout = 0;
+        s_limit = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 100000ull : 300000000ull;     // (see p2p_allreduce_kernel)
     }
     __syncthreads();
     const uint32_t seq = s_seq;
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256) void p2p_reduce_kernel(P2PArgs a, uint32_t exp
         const uint64_t t0 = wall_clock64();                                          // 100 MHz
         while (__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < expect) {
             __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > 300000000ull) {                                  // 3 s
+            if (wall_clock64() - t0 > s_limit) {                                          // 3 s (1 ms once the buffer has seen a time-out)
                 atomicExch(ctl, 1u);
                 s_timeout = 1;
                 break;

@@ -113,11 +113,11 @@ at::Tensor unpack(const pbl_layer& L, const at::Tensor& like, at::ScalarType dt)
 // bf16 activations [M, K] -> (fp16 copy scaled per token by a power of two, tok_scale [M]): pbl_act_bf16_prepare, one small kernel,
 // no host synchronisation (csrc/pbl_act.hip)
 std::pair<at::Tensor, at::Tensor> prepare_bf16(const at::Tensor& x2, int64_t M, int64_t K) {
-    const at::Tensor xs = x2.stride(-1) == 1 && x2.stride(0) >= K ? x2 : x2.contiguous();
+    const at::Tensor xs = x2.stride(-1) == 1 && (M == 1 || x2.stride(0) >= K) ? x2 : x2.contiguous();
     at::Tensor xh = at::empty({M, K}, x2.options().dtype(at::kHalf));
     at::Tensor sc = at::empty({M}, x2.options().dtype(at::kFloat));
-    check(pbl_act_bf16_prepare(xs.data_ptr(), int(M), uint32_t(K), size_t(xs.stride(0)), xh.data_ptr(), sc.data_ptr<float>(), stream_of(x2)),
-          "act_bf16_prepare");
+    const size_t ldx = M == 1 ? size_t(K) : size_t(xs.stride(0));       // (the stride of a size-1 dimension is arbitrary)
+    check(pbl_act_bf16_prepare(xs.data_ptr(), int(M), uint32_t(K), ldx, xh.data_ptr(), sc.data_ptr<float>(), stream_of(x2)), "act_bf16_prepare");
     return {xh, sc};
 }
 

@@ -136,29 +136,48 @@ class P2PAllReduce:
 
     def _allocate(self):
         """collective: every rank allocates, exports, maps (at the first all_reduce_ of a lazily created communicator:
-        all ranks run the same model, so they get here together)"""
+        all ranks run the same model, so they get here together).  A failure on ANY rank (no IPC support, a mapping that is
+        refused) is agreed over the group before anybody launches: every rank then releases what it holds and raises PblError, so
+        that the caller can fall back to RCCL on all ranks together instead of one rank raising while its peers wait in a barrier."""
         L = _lib.lib()
         group = self.group
+        err = None
         with torch.cuda.device(self.device):
             own = C.c_void_p()
-            _lib.check(L.pbl_comm_alloc(L.pbl_p2p_buffer_bytes_world(self.max_numel, self.world), C.byref(own)), "comm_alloc")
-            self._own = own.value
             handle = (C.c_ubyte * 64)()
-            _lib.check(L.pbl_ipc_export(self._own, handle), "ipc_export")
+            try:
+                _lib.check(L.pbl_comm_alloc(L.pbl_p2p_buffer_bytes_world(self.max_numel, self.world), C.byref(own)), "comm_alloc")
+                self._own = own.value
+                _lib.check(L.pbl_ipc_export(self._own, handle), "ipc_export")
+            except _lib.PblError as e:
+                err = e
             handles = [None] * self.world
-            dist.all_gather_object(handles, bytes(handle), group=group)
+            dist.all_gather_object(handles, (err is None, bytes(handle)), group=group)
             self._ptrs = (C.c_void_p * self.world)()
             self._opened = []
-            for r, h in enumerate(handles):
-                if r == self.rank:
-                    self._ptrs[r] = self._own
-                    continue
-                ptr = C.c_void_p()
-                buf = (C.c_ubyte * 64).from_buffer_copy(h)
-                _lib.check(L.pbl_ipc_open(buf, C.byref(ptr)), f"ipc_open(rank {r})")
-                self._ptrs[r] = ptr.value
-                self._opened.append(ptr.value)
-        dist.barrier(group=group)            # nobody launches before everybody has mapped everybody
+            if err is None and all(ok for ok, _ in handles):
+                try:
+                    for r, (_, h) in enumerate(handles):
+                        if r == self.rank:
+                            self._ptrs[r] = self._own
+                            continue
+                        ptr = C.c_void_p()
+                        buf = (C.c_ubyte * 64).from_buffer_copy(h)
+                        _lib.check(L.pbl_ipc_open(buf, C.byref(ptr)), f"ipc_open(rank {r})")
+                        self._ptrs[r] = ptr.value
+                        self._opened.append(ptr.value)
+                except _lib.PblError as e:
+                    err = e
+            elif err is None:
+                err = _lib.PblError("P2PAllReduce: a peer could not allocate / export its communication buffer")
+        # nobody launches before everybody has mapped everybody -- and everybody learns whether everybody did
+        if not agree_min(int(err is None), group, self.device):
+            for p in self._opened:
+                L.pbl_ipc_close(p)
+            if self._own:
+                L.pbl_comm_free(self._own)
+            self._own, self._opened, self._ptrs = None, [], None
+            raise _lib.PblError(f"P2PAllReduce: peer mapping failed on at least one rank ({err or 'on a peer'}); use collective='rccl'")
 
     def all_reduce_(self, t: torch.Tensor, out_f16: torch.Tensor | None = None) -> torch.Tensor:
         """t (fp32, contiguous) <- sum over ranks, in place; out_f16 (optional, same numel, fp16) also receives the sum

@@ -125,11 +125,11 @@ def act_bf16_prepare(x2: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
     """pbl_act_bf16_prepare: x2 [M, K] bf16 on the GPU -> (fp16 copy scaled per token by a power of two -- exact --, tok_scale [M]
     fp32); a token holding inf / NaN becomes its indicator row with scale +inf (csrc/pbl_act.hip).  One small kernel, no host sync."""
     M, K = x2.shape
-    if x2.stride(1) != 1 or x2.stride(0) < K:
+    if x2.stride(1) != 1 or (M > 1 and x2.stride(0) < K):
         x2 = x2.contiguous()
     xh = torch.empty(M, K, dtype=torch.float16, device=x2.device)
     sc = torch.empty(M, dtype=torch.float32, device=x2.device)
-    _lib.check(_lib.lib().pbl_act_bf16_prepare(x2.data_ptr(), M, K, x2.stride(0), xh.data_ptr(), sc.data_ptr(),
+    _lib.check(_lib.lib().pbl_act_bf16_prepare(x2.data_ptr(), M, K, K if M == 1 else x2.stride(0), xh.data_ptr(), sc.data_ptr(),
                                                torch.cuda.current_stream(x2.device).cuda_stream), "act_bf16_prepare")
     return xh, sc
 

@@ -349,6 +349,19 @@ def test_config5_ksplit_p2p_all_reduce_two_processes():
     assert out[0][0] == out[1][0]                    # both ranks hold the same bits
 
 
+def test_config5_ksplit_p2p_four_processes_one_device():
+    """the same protocol at four ranks (round 5: slot strides, flag / counter indexing and the agreed push limit at more than two
+    peers; eight ranks run as a bench.py plumbing line, profiles/r05_tp8_plumbing.jsonl): four processes share cuda:0, fused push +
+    reduce, the unfused all-reduce, two layers on one communicator, graph replay -- every rank holds the same bits"""
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    mp.spawn(_tp_worker, args=(4, _free_port(), "p2p", out), nprocs=4, join=True)
+    for rank in range(4):
+        rel, ratio, same = out[rank]
+        assert rel < 1e-3 and ratio < 1.0 and same, (rank, rel, ratio, same)
+    assert len({out[r][0] for r in range(4)}) == 1
+
+
 # ------------------------------------------------------------------------------------------- (f1) on-disk format
 class _TwoLinears(torch.nn.Module):
     def __init__(self):
