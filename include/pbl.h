@@ -387,6 +387,15 @@ int pbl_act_bf16_prepare(const void* x_bf16, int M, uint32_t K, size_t ldx, void
 int pbl_act_finish(const float* y_f32, const float* tok_scale, const float* bias, int M, uint32_t N, void* y_out, int out_dtype,
                    void* stream);
 
+/* bf16 activations in ONE launch (decode: one GEMV pass, M <= 4 rows of a group-free layer): x [M, K] bf16 -> y [M, N] bf16 (fp32 with
+ * y_f32).  The kernel's staging phase does what pbl_act_bf16_prepare does and its epilogue what pbl_act_finish does -- the same bits
+ * as the three-launch form.  PBL_ERR_UNSUPPORTED: more rows than one pass takes, or column groups -- run pbl_act_bf16_prepare +
+ * pbl_linear_f16_ws (fp32 out) + pbl_act_finish instead.  pbl_gemv_bf16_fused_host: pbl_gemv_f16_fused_host with bf16 x and a bf16
+ * (fp32) result.  Replaces F.linear under `bf16=True` (qat/run_qat.py:120) at decode time. */
+int pbl_linear_bf16(const pbl_layer* layer, const void* x_bf16, void* y, int M, int y_f32, void* stream);
+int pbl_gemv_bf16_fused_host(const pbl_layer* layers_host, const uint64_t* y_off_host, const void* x_bf16, void* y, int L, int M,
+                             uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, void* stream);
+
 /* Sequential decode (gptq_pb/eval_ppl_utils.py:55-64 at one token: every linear depends on the one before): pbl_linear_f16_ws with
  * a prefetch of the NEXT layer's blob riding on the launch -- extra workgroups that only read next_blob[0 .. next_bytes) while this
  * layer computes, so that the next launch's record look-ups and first tiles find warm cache lines.  NULL / 0: exactly

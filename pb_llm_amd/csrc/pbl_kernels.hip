@@ -229,6 +229,11 @@ struct GemvArgs {
     // first tiles find the Infinity Cache / this XCD's L2 warm instead of paying two dependent HBM latencies.  0: off.
     const uint8_t* pf_ptr;
     uint32_t pf_bytes, pf_wgs;
+    // bf16 activations IN the kernel (round 5; pbl_linear_bf16 / pbl_gemv_bf16_fused_host): x is bf16 -- the staging phase finds every
+    // token's largest magnitude, scales the row by a power of two into fp16's range (exact) while it copies it into LDS, the epilogue
+    // multiplies the result back and writes bf16 (fp32 when y_f32).  A token holding inf / NaN runs as its indicator row with scale
+    // +inf.  Exactly the arithmetic of pbl_act_bf16_prepare + the fp16 kernel + pbl_act_finish (csrc/pbl_act.hip), in ONE launch.
+    int x_bf16;
 };
 
 // A prefetch workgroup: slice `j` of `n` of [ptr, ptr + bytes), read with plain (cacheable) 16-byte loads that are all in flight
@@ -335,10 +340,33 @@ __device__ __forceinline__ void chunk_accumulate(uint32_t xbase, uint32_t tok_st
 // wave w takes panels w, w+S, ... and salient rounds w, w+S, ... and the partial sums are
 // merged through LDS -- so one small layer (256 records at N = 4096) still puts thousands of
 // waves on the chip (latency mode, sequential decode).
-template <int MB, int WPB, bool SF, int SPLIT>
+// fp32 -> bf16 bits, round to nearest even; NaN stays NaN (csrc/pbl_act.hip)
+__device__ __forceinline__ uint32_t bf16_bits_rne(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x0040u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// one bf16 (low 16 bits of b) -> the fp16 bits the kernel multiplies with: scaled by `down` (a power of two: exact) when the token is
+// finite; else the indicator finite -> 0, +-inf -> +-1, NaN -> NaN (csrc/pbl_act.hip: act_bf16_prepare_kernel, the same arithmetic)
+__device__ __forceinline__ uint32_t bf16_to_scaled_f16(uint32_t b, bool finite, float down) {
+    const float f = __builtin_bit_cast(float, b << 16);
+    float r;
+    if (finite) r = f * down;
+    else {
+        const uint32_t a = (b << 16) & 0x7FFFFFFFu;
+        r = a > 0x7F800000u ? f : (a == 0x7F800000u ? ((b & 0x8000u) ? -1.f : 1.f) : 0.f);
+    }
+    return uint32_t(__builtin_bit_cast(uint16_t, _Float16(r)));
+}
+
+// XB: bf16 activations converted in the staging phase, bf16 result (GemvArgs.x_bf16).  A template parameter, not a run-time branch:
+// the fp16 instantiations -- the headline kernel among them -- are the code they were.
+template <int MB, int WPB, bool SF, int SPLIT, bool XB = false>
 __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void pbl_gemv_kernel(GemvArgs args) {
     static_assert(SPLIT == 1 || SPLIT == WPB, "split mode uses every wave of the workgroup on one record");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t s_amax[XB ? MB * WPB : 1];           // XB: per (token, wave) the largest |x| bit pattern
+    __shared__ float s_tscale[XB ? MB : 1];                  //     per token the power of two (or +inf) the result is multiplied with
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -433,7 +461,68 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     }
 
     // ---- phase 0: stage x ---------------------------------------------------------
-    {
+    if constexpr (XB) {
+        // bf16 x: pass 1 finds every token's largest magnitude (bf16 << 16 is the fp32 pattern; |x| patterns order like unsigned
+        // integers, inf / NaN on top), one barrier, pass 2 re-reads the row (L1 / L2) and writes the scaled fp16 copy
+        const int nthr = WPB * PBL_WAVE;
+        const uint16_t* xb = reinterpret_cast<const uint16_t*>(xg);
+        const bool vec = (K & 7) == 0 && (reinterpret_cast<uintptr_t>(xb) & 15) == 0;
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            uint32_t mx = 0;
+            if (vec) {
+                const u32x4* src = reinterpret_cast<const u32x4*>(xb + size_t(m) * K);
+                for (int i = tid; i < (K >> 3); i += nthr) {
+                    const u32x4 v = src[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t lo = (v[j] << 16) & 0x7FFFFFFFu, hi = v[j] & 0x7FFF0000u;
+                        mx = lo > mx ? lo : mx;
+                        mx = hi > mx ? hi : mx;
+                    }
+                }
+            } else {
+                for (int i = tid; i < K; i += nthr) {
+                    const uint32_t a_ = (uint32_t(xb[size_t(m) * K + i]) << 16) & 0x7FFFFFFFu;
+                    mx = a_ > mx ? a_ : mx;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const uint32_t o = uint32_t(__shfl_xor(int(mx), off, PBL_WAVE));
+                mx = o > mx ? o : mx;
+            }
+            if (lane == 0) s_amax[m * WPB + wave] = mx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            uint32_t mx = 0;
+#pragma unroll
+            for (int w = 0; w < WPB; ++w) mx = s_amax[m * WPB + w] > mx ? s_amax[m * WPB + w] : mx;
+            const bool finite = mx < 0x7F800000u;
+            const int eb = int(mx >> 23) - 127 - 14;                     // 2^-e, e = max(0, exponent(amax) - 14): amax / 2^e < 2^15
+            const int e = eb > 0 ? eb : 0;
+            const float down = __builtin_bit_cast(float, uint32_t(127 - e) << 23);
+            if (tid == 0) s_tscale[m] = finite ? __builtin_bit_cast(float, uint32_t(127 + e) << 23) : __builtin_inff();
+            if (vec) {
+                const u32x4* src = reinterpret_cast<const u32x4*>(xb + size_t(m) * K);
+                u32x4* dst = reinterpret_cast<u32x4*>(xs + m * xstride);
+                for (int i = tid; i < (K >> 3); i += nthr) {
+                    const u32x4 v = src[i];
+                    u32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = bf16_to_scaled_f16(v[j] & 0xFFFFu, finite, down) | (bf16_to_scaled_f16(v[j] >> 16, finite, down) << 16);
+                    dst[i] = o;
+                }
+            } else {
+                for (int i = tid; i < K; i += nthr)
+                    reinterpret_cast<uint16_t*>(xs)[m * xstride + i] = uint16_t(bf16_to_scaled_f16(xb[size_t(m) * K + i], finite, down));
+            }
+            for (int i = K + tid; i < xstride; i += nthr) xs[m * xstride + i] = _Float16(0);
+        }
+    } else {
         const int nthr = WPB * PBL_WAVE;
         if ((K & 7) == 0 && (reinterpret_cast<uintptr_t>(xg) & 15) == 0) {
             const int nv = K >> 3;
@@ -624,13 +713,17 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
         const float D = fmaf(A, accsum[m], -(B * X[m]));
         const float sal = (SF && sf) ? fmaf(-pr.hi, S, Q) : fmaf(pr.sscale, fmaf(-pr.szero, S, Q), -(pr.hi * S));
         float yv = fmaf(alpha, D, fmaf(mu, X[m], sal)) + e;
-        if (L.bias && row < L.N) yv += L.bias[row];
+        if constexpr (XB) {                                      // back to the token's own scale, then the bias: pbl_act_finish's fma
+            const float bv = (L.bias && row < L.N) ? L.bias[row] : 0.f;
+            yv = fmaf(yv, s_tscale[m], bv);
+        } else if (L.bias && row < L.N) yv += L.bias[row];
         if (PBL_ABLATE == 1 && abl == 0x9E3779B9u) yv += 1.f;
         if (sub == 0 && row < L.N) {
             if (args.push_world) {
                 for (int p = 0; p < args.push_world; ++p)       // 7 xGMI stores + 1 local, 4 bytes each from 16 lanes (64-byte runs)
                     pblp2p::slot_ptr(args.push_peer[p], push_set, args.push_rank, args.push_world, args.push_cap)[size_t(m) * ldy + row] = yv;
             } else if (args.y_f32) static_cast<float*>(yg)[size_t(m) * ldy + row] = yv;
+            else if constexpr (XB) static_cast<uint16_t*>(yg)[size_t(m) * ldy + row] = uint16_t(bf16_bits_rne(yv));
             else static_cast<_Float16*>(yg)[size_t(m) * ldy + row] = _Float16(yv);
         }
     }
@@ -660,7 +753,7 @@ size_t lds_bytes(uint32_t P, uint32_t max_nch, int mb, int wpb, int split = 1) {
 
 template <int MB, int WPB, bool SF, int SPLIT = 1>
 int launch(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
-    auto k = pbl_gemv_kernel<MB, WPB, SF, SPLIT>;
+    auto k = a.x_bf16 ? pbl_gemv_kernel<MB, WPB, SF, SPLIT, true> : pbl_gemv_kernel<MB, WPB, SF, SPLIT, false>;
     if (lds > 64 * 1024) {
         if (lds > 160 * 1024) return PBL_ERR_UNSUPPORTED;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1224,6 +1317,36 @@ int pbl_linear_f16_ws(const pbl_layer* layer, const void* x, void* y, int M, int
     return PBL_OK;
 }
 
+// bf16 activations in ONE launch (round 5): x [M, K] bf16, y [M, N] bf16 (fp32 with y_f32) = F.linear(x, W, bias) as the reference's
+// bf16 runs compute it (qat/run_qat.py:120; quant/outlier_quantizer.py:101-106 under bf16) -- the GEMV's staging phase scales every
+// token's row by a power of two into fp16's range while it copies it into LDS (exact; a token holding inf / NaN runs as its indicator
+// row), the epilogue scales back, adds the bias and rounds to bf16: the arithmetic of pbl_act_bf16_prepare + pbl_linear_f16 +
+// pbl_act_finish, bit for bit, without the two extra launches.  One GEMV pass of a group-free layer only (M <= the route's limit,
+// at most 4): PBL_ERR_UNSUPPORTED otherwise -- the caller then runs the three-launch form, which serves every kernel family.
+int pbl_linear_bf16(const pbl_layer* layer, const void* x_bf16, void* y, int M, int y_f32, void* stream) {
+    if (!layer || !layer->blob || !x_bf16 || !y || M < 1) return PBL_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(layer->blob) & 15) return PBL_ERR_MISALIGNED;
+    if (layer->G != 1) return PBL_ERR_UNSUPPORTED;
+    const Route r = route_of(layer, M, true);
+    if (M > r.mb_max) return PBL_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool sf = layer->flags & PBL_FLAG_SAL_F16;
+    GemvArgs a{};
+    a.layer = *layer;
+    a.x = static_cast<const _Float16*>(x_bf16);                  // (bf16 bits: the XB instantiation reads them as such)
+    a.y = y;
+    a.M = M; a.y_f32 = y_f32; a.grouped = 0; a.x_bf16 = 1;
+    const int split = r.split, wpb = r.wpb;
+    const dim3 grid(split > 1 ? layer->NRB : (layer->NRB + wpb - 1) / wpb, 1, 1);
+    const size_t lds = lds_bytes(layer->P, layer->max_nch, M, wpb, split);
+    switch (split) {
+        case 8: return launch_split<8>(M, sf, a, grid, lds, st);
+        case 4: return launch_split<4>(M, sf, a, grid, lds, st);
+        case 2: return launch_split<2>(M, sf, a, grid, lds, st);
+        default: return wpb == 4 ? launch_mb<4>(M, sf, a, grid, lds, st) : launch_mb<1>(M, sf, a, grid, lds, st);
+    }
+}
+
 // pbl_linear_f16_ws with a prefetch of the NEXT layer's blob riding on the launch (sequential decode: layers are dependent, every
 // launch otherwise starts with two dependent HBM round trips -- record look-up, then the record -- on cold lines).  next_blob /
 // next_bytes: the device blob the following launch will multiply with (NULL / 0: exactly pbl_linear_f16_ws).  Only GEMV launches
@@ -1371,12 +1494,28 @@ int pbl_gemv_f16_fused(const pbl_layer* layers_dev, const uint64_t* y_off_dev, c
     return fused_launch(a, Lc, M, max_NRB, K, max_nch, group_flags, stream);
 }
 
+static int fused_host(const pbl_layer* layers_host, const uint64_t* y_off_host, const void* x, void* y, int Lc, int M,
+                      uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, int x_bf16, void* stream);
+
 int pbl_gemv_f16_fused_host(const pbl_layer* layers_host, const uint64_t* y_off_host, const void* x, void* y, int Lc, int M,
                             uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, void* stream) {
+    return fused_host(layers_host, y_off_host, x, y, Lc, M, ldy, max_NRB, K, max_nch, group_flags, y_f32, 0, stream);
+}
+
+// the same launch with bf16 activations converted in the kernel and a bf16 (or fp32) result: see pbl_linear_bf16.  Group-free members
+// only (PBL_ERR_UNSUPPORTED when bit 0 of group_flags is set: the column-group kernel has no bf16 instantiation).
+int pbl_gemv_bf16_fused_host(const pbl_layer* layers_host, const uint64_t* y_off_host, const void* x_bf16, void* y, int Lc, int M,
+                             uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, void* stream) {
+    if (group_flags & 1) return PBL_ERR_UNSUPPORTED;
+    return fused_host(layers_host, y_off_host, x_bf16, y, Lc, M, ldy, max_NRB, K, max_nch, group_flags, y_f32, 1, stream);
+}
+
+static int fused_host(const pbl_layer* layers_host, const uint64_t* y_off_host, const void* x, void* y, int Lc, int M,
+                      uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, int x_bf16, void* stream) {
     if (!layers_host || !y_off_host || !x || !y || Lc < 1 || Lc > PBL_FUSED_INLINE_MAX || M < 1 || M > PBL_MAX_TOKENS_PER_LAUNCH || !ldy)
         return PBL_ERR_INVALID_ARG;
     GemvArgs a{};
-    a.M = M; a.y_f32 = y_f32; a.grouped = 1; a.n_inl = Lc;
+    a.M = M; a.y_f32 = y_f32; a.grouped = 1; a.n_inl = Lc; a.x_bf16 = x_bf16;
     for (int l = 0; l < Lc; ++l) {
         if (!layers_host[l].blob || (reinterpret_cast<uintptr_t>(layers_host[l].blob) & 15)) return PBL_ERR_MISALIGNED;
         a.inl[l] = layers_host[l]; a.inl_off[l] = y_off_host[l];

@@ -218,6 +218,15 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
         // <= 32 rows: prepare (scaled fp16 copy + per-token scale, on the device) -> the packed kernels with an fp32 result ->
         // scale, bias and cast in pbl_act_finish.  The same three launches eagerly and under stream capture; +-inf / NaN inputs come
         // out as F.linear's do (csrc/pbl_act.hip).
+        if (M <= PBL_MAX_TOKENS_PER_LAUNCH && G == 1) {
+            // decode: ONE launch -- the GEMV's staging phase converts, its epilogue scales back and rounds to bf16 (pbl_linear_bf16:
+            // the same bits as the three launches below)
+            const at::Tensor xs = x2.contiguous();
+            at::Tensor y = at::empty({M, N}, x.options().dtype(out_f32 ? at::kFloat : at::kBFloat16));
+            const int rc = pbl_linear_bf16(&L, xs.data_ptr(), y.data_ptr(), int(M), out_f32 ? 1 : 0, stream_of(x));
+            if (rc == PBL_OK) return y.reshape(shape);
+            TORCH_CHECK(rc == PBL_ERR_UNSUPPORTED, "libpbl linear_bf16: ", pbl_status_string(rc), " (", rc, ")");
+        }
         at::Tensor xh, tsc;
         std::tie(xh, tsc) = prepare_bf16(x2, M, K);
         const at::Tensor y32 = run_small(Lnb, xh, M, true, isml);

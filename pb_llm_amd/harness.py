@@ -139,8 +139,9 @@ class _FusedMember(nn.Module):
     (the caching allocator hands the next token's activation the address of the previous one), and the call order of the
     members does not matter.  A member called with another tensor -- a view, a copy, the next token -- launches again;
     launches that served no other member are counted (`_FusedGroup.solo_launches`) and reported once, because a model
-    that never shares the tensor pays the whole group per projection.  More than 4 rows, or a non-fp16 activation: each
-    member runs its own PBLinear (matrix-core / GEMM regime), bit-identical to the unfused model."""
+    that never shares the tensor pays the whole group per projection.  More than 4 rows, or an fp32 activation: each
+    member runs its own PBLinear (matrix-core / GEMM regime), bit-identical to the unfused model.  bf16 activations (HF LLaMA
+    checkpoints, qat/run_qat.py:120) run the same fused launch with the conversion inside the kernel (round 5)."""
 
     def __init__(self, group: "_FusedGroup", index: int, own: PBLinear):
         super().__init__()
@@ -152,7 +153,8 @@ class _FusedMember(nn.Module):
     def forward(self, x):
         g = self._group[0]
         rows = x.numel() // x.shape[-1]
-        if x.dtype != torch.float16 or rows > 4 or not x.is_cuda or (torch.is_grad_enabled() and x.requires_grad):
+        if rows > 4 or not x.is_cuda or (torch.is_grad_enabled() and x.requires_grad) or \
+                not (x.dtype == torch.float16 or (x.dtype == torch.bfloat16 and g.fused.bf16_ok)):
             return self.own(x)
         if g.x_ref is x and g.x_version == x._version and self._index in g.pending:     # each launch serves each member once
             g.pending.discard(self._index)

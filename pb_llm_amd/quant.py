@@ -500,6 +500,16 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         # input; a token holding inf / NaN becomes its indicator row with scale +inf, so +-inf / NaN come out as F.linear gives
         # them -- csrc/pbl_act.hip), the packed kernels run once with an fp32 result, pbl_act_finish scales back, adds the bias
         # and casts.  Three launches, no host sync: the same eagerly and under hipGraph capture.
+        if M <= _lib.PBL_MAX_TOKENS_PER_LAUNCH and packed.G == 1:
+            # decode: ONE launch (pbl_linear_bf16: the GEMV converts in its staging phase and rounds to bf16 in its epilogue; the
+            # same bits as the three launches below)
+            xc = x2.contiguous()
+            y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+            rc = L.pbl_linear_bf16(C.byref(layer), xc.data_ptr(), y.data_ptr(), M, int(out_f32), stream)
+            if rc == 0:
+                return y.reshape(*lead, packed.N)
+            if rc != _lib.PBL_ERR_UNSUPPORTED:
+                _lib.check(rc, "linear_bf16")
         xh, tsc = act_bf16_prepare(x2)
         y = small(xh, packed.layer_struct(None), None, M)
         return act_finish(y, tsc, bias_f32, torch.float32 if out_f32 else x.dtype).reshape(*lead, packed.N)

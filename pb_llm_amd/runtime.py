@@ -97,16 +97,25 @@ class FusedGemv:
         self.max_nch = max(p.max_nch for p in self.packed)
         # bit 0: column-group layers present (the launch then runs the column-group kernel), bit 1: fp16-checkpoint layers present
         self.flags = int(any(p.G > 1 for p in self.packed)) | 2 * int(any(p.flags & _lib.PBL_FLAG_SAL_F16 for p in self.packed))
+        self.bf16_ok = self._inline and not (self.flags & 1)
 
     def __call__(self, x2: torch.Tensor, out_f32: bool = False) -> list[torch.Tensor]:
         M = x2.shape[0]
-        if x2.dtype != torch.float16 or not x2.is_contiguous() or x2.shape[1] != self.K or not 1 <= M <= _lib.PBL_MAX_TOKENS_PER_LAUNCH:
-            raise _lib.PblError("FusedGemv: x must be a contiguous fp16 [M <= 4, K] tensor")
+        if x2.dtype not in (torch.float16, torch.bfloat16) or not x2.is_contiguous() or x2.shape[1] != self.K or not 1 <= M <= _lib.PBL_MAX_TOKENS_PER_LAUNCH:
+            raise _lib.PblError("FusedGemv: x must be a contiguous fp16 / bf16 [M <= 4, K] tensor")
         total = int(self.offs[-1])
-        y = torch.empty(M, total, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
+        y = torch.empty(M, total, dtype=torch.float32 if out_f32 else x2.dtype, device=x2.device)
         st = torch.cuda.current_stream(x2.device).cuda_stream
         L = _lib.lib()
-        if self._inline:
+        if x2.dtype == torch.bfloat16:
+            # bf16 activations converted IN the launch, bf16 result (pbl_gemv_bf16_fused_host; group-free members, at most
+            # PBL_FUSED_INLINE_MAX of them: what q/k/v and gate/up are)
+            if not self.bf16_ok:
+                raise _lib.PblError("FusedGemv: bf16 activations need group-free members and at most 4 of them")
+            _lib.check(L.pbl_gemv_bf16_fused_host(C.addressof(self._structs_host), C.addressof(self._yoff_host), x2.data_ptr(), y.data_ptr(),
+                                                  len(self.packed), M, total, self.max_NRB, self.K, self.max_nch, self.flags,
+                                                  int(out_f32), st), "fused gemv (bf16)")
+        elif self._inline:
             _lib.check(L.pbl_gemv_f16_fused_host(C.addressof(self._structs_host), C.addressof(self._yoff_host), x2.data_ptr(), y.data_ptr(),
                                                  len(self.packed), M, total, self.max_NRB, self.K, self.max_nch, self.flags,
                                                  int(out_f32), st), "fused gemv")

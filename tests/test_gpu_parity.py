@@ -5,6 +5,8 @@ Tolerance (BASELINE.json north_star):  max|y - ref| <= 1e-3 * max|r
 and allclose(rtol=1e-3, atol=1e-3*rms(ref)), ref = float64 F.linear on the same
 operands; the goldens (reference torch CPU outputs) are held to the same bar.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -700,3 +702,107 @@ def test_bf16_activations_out_of_fp16_range():
     xm[0, 3], xm[0, 4] = float("inf"), float("inf")
     ym = layer(xm)
     assert not torch.isfinite(ym).any()
+
+
+def _three_launch_bf16(layer, xb, out_f32=False):
+    """pbl_act_bf16_prepare + pbl_linear_f16_ws (fp32 result, no bias) + pbl_act_finish: the form that serves every kernel family"""
+    p = layer.packed
+    x2 = xb.reshape(-1, p.K)
+    xh, tsc = Q.act_bf16_prepare(x2)
+    y32 = torch.empty(x2.shape[0], p.N, dtype=torch.float32, device=xb.device)
+    lay = p.layer_struct(None)
+    _lib.check(_lib.lib().pbl_linear_f16_ws(C.byref(lay), xh.data_ptr(), y32.data_ptr(), x2.shape[0], 1, None, 0,
+                                            torch.cuda.current_stream().cuda_stream), "linear")
+    return Q.act_finish(y32, tsc, layer.pbl_bias, torch.float32 if out_f32 else torch.bfloat16)
+
+
+def test_bf16_single_launch_gemv_equals_the_three_launch_form(llama7b_qproj):
+    """round 5: at decode (<= 4 rows) bf16 activations are converted INSIDE the GEMV (staging phase: per-token power-of-two scale
+    into fp16's range; epilogue: scale back, bias, round to bf16) -- pbl_linear_bf16, what `module(x_bf16)` runs.  Bit for bit the
+    arithmetic of prepare + fp16 kernel + finish, for the headline layer (throughput mode and, as an N = 512 slice, the waves-share-
+    a-record mode), an fp16 checkpoint with bias, a ragged K, values beyond fp16's range and non-finite tokens; fp32 partials too."""
+    W, mask, r = llama7b_qproj
+    big = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"]).to(DEV)
+    sl = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"][:512]).half(), torch.from_numpy(synth.normal((512,), 3, 3, 0.1)),
+                               torch.from_numpy(mask[:512]), -1, r["hscale"][:512], r["hzero"][:512]).to(DEV)
+    Wr = synth.llm_weight(80, 1000, seed=12)                       # K % 8 == 0 but not a panel multiple; N not a record multiple
+    mr = O.ptq_low_mask(Wr, 0.9, "magnitude", None, -1)
+    rr = O.ptq_rtn(Wr, mr, 8, -1)
+    rag = Q.PBLinear.from_dense(torch.from_numpy(rr["W_fq"]).half(), None, torch.from_numpy(mr), -1, rr["hscale"], rr["hzero"]).to(DEV)
+    for layer in (big, sl, rag):
+        K = layer.in_features
+        for M in (1, 2, 3, 4):
+            x = torch.from_numpy(synth.activations((M, K), 30 + M, 21)).float().to(DEV)
+            x[0, 5] = 7.0e4                                          # beyond fp16's range: the token is scaled
+            xb = x.bfloat16()
+            y = layer(xb)
+            assert y.dtype == torch.bfloat16 and y.shape == (M, layer.out_features)
+            assert torch.equal(y, _three_launch_bf16(layer, xb)), (K, M)
+            ref = O.dense_linear(xb.float().cpu().numpy(), layer.weight.float().cpu().numpy(),
+                                 None if layer.pbl_bias is None else layer.pbl_bias.cpu().numpy())
+            assert O.parity_errors(y.float().cpu().numpy(), ref)[0] < 1e-2
+            yf = Q.pb_linear_forward(layer.packed, layer.pbl_bias, xb, out_f32=True)
+            assert yf.dtype == torch.float32 and torch.equal(yf, _three_launch_bf16(layer, xb, out_f32=True))
+            assert torch.equal(yf.bfloat16(), y)
+            xi = xb.clone()
+            xi[M - 1, 9] = float("-inf")
+            if M > 1:
+                xi[0, 11] = float("nan")
+            yi, wi = layer(xi), _three_launch_bf16(layer, xi)
+            assert torch.equal(torch.nan_to_num(yi.float(), nan=3.0), torch.nan_to_num(wi.float(), nan=3.0)), (K, M)
+            assert torch.isneginf(yi[M - 1]).any() or torch.isposinf(yi[M - 1]).any()
+    # a strided view of a wider tensor, and a leading batch dimension
+    xw = torch.from_numpy(synth.activations((2, 2 * 4096), 8, 21)).to(DEV).bfloat16()
+    xv = xw[:, ::2]
+    assert torch.equal(big(xv), big(xv.contiguous()))
+    x3 = xw[:, :4096].reshape(2, 1, 4096)
+    assert torch.equal(big(x3).reshape(2, 4096), big(x3.reshape(2, 4096)))
+
+
+def test_bf16_fused_decode_of_a_bf16_model():
+    """a bf16 HF LLaMA (how the checkpoints ship; qat/run_qat.py:120 trains under bf16) through fuse_decode_ + GraphedForward: the
+    fused q/k/v and gate/up launches take bf16 activations directly (pbl_gemv_bf16_fused_host) -- logits of the fused model, eager and
+    graph-replayed, equal the unfused PB model's bit for bit; against the dense bf16 model within bf16 forward tolerance"""
+    import copy
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from pb_llm_amd import harness as H
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8,
+                      num_key_value_heads=8, vocab_size=1000, max_position_embeddings=256)
+    model = LlamaForCausalLM(cfg).half().eval()
+
+    def producer(name, W):
+        Wn = W.float().numpy()
+        mask = O.ptq_low_mask(Wn, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(Wn, mask, 8, -1)
+        return dict(W_fq=torch.from_numpy(r["W_fq"]), low_mask=torch.from_numpy(mask), hscale=r["hscale"], hzero=r["hzero"])
+
+    side = H.quantize_dense_(model, producer)
+    dense = copy.deepcopy(model).to(DEV).bfloat16()
+    plain = H.to_pb_(model, side).to(DEV)
+    for m in plain.modules():                                # everything around the packed linears in bf16: norms, embeddings, lm_head
+        if not isinstance(m, Q.PBLinear):
+            for n_, p_ in list(m._parameters.items()):
+                if p_ is not None:
+                    p_.data = p_.data.bfloat16()
+    plain.lm_head = plain.lm_head.bfloat16()
+    fused = copy.deepcopy(plain)
+    assert H.fuse_decode_(fused) == 4
+    ids = torch.from_numpy((synth.uniform01(64, 7, 1) * 1000).astype(np.int64)).view(1, -1).to(DEV)
+    with torch.no_grad():
+        for t in range(4):
+            tok = ids[:, t:t + 1]
+            lp = plain(tok, use_cache=False).logits
+            assert lp.dtype == torch.bfloat16
+            lf = fused(tok, use_cache=False).logits
+            assert torch.equal(lf, lp), t
+            ld = dense(tok, use_cache=False).logits.float()
+            assert float((lp.float() - ld).abs().max() / ld.abs().max()) < 6e-2, t        # bf16 end to end: 8 significand bits
+        grp = fused.model.layers[0].self_attn.q_proj._group[0]
+        assert grp.launches > 0 and grp.served >= 2 * grp.launches - 2           # the bf16 calls did take the fused launch
+        for T_ in (3, 4, 5):
+            assert torch.equal(fused(ids[:, :T_], use_cache=False).logits, plain(ids[:, :T_], use_cache=False).logits), T_
+        g = H.GraphedForward(fused, ids[:, :1])
+        for t in (9, 10, 11):
+            tok = ids[:, t:t + 1]
+            assert torch.equal(g.replay(tok), plain(tok, use_cache=False).logits), t
