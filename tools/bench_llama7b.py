@@ -78,7 +78,7 @@ with torch.no_grad():
 out["logits_rel_max_diff_vs_dense"] = float((got - ref).abs().max() / ref.abs().max())
 if "prefill" in MODES:
     from pb_llm_amd import quant as Qm
-    for backend in ("library", "auto"):
+    for backend in ("library", "tuned", "auto"):
         Qm.GEMM_BACKEND = backend
         t = timeit(lambda: model(ids))
         out[f"prefill_pb_{backend}_ms"] = round(t * 1e3, 2)
@@ -96,4 +96,23 @@ if "decode" in MODES:
     t = timeit(lambda: g.replay(tok1), 50)
     out["decode_pb_fused_graph_ms_per_token"] = round(t * 1e3, 3)
     out["decode_tokens_per_s_pb_fused_graph"] = round(1.0 / t, 1)
+if os.environ.get("BF16", "1") == "1":
+    # the same model in bf16 (how HF LLaMA checkpoints ship; qat/run_qat.py:120): everything around the packed linears is cast,
+    # the linears take bf16 activations through the same kernels (round 5: prepare + GEMM epilogue at prefill, inside the GEMV /
+    # the fused launches at decode)
+    from pb_llm_amd import quant as Qm
+    for m_ in model.modules():
+        if not isinstance(m_, PBLinear):
+            for n_, p_ in list(m_._parameters.items()):
+                if p_ is not None:
+                    p_.data = p_.data.bfloat16()
+    Qm.GEMM_BACKEND = "auto"
+    if "prefill" in MODES:
+        t = timeit(lambda: model(ids))
+        out["prefill_pb_auto_bf16_ms"] = round(t * 1e3, 2)
+    if "decode" in MODES:
+        out["decode_pb_fused_eager_bf16_ms_per_token"] = round(timeit(lambda: model(tok1), 20) * 1e3, 3)
+        gb = H.GraphedForward(model, tok1)
+        t = timeit(lambda: gb.replay(tok1), 50)
+        out["decode_pb_fused_graph_bf16_ms_per_token"] = round(t * 1e3, 3)
 print(json.dumps(out))
