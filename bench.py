@@ -47,7 +47,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_PROFILE = os.path.join("profiles", "traffic_r04.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "traffic_r05.json")
 
 
 def build_base_layers(n_distinct, N, K, low_frac, seed0):
@@ -254,9 +254,6 @@ def main():
     ap.add_argument("--low-frac", type=float, default=0.9)
     ap.add_argument("--mode", choices=["grouped", "graph", "eager"], default="grouped")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--prefetch-next", type=int, choices=[-1, 0, 1], default=-1,
-                    help="--mode graph / eager: launch every layer through pbl_linear_f16_pf with (1) or without (0) the prefetch of the "
-                         "next layer's blob riding on the launch (-1: the module path)")
     ap.add_argument("--parallel", choices=["auto", "dp", "tp"], default="auto",
                     help="auto: tp when --gpus > 1; tp: LLaMA tensor-parallel mapping of the layer stream + one "
                          "all-reduce of the K-split partial outputs per step (strong scaling); dp: independent "
@@ -360,23 +357,6 @@ def main():
     singles = None
     if a.mode != "grouped":
         singles = [(PBLinear(p, None), x) for g, _ in groups for p, x in zip(g.packed, g.x)]
-        if a.prefetch_next >= 0:
-            # the sequential-decode pattern through the C ABI directly: one launch per layer, each carrying (1) or not (0) a prefetch
-            # of the NEXT layer's blob (pbl_linear_f16_pf): what a decoder's dependent linears would do
-            import ctypes as C_
-            from pb_llm_amd import _lib as _l
-            flat = [(p, x, y) for g, _ in groups for p, x, y in zip(g.packed, g.x, g.y)]
-
-            class _Call:
-                def __init__(self, p, x, y, nxt):
-                    self.layer, self.x, self.y, self.nxt, self.M = p.layer_struct(None), x, y, nxt, x.shape[0]
-
-                def __call__(self, _x):
-                    nb = self.nxt.blob if (self.nxt is not None and a.prefetch_next == 1) else None
-                    _l.check(_l.lib().pbl_linear_f16_pf(C_.byref(self.layer), self.x.data_ptr(), self.y.data_ptr(), self.M, 0, None, 0,
-                                                        nb.data_ptr() if nb is not None else None, nb.numel() if nb is not None else 0,
-                                                        torch.cuda.current_stream(dev).cuda_stream), "linear_f16_pf")
-            singles = [(_Call(p, x, y, flat[(i + 1) % len(flat)][0]), x) for i, (p, x, y) in enumerate(flat)]
     kev = []            # (start, end) events around the GEMV launches of a step (tp, eager: the timed region also holds the collective)
 
     # ---- tensor parallel: which exchange runs.  Decided ONCE, group-wide (every rank must take the same path: the fused pair, the
@@ -643,7 +623,7 @@ def main():
             "dtype": "f16 (x, y) / 1-bit + u8 weights, f32 accumulate", "data": "synthetic",
             "config": {"workload": f"llama-7b q_proj {a.N}x{a.K} xnor low_frac={a.low_frac} + int8 salient, "
                                    f"bs={a.M} GEMV, stream of {a.layers} layer blobs at distinct HBM addresses "
-                                   f"({a.distinct} distinct weight sets), mode={a.mode}" + (f", prefetch_next={a.prefetch_next}" if a.prefetch_next >= 0 else ""),
+                                   f"({a.distinct} distinct weight sets), mode={a.mode}",
                        "layers_per_step": a.layers, "tokens": a.M, "parallelism": par},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

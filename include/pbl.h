@@ -396,13 +396,6 @@ int pbl_linear_bf16(const pbl_layer* layer, const void* x_bf16, void* y, int M, 
 int pbl_gemv_bf16_fused_host(const pbl_layer* layers_host, const uint64_t* y_off_host, const void* x_bf16, void* y, int L, int M,
                              uint32_t ldy, uint32_t max_NRB, uint32_t K, uint32_t max_nch, int group_flags, int y_f32, void* stream);
 
-/* Sequential decode (gptq_pb/eval_ppl_utils.py:55-64 at one token: every linear depends on the one before): pbl_linear_f16_ws with
- * a prefetch of the NEXT layer's blob riding on the launch -- extra workgroups that only read next_blob[0 .. next_bytes) while this
- * layer computes, so that the next launch's record look-ups and first tiles find warm cache lines.  NULL / 0: exactly
- * pbl_linear_f16_ws; launches that are not one GEMV pass ignore the hint.  Results are those of pbl_linear_f16_ws bit for bit. */
-int pbl_linear_f16_pf(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* workspace, size_t workspace_bytes,
-                      const void* next_blob, size_t next_bytes, void* stream);
-
 /* Decode-time FUSED projections (q/k/v, gate/up: layers that read the same activation): L layers, ONE x [M, K] (fp16,
  * 16-B aligned rows are not required), ONE output matrix y [M, ldy] in which layer l owns the columns
  * [y_off[l], y_off[l] + N_l).  Unlike pbl_gemv_f16_grouped no pointer table refers to x or y, so the caller may pass

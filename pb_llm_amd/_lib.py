@@ -57,7 +57,7 @@ EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_pack_d
            "pbl_p2p_buffer_bytes", "pbl_comm_alloc", "pbl_comm_free", "pbl_ipc_export", "pbl_ipc_open", "pbl_ipc_close",
            "pbl_p2p_allreduce_f32", "pbl_p2p_allreduce_f32_dev", "pbl_p2p_buffer_bytes_world", "pbl_p2p_check",
            "pbl_linear_f16_push", "pbl_p2p_reduce_f32_dev", "pbl_linear_push_max_tokens",
-           "pbl_gemm_f16_image_ex", "pbl_act_bf16_prepare", "pbl_act_finish", "pbl_linear_f16_pf",
+           "pbl_gemm_f16_image_ex", "pbl_act_bf16_prepare", "pbl_act_finish",
            "pbl_linear_bf16", "pbl_gemv_bf16_fused_host"]
 
 
@@ -186,8 +186,6 @@ def lib() -> C.CDLL:
     L.pbl_gemm_f16_image_ex.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, vp, sz, vp, vp]
     L.pbl_act_bf16_prepare.restype = C.c_int
     L.pbl_act_bf16_prepare.argtypes = [vp, C.c_int, u32, sz, vp, vp, vp]
-    L.pbl_linear_f16_pf.restype = C.c_int
-    L.pbl_linear_f16_pf.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, sz, vp, sz, vp]
     L.pbl_linear_bf16.restype = C.c_int
     L.pbl_linear_bf16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
     L.pbl_gemv_bf16_fused_host.restype = C.c_int

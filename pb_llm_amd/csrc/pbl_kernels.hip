@@ -224,37 +224,12 @@ struct GemvArgs {
     int push_world, push_rank;
     size_t push_cap;
     uint8_t* push_peer[PBL_P2P_MAX_WORLD];
-    // next-layer prefetch (pbl_linear_f16_pf; sequential decode): the launch carries pf_wgs EXTRA workgroups behind the working ones
-    // that only read pf_bytes at pf_ptr -- the blob of the layer the NEXT launch multiplies with -- so that its record look-ups and
-    // first tiles find the Infinity Cache / this XCD's L2 warm instead of paying two dependent HBM latencies.  0: off.
-    const uint8_t* pf_ptr;
-    uint32_t pf_bytes, pf_wgs;
     // bf16 activations IN the kernel (round 5; pbl_linear_bf16 / pbl_gemv_bf16_fused_host): x is bf16 -- the staging phase finds every
     // token's largest magnitude, scales the row by a power of two into fp16's range (exact) while it copies it into LDS, the epilogue
     // multiplies the result back and writes bf16 (fp32 when y_f32).  A token holding inf / NaN runs as its indicator row with scale
     // +inf.  Exactly the arithmetic of pbl_act_bf16_prepare + the fp16 kernel + pbl_act_finish (csrc/pbl_act.hip), in ONE launch.
     int x_bf16;
 };
-
-// A prefetch workgroup: slice `j` of `n` of [ptr, ptr + bytes), read with plain (cacheable) 16-byte loads that are all in flight
-// together and whose data is dropped.  Slices are ordered so that the workgroups an XCD hosts (workgroup b runs on XCD b % 8) cover
-// ONE contiguous eighth of the blob -- the eighth whose records the next launch's XCD-aware mapping hands to the same XCD.
-__device__ __forceinline__ void prefetch_slice(const uint8_t* ptr, uint32_t bytes, uint32_t j, uint32_t n, uint32_t xcd, int tid, int nthr) {
-    const uint32_t per_x = n >> 3;                                   // workgroups per XCD (n is a multiple of 8)
-    const uint32_t units = (bytes + 15u) >> 4;                       // 16-byte units
-    const uint32_t ux = (units + 7u) >> 3;                           // units per XCD eighth
-    const uint32_t uw = (ux + per_x - 1u) / per_x;                   // units per workgroup
-    const uint32_t lo = xcd * ux + (j >> 3) * uw;
-    uint32_t hi = lo + uw;
-    hi = hi < (xcd + 1u) * ux ? hi : (xcd + 1u) * ux;
-    hi = hi < units ? hi : units;
-    const u32x4* p = reinterpret_cast<const u32x4*>(ptr);
-    for (uint32_t u = lo + uint32_t(tid); u < hi; u += uint32_t(nthr)) {
-        u32x4 sink;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sink) : "v"(p + u) : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
 
 // Gather 8 fp16 values from LDS byte addresses a[0..7] into 4 packed half2 registers
 // (entry 2p in the low half, 2p+1 in the high half).  All loads are in flight and waited
@@ -390,11 +365,7 @@ __global__ __launch_bounds__(WPB * PBL_WAVE, (MB == 1 ? PBL_MIN_WAVES : 1)) void
     // the 128-byte lines shared by neighbouring records stay within one L2.  Measured neutral
     // (FETCH_SIZE 1416.8 -> 1414.0 MB per 224-layer launch): there is no inter-record reuse.
     const uint32_t nwg = SPLIT > 1 ? L.NRB : (L.NRB + WPB - 1) / WPB;
-    if (blockIdx.x >= nwg) {        // whole workgroup exits together (grouped launches over-provision; prefetch workgroups)
-        if (args.pf_wgs && blockIdx.x - nwg < args.pf_wgs)
-            prefetch_slice(args.pf_ptr, args.pf_bytes, blockIdx.x - nwg, args.pf_wgs, blockIdx.x & 7u, tid, WPB * PBL_WAVE);
-        return;
-    }
+    if (blockIdx.x >= nwg) return;  // whole workgroup exits together (grouped launches over-provision)
     const uint32_t xq = nwg >> 3, xr_ = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
     const uint32_t wg = (xcd < xr_ ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq) + xi;
     const uint32_t rb0 = SPLIT > 1 ? wg : wg * WPB;
@@ -1338,45 +1309,6 @@ int pbl_linear_bf16(const pbl_layer* layer, const void* x_bf16, void* y, int M, 
     a.M = M; a.y_f32 = y_f32; a.grouped = 0; a.x_bf16 = 1;
     const int split = r.split, wpb = r.wpb;
     const dim3 grid(split > 1 ? layer->NRB : (layer->NRB + wpb - 1) / wpb, 1, 1);
-    const size_t lds = lds_bytes(layer->P, layer->max_nch, M, wpb, split);
-    switch (split) {
-        case 8: return launch_split<8>(M, sf, a, grid, lds, st);
-        case 4: return launch_split<4>(M, sf, a, grid, lds, st);
-        case 2: return launch_split<2>(M, sf, a, grid, lds, st);
-        default: return wpb == 4 ? launch_mb<4>(M, sf, a, grid, lds, st) : launch_mb<1>(M, sf, a, grid, lds, st);
-    }
-}
-
-// pbl_linear_f16_ws with a prefetch of the NEXT layer's blob riding on the launch (sequential decode: layers are dependent, every
-// launch otherwise starts with two dependent HBM round trips -- record look-up, then the record -- on cold lines).  next_blob /
-// next_bytes: the device blob the following launch will multiply with (NULL / 0: exactly pbl_linear_f16_ws).  Only GEMV launches
-// of group-free layers carry the prefetch (PBL_PF_WGS extra workgroups on the first pass); other routes ignore it.
-#ifndef PBL_PF_WGS
-#define PBL_PF_WGS 64
-#endif
-int pbl_linear_f16_pf(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, void* workspace, size_t workspace_bytes,
-                      const void* next_blob, size_t next_bytes, void* stream) {
-    if (!next_blob || !next_bytes || !layer || layer->G != 1 || M < 1) return pbl_linear_f16_ws(layer, x, y, M, y_f32, workspace, workspace_bytes, stream);
-    if (!layer->blob || !x || !y) return PBL_ERR_INVALID_ARG;
-    if ((reinterpret_cast<uintptr_t>(layer->blob) & 15) || (reinterpret_cast<uintptr_t>(next_blob) & 15)) return PBL_ERR_MISALIGNED;
-    const Route r = route_of(layer, M, !(reinterpret_cast<uintptr_t>(x) & 15));
-    if (r.mfma || M > r.mb_max) return pbl_linear_f16_ws(layer, x, y, M, y_f32, workspace, workspace_bytes, stream);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const bool sf = layer->flags & PBL_FLAG_SAL_F16;
-    GemvArgs a{};
-    a.layer = *layer;
-    a.x = static_cast<const _Float16*>(x);
-    a.y = y;
-    a.M = M; a.y_f32 = y_f32; a.grouped = 0;
-    a.pf_ptr = static_cast<const uint8_t*>(next_blob);
-    a.pf_bytes = uint32_t(next_bytes > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : next_bytes);
-    a.pf_wgs = PBL_PF_WGS;
-    const int split = r.split, wpb = r.wpb;
-    const uint32_t nwg = split > 1 ? layer->NRB : (layer->NRB + wpb - 1) / wpb;
-    // the prefetch workgroups sit behind the working ones; their XCD (workgroup b runs on XCD b % 8) is their index % 8 only when
-    // the working range is a multiple of 8 -- other layers run without the prefetch
-    if (nwg & 7u) return pbl_linear_f16_ws(layer, x, y, M, y_f32, workspace, workspace_bytes, stream);
-    const dim3 grid(nwg + a.pf_wgs, 1, 1);
     const size_t lds = lds_bytes(layer->P, layer->max_nch, M, wpb, split);
     switch (split) {
         case 8: return launch_split<8>(M, sf, a, grid, lds, st);
