@@ -353,6 +353,20 @@ size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* geom);
 int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, void* stream);
 int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
                        const uint32_t* geom, void* stream);
+/* Shapes whose tiles are not a whole number of rounds of the chip (5120 x 5120 at 2048 rows: 320 tiles of 128 x 256 on 256 CUs; a
+ * 300-token prompt: 64 tiles) -- pbl_gemm_f16_image_ws cuts the launch into a full part (whole rounds, straight to y) and a tail
+ * whose tiles are split along K so that tail x splits fills the chip once; the tail's fp32 partial tiles go through `workspace`
+ * (pbl_gemm_image_workspace_bytes(layer, M) bytes, 16-byte aligned, any content; 0: the plan is one launch) and a small kernel adds
+ * them in split order (deterministic), adds the bias, applies tok_scale and casts.  Without a workspace (NULL / too small, and in
+ * pbl_gemm_f16_image / _ex) everything is ONE launch, bit-identical to pbl_gemm_f16_ws / _prepared; with it the tail's tiles differ
+ * by fp32 summation order.  pbl_gemm_image_plan reports the plan (mode 0 one launch / 1 token tail / 2 row tail, cut, splits, half
+ * slabs per split, region tokens x columns).  Caller: the reference's perplexity loops at 2048 rows on llama-13b's 5120-row layers,
+ * and every prompt shorter than a chip's worth of tiles (gptq_pb/eval_ppl_utils.py:55-64, evaluate.py:126-145). */
+size_t pbl_gemm_image_workspace_bytes(const pbl_layer* layer, int M);
+int pbl_gemm_image_plan(const pbl_layer* layer, int M, uint64_t* out6);
+int pbl_gemm_f16_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int out_dtype, const float* tok_scale,
+                          const void* image, size_t image_bytes, const uint32_t* geom, void* workspace, size_t workspace_bytes,
+                          void* stream);
 /* The same with the result's type named (PBL_DTYPE_F16 / PBL_DTYPE_F32: exactly the call above) and, for bf16 activations
  * (qat/run_qat.py:120 `bf16=True`; F.linear(x_bf16, w, b), quant/outlier_quantizer.py:101-106 under bf16 autocast),
  * PBL_DTYPE_BF16 with tok_scale [M] (device, fp32): x is the fp16 copy pbl_act_bf16_prepare made of the bf16 activations and

@@ -58,7 +58,8 @@ EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_pack_d
            "pbl_p2p_allreduce_f32", "pbl_p2p_allreduce_f32_dev", "pbl_p2p_buffer_bytes_world", "pbl_p2p_check",
            "pbl_linear_f16_push", "pbl_p2p_reduce_f32_dev", "pbl_linear_push_max_tokens",
            "pbl_gemm_f16_image_ex", "pbl_act_bf16_prepare", "pbl_act_finish",
-           "pbl_linear_bf16", "pbl_gemv_bf16_fused_host"]
+           "pbl_linear_bf16", "pbl_gemv_bf16_fused_host", "pbl_gemm_image_workspace_bytes", "pbl_gemm_image_plan",
+           "pbl_gemm_f16_image_ws"]
 
 
 def lib() -> C.CDLL:
@@ -190,6 +191,12 @@ def lib() -> C.CDLL:
     L.pbl_linear_bf16.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp]
     L.pbl_gemv_bf16_fused_host.restype = C.c_int
     L.pbl_gemv_bf16_fused_host.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, u32, u32, u32, u32, C.c_int, C.c_int, vp]
+    L.pbl_gemm_image_workspace_bytes.restype = sz
+    L.pbl_gemm_image_workspace_bytes.argtypes = [C.POINTER(PblLayer), C.c_int]
+    L.pbl_gemm_image_plan.restype = C.c_int
+    L.pbl_gemm_image_plan.argtypes = [C.POINTER(PblLayer), C.c_int, vp]
+    L.pbl_gemm_f16_image_ws.restype = C.c_int
+    L.pbl_gemm_f16_image_ws.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, vp, sz, vp, vp, sz, vp]
     L.pbl_act_finish.restype = C.c_int
     L.pbl_act_finish.argtypes = [vp, vp, vp, C.c_int, u32, vp, C.c_int, vp]
     _lib = L

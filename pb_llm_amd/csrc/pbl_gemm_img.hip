@@ -289,6 +289,15 @@ struct ImgArgs {
     const uint32_t* rtab;
     const uint32_t* levels;
     const float* tok_scale; // OM == 2: [M] fp32, the power of two (or +inf) every token's row of y is multiplied with (pbl_act_bf16_prepare)
+    // the work of THIS launch (round 5, pbl_gemm_f16_image_ws: a thin last round is cut off and split along K): row tiles
+    // [rt0, rt0 + nrt) x token tiles [tt0, tt0 + ntt), each in KSn work items of hps half slabs out of [h0, h0 + nh).  Work item
+    // (tile, ks) writes y element (tok, row) to  ybase[(tok - ytok0) * ldy + (row - ycol0)],  ybase = y + ks * part_stride floats
+    // (KSn > 1: fp32 partial tiles of a region buffer, summed by img_reduce_kernel; else the caller's y with ytok0 = ycol0 = 0, ldy = N).
+    uint32_t rt0, nrt, tt0, ntt;
+    int h0, nh, hps, KSn;
+    size_t part_stride;
+    uint32_t ldy, ycol0;
+    int ytok0;
 #if PBL_TRACE
     uint64_t* trace;
 #endif
@@ -314,14 +323,23 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const pbl_layer& L = a.L;
     const int K = int(L.K), M = a.M;
-    const int NH = (K + GI_HS - 1) / GI_HS, NU = (K + GI_XC - 1) / GI_XC;
+    const int NH = (K + GI_HS - 1) / GI_HS, NUt = (K + GI_XC - 1) / GI_XC;     // the layer's half slabs / 64-column steps
     // XCD-aware work order (speed only): workgroup b runs on XCD b % 8; every XCD gets a CONTIGUOUS range of the token-tile-major
     // work list, so the workgroups resident on an XCD share one 256-token slab of x in its L2
-    const uint32_t nrbk = (L.NRB + 7) / 8, nwg = gridDim.x;
+    const uint32_t nwg = gridDim.x;
     const uint32_t xq = nwg >> 3, xr_ = nwg & 7, xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
     const uint32_t wg = (xcd < xr_ ? xcd * (xq + 1) : xr_ * (xq + 1) + (xcd - xr_) * xq) + xi;
-    const uint32_t rowblk = wg % nrbk;
-    const int tok0 = int(wg / nrbk) * GI_TOK;
+    // work item -> (K split, tile): splits outermost, then token tiles, then row tiles
+    const uint32_t ntile = a.nrt * a.ntt;
+    const int ks = int(wg / ntile);
+    const uint32_t tl = wg - uint32_t(ks) * ntile;
+    const uint32_t rowblk = a.rt0 + tl % a.nrt;
+    const int tok0 = int(a.tt0 + tl / a.nrt) * GI_TOK;
+    const int hb = a.h0 + ks * a.hps;                                  // this item's half slabs [hb, he)
+    const int he = min(hb + a.hps, a.h0 + a.nh);
+    const int ub = 2 * hb;                                             // ... = the layer's steps [ub, ub + NU)
+    const int NU = min(NUt, 2 * he) - ub;
+    char* const ybase = static_cast<char*>(a.y) + size_t(ks) * a.part_stride * sizeof(float);
     // ---- the result tile: Ys[256 tokens][128 rows] over the (then idle) ring and stages; the MFMA waves fill it, ALL eight waves
     // store it (32 tokens each, contiguous 16-byte units): with four storing waves the tail of the kernel was 6.4 us, with eight 3.4
     typedef typename std::conditional<Y32, float, _Float16>::type yt;
@@ -333,13 +351,13 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // the tile is complete
         asm volatile("" ::: "memory");
-        const bool vec = (L.N & (Y32 ? 3 : 7)) == 0 && row0 + GI_ROWS <= L.N;     // whole 16-byte units, all rows exist
+        const bool vec = (a.ldy & (Y32 ? 3 : 7)) == 0 && row0 + GI_ROWS <= L.N;   // whole 16-byte units, all rows exist (row0 - ycol0: a multiple of 128)
         constexpr int UPR = GI_ROWS * int(sizeof(yt)) / 16;      // 16-byte units per token row: 16 (fp16) / 32 (fp32)
         constexpr int EPU = 16 / int(sizeof(yt));                // elements per unit
         for (int idx = lane; idx < 32 * UPR; idx += GW) {
             const int t = 32 * wave + idx / UPR, un = idx % UPR, tok = tok0 + t;
             if (tok >= M) continue;
-            yt* dstg = static_cast<yt*>(a.y) + size_t(tok) * L.N + row0 + un * EPU;
+            yt* dstg = reinterpret_cast<yt*>(ybase) + size_t(tok - a.ytok0) * a.ldy + (row0 - a.ycol0) + un * EPU;
             const yt* src = reinterpret_cast<const yt*>(smem_i + uint32_t(t) * YSTR) + un * EPU;
             if (vec) *reinterpret_cast<u32x4*>(dstg) = *reinterpret_cast<const u32x4*>(src);
             else
@@ -437,13 +455,13 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
             // the descriptor's range instead, so they read zeros (the weights there are finite, the products vanish)
             if constexpr (KT) xvlast[q] = xvoff[q] + ((ktail_units && lu >= ktail_units) ? 0x40000000u : 0u);
         }
-        auto stage_x = [&](int u, uint32_t slot_off) {           // the wave's 8 pieces of step u into the ring slot at slot_off
-            const uint32_t so = uint32_t(u) * (GI_XC * 2);
+        auto stage_x = [&](int u, uint32_t slot_off) {           // the wave's 8 pieces of this item's step u into the ring slot at slot_off
+            const uint32_t so = uint32_t(ub + u) * (GI_XC * 2);    // (steps past the item's end read the next split's columns: never used)
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const uint32_t dst = GI_X_OFF + slot_off + uint32_t(8 * p + q) * 1024u;
                 uint32_t vo = xvoff[q];
-                if constexpr (KT) vo = (u == NU - 1) ? xvlast[q] : vo;
+                if constexpr (KT) vo = (ub + u == NUt - 1) ? xvlast[q] : vo;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_i + dst), 16, int(vo), int(so), 0, 0);
             }
         };
@@ -499,16 +517,16 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
 
         // ---- prologue: half slab 0 of A, steps 0 and 1 of x, the requests that follow
 #pragma unroll
-        for (int i = 0; i < 2; ++i) load_levels(i, 0);
+        for (int i = 0; i < 2; ++i) load_levels(i, (uint32_t(hb) * GI_HS) / gs);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) request(i, 0, e[0][i], nvs[0][i]);
+        for (int i = 0; i < 2; ++i) request(i, hb, e[0][i], nvs[0][i]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) request(i, 1, e[1][i], nvs[1][i]);
+        for (int i = 0; i < 2; ++i) request(i, hb + 1, e[1][i], nvs[1][i]);
         stage_x(0, 0);
         stage_x(1, GI_XSLOT);
         asm volatile("s_waitcnt vmcnt(0)" : GI_EREGS :: "memory");
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { expand(i, e[0][i], nvs[0][i], 0); request(i, 2, e[0][i], nvs[0][i]); }
+        for (int i = 0; i < 2; ++i) { expand(i, e[0][i], nvs[0][i], 0); request(i, hb + 2, e[0][i], nvs[0][i]); }
         TR_STAMP(1);
         barrier();                                               // barrier 0: stage 0 of A, steps 0 and 1 of x are in LDS
 
@@ -518,7 +536,7 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
         auto step = [&](int q, auto qm_tag) {
             constexpr int QM = decltype(qm_tag)::value;           // q & 3
             constexpr int i = QM & 1, st = ((QM >> 1) + 1) & 1;   // record; stage == register set == parity of the target half slab
-            const int hh = (q >> 1) + 1;
+            const int hh = hb + (q >> 1) + 1;                   // (absolute half slab; q counts this item's steps)
             if (!(PBL_IMG_ABLATE & 2)) stage_x(q + 2, xs_free);
             { const uint32_t t = xs_free; xs_free = xs_a; xs_a = xs_b; xs_b = t; }
             if (L.G > 1 && (uint32_t(hh) * GI_HS) % gs == 0 && hh < NH) load_levels(i, (uint32_t(hh) * GI_HS) / gs);
@@ -1114,12 +1132,154 @@ extern "C" int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom
                            static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
 }
 
+namespace {
+
+// ---- the launch plan: cutting a thin last round off and splitting it along K ---------------------------------------------------
+// The kernel's unit is a tile of 128 rows x 256 tokens over the WHOLE K, one per CU and round.  T tiles on C CUs cost ceil(T / C)
+// rounds whatever T % C is: 5120 x 5120 at 2048 rows is 320 tiles = two rounds for 1.25 rounds of work, a 300-token prompt on
+// 4096 x 4096 is 64 tiles on 256 CUs.  Round 4 answered with the library for such shapes; round 5 keeps them on this kernel:
+// the launch is cut into a FULL part (whole rounds, tiles over the whole K, written straight to y) and a TAIL part whose tiles are
+// split along K into KS work items each, so that tail tiles x KS fills the chip once; the tail's fp32 partial tiles go to a region
+// buffer [KS][region] in the caller's workspace and img_reduce_kernel adds them in split order (deterministic), adds the bias,
+// scales (bf16 activations) and casts.  The tail is either the last token tiles of every row tile ("token tail": the region is
+// the contiguous rows [t0, M) of y) or the last row tiles of every token tile ("row tail": the columns [c0, N) of y).
+// Unlike round 4's stream-K attempt (partials exchanged through agent-scope stores and flags INSIDE one launch: the exchange cost
+// the workers what the split saved) the partial tiles cross a launch boundary: plain stores, plain loads.
+struct ImgPlan {
+    int mode;                       // 0: one launch over everything (no workspace); 1: token tail; 2: row tail
+    uint32_t RT, TT;                // row tiles, token tiles of the whole problem
+    uint32_t cut;                   // mode 1: token tiles [0, cut) are the full part; mode 2: row tiles [0, cut)
+    int KS, hps;                    // K splits of the tail, half slabs per split
+    size_t region_tok, region_col;  // the tail's region of y: tokens x columns
+};
+int g_img_force_mode = -1, g_img_force_cut = 0, g_img_force_ks = 0;      // tests / tools only (pbl_debug_force_gemm_plan)
+
+ImgPlan img_plan(const pbl_layer* layer, int M) {
+    ImgPlan p = {};
+    p.RT = (layer->NRB + 7) / 8;
+    p.TT = uint32_t((M + GI_TOK - 1) / GI_TOK);
+    const int NH = int((layer->K + GI_HS - 1) / GI_HS);
+    const double cus = double(sb_cu_count());
+    const uint32_t T = p.RT * p.TT;
+    auto region = [&](ImgPlan& q) {
+        if (q.mode == 1) { q.region_tok = size_t(M) - size_t(q.cut) * GI_TOK; q.region_col = layer->N; }
+        else { q.region_tok = size_t(M); q.region_col = size_t(layer->N) - size_t(q.cut) * GI_ROWS; }
+    };
+    if (g_img_force_mode >= 0) {
+        p.mode = g_img_force_mode;
+        if (p.mode) {
+            p.cut = uint32_t(g_img_force_cut); p.KS = g_img_force_ks > 0 ? g_img_force_ks : 2;
+            if (p.cut >= (p.mode == 1 ? p.TT : p.RT) || NH / p.KS < 2) { p.mode = 0; return p; }
+            p.hps = (NH + p.KS - 1) / p.KS; p.KS = (NH + p.hps - 1) / p.hps;
+            region(p);
+        }
+        return p;
+    }
+    // cost model in us (measured, profiles/r04_gemm.md / r05_gemm.md): a round costs ~2.06 us per half slab of K plus ~6 us of
+    // start-up and tail per work item; the reduce reads KS fp32 regions and writes one at ~3 TB/s behind a ~4 us launch; two
+    // more launches cost ~3 us.  Only the ORDER of the candidates matters.
+    const double t_hs = 2.06, c0 = 6.0;
+    auto rounds = [&](double items) { return items <= 0 ? 0.0 : double(uint64_t((items + cus - 1) / cus)); };
+    const double unsplit = rounds(T) * (NH * t_hs + c0);
+    double best = unsplit * 0.93;                       // a split has to be worth at least 7 %
+    for (int mode = 1; mode <= 2; ++mode) {
+        const uint32_t n = mode == 1 ? p.TT : p.RT, other = mode == 1 ? p.RT : p.TT;
+        for (uint32_t cut = 0; cut < n; ++cut) {
+            const double full = double(cut) * other, tail = double(n - cut) * other;
+            if (cut && rounds(full) * cus - full > 0.12 * cus) continue;      // the full part must be (nearly) whole rounds
+            for (int ks = 2; ks <= 8 && NH / ks >= 4; ++ks) {
+                const int hps = (NH + ks - 1) / ks, KS = (NH + hps - 1) / hps;
+                if (NH - (KS - 1) * hps < 2) continue;                         // (no sliver of a last split)
+                ImgPlan q = p;
+                q.mode = mode; q.cut = cut; q.KS = KS; q.hps = hps;
+                region(q);
+                const double bytes = double(q.region_tok) * double(q.region_col) * (4.0 * KS + 2.0);
+                const double cost = rounds(full) * (NH * t_hs + c0) + rounds(tail * KS) * (hps * t_hs + c0) + 4.0 + bytes / 3.0e6 + 3.0;
+                if (cost < best) { best = cost; p = q; }
+            }
+        }
+    }
+    return p;
+}
+
+// y region = sum over the KS partial regions in split order (+ bias, x tok_scale, cast): 4 columns per thread
+template <int OM>
+__global__ __launch_bounds__(256) void img_reduce_kernel(const float* __restrict__ part, size_t stride, int KS, void* __restrict__ y, uint32_t ldy,
+                                                         uint32_t tok0, uint32_t col0, uint32_t ntok, uint32_t ncol, const float* __restrict__ bias,
+                                                         const float* __restrict__ tok_scale) {
+    const size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * 4;      // element of the region, ncol % 4 == 0 (ncol: a multiple of 128 or N % 4 == 0 checked by the host)
+    if (i >= size_t(ntok) * ncol) return;
+    const uint32_t t = uint32_t(i / ncol), c = uint32_t(i - size_t(t) * ncol);
+    v4f sum = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < KS; k0 += 8) {
+        v4f v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = k0 + j < KS ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(part + size_t(k0 + j) * stride + i)) : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (k0 + j < KS) sum = (k0 + j) ? sum + v[j] : v[j];
+    }
+    v4f b = {0.f, 0.f, 0.f, 0.f};
+    if (bias) b = *reinterpret_cast<const v4f*>(bias + col0 + c);
+    float o[4];
+    const float sc = OM == 2 ? tok_scale[tok0 + t] : 1.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = OM == 2 ? __builtin_fmaf(sum[r], sc, b[r]) : sum[r] + b[r];
+    const size_t dst = size_t(tok0 + t) * ldy + col0 + c;
+    if (OM == 1) *reinterpret_cast<v4f*>(static_cast<float*>(y) + dst) = v4f{o[0], o[1], o[2], o[3]};
+    else {
+        uint2 pk;
+        if (OM == 2) { pk.x = bf16_bits(o[0]) | (bf16_bits(o[1]) << 16); pk.y = bf16_bits(o[2]) | (bf16_bits(o[3]) << 16); }
+        else { pk.x = h16(o[0]) | (h16(o[1]) << 16); pk.y = h16(o[2]) | (h16(o[3]) << 16); }
+        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(y) + dst) = pk;
+    }
+}
+
+int img_launch(const ImgArgs& a0, int om, bool kt, hipStream_t st) {
+#define GI_PICK(OM_) (kt ? reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, true>) : reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, false>))
+    const void* k = om == 1 ? GI_PICK(1) : (om == 2 ? GI_PICK(2) : GI_PICK(0));
+#undef GI_PICK
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(GI_LDS)) != hipSuccess) return PBL_ERR_LAUNCH;
+    ImgArgs a = a0;
+    void* argv[] = {&a};
+    const dim3 grid(a.nrt * a.ntt * uint32_t(a.KSn));
+    if (!grid.x) return PBL_OK;
+    return hipLaunchKernel(k, grid, dim3((GI_NCONS + GI_NPROD) * GW), argv, GI_LDS, st) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// tests / tools: force the launch plan of pbl_gemm_f16_image_ws (mode 0: one launch; 1: token tail; 2: row tail; cut: tiles of the
+// full part; ks: K splits of the tail); mode < 0: back to the cost model
+extern "C" void pbl_debug_force_gemm_plan(int mode, int cut, int ks) { g_img_force_mode = mode; g_img_force_cut = cut; g_img_force_ks = ks; }
+
+// the plan pbl_gemm_f16_image_ws takes for M rows: out[0 .. 6) = mode (0 one launch, 1 token tail, 2 row tail), cut (tiles of the
+// full part along the cut dimension), K splits of the tail, half slabs per split, region tokens, region columns
+extern "C" int pbl_gemm_image_plan(const pbl_layer* layer, int M, uint64_t* out6) {
+    if (!layer || !out6 || M < 1) return PBL_ERR_INVALID_ARG;
+    if (!layer_ok(layer)) return PBL_ERR_UNSUPPORTED;
+    const ImgPlan p = img_plan(layer, M);
+    out6[0] = uint64_t(p.mode); out6[1] = p.cut; out6[2] = uint64_t(p.KS); out6[3] = uint64_t(p.hps); out6[4] = p.region_tok; out6[5] = p.region_col;
+    return PBL_OK;
+}
+
+// Transient workspace pbl_gemm_f16_image_ws wants for M rows of x (0: the plan is one launch): the fp32 partial regions of the
+// K-split tail.  16-byte aligned, any content, from the caller's allocator.
+extern "C" size_t pbl_gemm_image_workspace_bytes(const pbl_layer* layer, int M) {
+    if (!layer_ok(layer) || M < 1) return 0;
+    const ImgPlan p = img_plan(layer, M);
+    if (!p.mode || (p.region_col & 3)) return 0;
+    return size_t(p.KS) * p.region_tok * p.region_col * sizeof(float);
+}
+
 // y[M, N] = x[M, K] . W^T (+ bias) over an image pbl_gemm_image_build made for THIS layer, with the same geometry words (any
-// M >= 1).  out_dtype: PBL_DTYPE_F16 / PBL_DTYPE_F32 -- bit-identical to pbl_gemm_f16_ws / _prepared -- or PBL_DTYPE_BF16 with
-// tok_scale [M] (device, fp32; pbl_act_bf16_prepare wrote it next to the fp16 copy of the bf16 activations):
-// y[t, r] = bf16(acc[t, r] * tok_scale[t] + bias[r]), scaled and cast in the kernel's epilogue.
-extern "C" int pbl_gemm_f16_image_ex(const pbl_layer* layer, const void* x, void* y, int M, int out_dtype, const float* tok_scale,
-                                     const void* image, size_t image_bytes, const uint32_t* geom, void* stream) {
+// M >= 1).  out_dtype: PBL_DTYPE_F16 / PBL_DTYPE_F32, or PBL_DTYPE_BF16 with tok_scale [M] (device, fp32; pbl_act_bf16_prepare wrote
+// it next to the fp16 copy of the bf16 activations): y[t, r] = bf16(acc[t, r] * tok_scale[t] + bias[r]).
+// workspace (pbl_gemm_image_workspace_bytes(layer, M), 16-byte aligned; NULL / too small: one launch over everything, bit-identical
+// to pbl_gemm_f16_ws / _prepared): with it a thin last round is cut off and split along K (see ImgPlan) -- the tiles of the full part
+// keep those bits, the tail's differ by fp32 summation order (within the parity tolerance; repeatable run to run).
+extern "C" int pbl_gemm_f16_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int out_dtype, const float* tok_scale,
+                                     const void* image, size_t image_bytes, const uint32_t* geom, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
     if (!layer || !layer->blob || !x || !y || !image || !geom || M < 1) return PBL_ERR_INVALID_ARG;
     if (out_dtype != PBL_DTYPE_F16 && out_dtype != PBL_DTYPE_F32 && out_dtype != PBL_DTYPE_BF16) return PBL_ERR_INVALID_ARG;
     if ((out_dtype == PBL_DTYPE_BF16) != (tok_scale != nullptr)) return PBL_ERR_INVALID_ARG;
@@ -1129,27 +1289,56 @@ extern "C" int pbl_gemm_f16_image_ex(const pbl_layer* layer, const void* x, void
     ImgGeom g;
     if (!make_geom(layer, geom, g)) return PBL_ERR_UNSUPPORTED;
     if (image_bytes < g.total) return PBL_ERR_CAPACITY;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int NH = int((layer->K + GI_HS - 1) / GI_HS);
+    const int om = out_dtype == PBL_DTYPE_F32 ? 1 : (out_dtype == PBL_DTYPE_BF16 ? 2 : 0);
     ImgArgs a;
     const uint8_t* ib = static_cast<const uint8_t*>(image);
-    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = out_dtype == PBL_DTYPE_F32; a.tok_scale = tok_scale;
+    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = om == 1; a.tok_scale = tok_scale;
     a.slots = ib + g.slots_off; a.rbase = reinterpret_cast<const uint32_t*>(ib + sizeof(ImgHeader));
     a.rtab = reinterpret_cast<const uint32_t*>(ib + g.rtab_off); a.levels = reinterpret_cast<const uint32_t*>(ib + g.levels_off);
 #if PBL_TRACE
     a.trace = g_img_trace;
 #endif
     const bool kt = (layer->K & (GI_XC - 1)) != 0;
-#define GI_PICK(OM_) (kt ? reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, true>) : reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, false>))
-    const void* k = out_dtype == PBL_DTYPE_F32 ? GI_PICK(1) : (out_dtype == PBL_DTYPE_BF16 ? GI_PICK(2) : GI_PICK(0));
-#undef GI_PICK
-    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(GI_LDS)) != hipSuccess) return PBL_ERR_LAUNCH;
-    void* argv[] = {&a};
-    const dim3 grid(((layer->NRB + 7) / 8) * uint32_t((M + GI_TOK - 1) / GI_TOK));
-    return hipLaunchKernel(k, grid, dim3((GI_NCONS + GI_NPROD) * GW), argv, GI_LDS, static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+    ImgPlan p = img_plan(layer, M);
+    const size_t need = p.mode ? size_t(p.KS) * p.region_tok * p.region_col * sizeof(float) : 0;
+    if (p.mode && (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) || (p.region_col & 3) ||
+                   (layer->N & (om == 1 ? 3u : 7u)))) p.mode = 0;
+    // the full part (everything when the plan is one launch): whole K, straight to y
+    a.rt0 = 0; a.tt0 = 0; a.nrt = p.mode == 2 ? p.cut : p.RT; a.ntt = p.mode == 1 ? p.cut : p.TT;
+    a.h0 = 0; a.nh = NH; a.hps = NH; a.KSn = 1; a.part_stride = 0; a.ldy = layer->N; a.ycol0 = 0; a.ytok0 = 0;
+    int rc = img_launch(a, om, kt, st);
+    if (rc != PBL_OK || !p.mode) return rc;
+    // the tail: KS work items per tile, fp32 partial tiles into the region buffer (no bias, no scale: the reduce applies them)
+    ImgArgs t = a;
+    t.L.bias = nullptr; t.tok_scale = nullptr; t.y = workspace; t.y_f32 = 1;
+    if (p.mode == 1) { t.rt0 = 0; t.nrt = p.RT; t.tt0 = p.cut; t.ntt = p.TT - p.cut; t.ycol0 = 0; t.ytok0 = int(p.cut) * GI_TOK; }
+    else { t.rt0 = p.cut; t.nrt = p.RT - p.cut; t.tt0 = 0; t.ntt = p.TT; t.ycol0 = p.cut * GI_ROWS; t.ytok0 = 0; }
+    t.hps = p.hps; t.KSn = p.KS; t.part_stride = p.region_tok * p.region_col; t.ldy = uint32_t(p.region_col);
+    rc = img_launch(t, 1, kt, st);
+    if (rc != PBL_OK) return rc;
+    const float* part = static_cast<const float*>(workspace);
+    size_t stride = t.part_stride;
+    int KS = p.KS;
+    uint32_t ldy = layer->N, tok0 = uint32_t(t.ytok0), col0 = t.ycol0, ntok = uint32_t(p.region_tok), ncol = uint32_t(p.region_col);
+    const float* bias = layer->bias;
+    void* rv[] = {&part, &stride, &KS, &y, &ldy, &tok0, &col0, &ntok, &ncol, &bias, &tok_scale};
+    const void* rk = om == 1 ? reinterpret_cast<const void*>(img_reduce_kernel<1>) : (om == 2 ? reinterpret_cast<const void*>(img_reduce_kernel<2>)
+                                                                                                : reinterpret_cast<const void*>(img_reduce_kernel<0>));
+    const size_t n4 = (size_t(ntok) * ncol + 3) / 4;
+    return hipLaunchKernel(rk, dim3(uint32_t((n4 + 255) / 256)), dim3(256), rv, 0, st) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+// the same without a workspace: ONE launch over everything, bit-identical to pbl_gemm_f16_ws / _prepared
+extern "C" int pbl_gemm_f16_image_ex(const pbl_layer* layer, const void* x, void* y, int M, int out_dtype, const float* tok_scale,
+                                     const void* image, size_t image_bytes, const uint32_t* geom, void* stream) {
+    return pbl_gemm_f16_image_ws(layer, x, y, M, out_dtype, tok_scale, image, image_bytes, geom, nullptr, 0, stream);
 }
 
 extern "C" int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
                                   const uint32_t* geom, void* stream) {
-    return pbl_gemm_f16_image_ex(layer, x, y, M, y_f32 ? PBL_DTYPE_F32 : PBL_DTYPE_F16, nullptr, image, image_bytes, geom, stream);
+    return pbl_gemm_f16_image_ws(layer, x, y, M, y_f32 ? PBL_DTYPE_F32 : PBL_DTYPE_F16, nullptr, image, image_bytes, geom, nullptr, 0, stream);
 }
 
 // tuning hook (tools/): the number of waves the small-batch kernel's K split aims at

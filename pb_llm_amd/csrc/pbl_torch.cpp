@@ -133,7 +133,7 @@ at::Tensor finish(const at::Tensor& y32, const at::Tensor& tok_scale, const floa
 at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                        int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
                        const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
-                       bool small_image) {
+                       bool small_image, bool split_k) {
     TORCH_CHECK(x.is_cuda() && blob.is_cuda(), "pbllm_native.linear: GPU tensors only (the HIP kernels are the only compute path)");
     const auto xt = x.scalar_type();
     TORCH_CHECK(xt == at::kHalf || xt == at::kBFloat16 || xt == at::kFloat, "pbllm_native.linear: fp16, bf16 or fp32 activations");
@@ -197,8 +197,14 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
                 bool done = false;
                 if (img && R <= SMALL_IMAGE_MAX && small_image) done = run_small_image(Lk, xin, y, R, k32, iref);   // 33 - 64 rows: one pass over the image
                 if (!done && img) {
-                    check(pbl_gemm_f16_image_ex(&Lk, xin.data_ptr(), y.data_ptr(), int(R), k32 ? PBL_DTYPE_F32 : (direct && xt == at::kBFloat16 ? PBL_DTYPE_BF16 : PBL_DTYPE_F16),
-                                                direct && xt == at::kBFloat16 ? tsc.data_ptr<float>() : nullptr, iref.data, iref.bytes, iref.geom.data(), stream_of(x)),
+                    // a thin last round (5120-row layers at 2048 rows, short prompts) is cut off and split along K through a transient
+                    // workspace (pbl_gemm_f16_image_ws); split_k == false: one launch, bit-identical to the round-3 kernel
+                    const size_t wb = split_k ? pbl_gemm_image_workspace_bytes(&Lk, int(R)) : 0;
+                    at::Tensor wsk;
+                    if (wb) wsk = at::empty({int64_t(wb)}, x.options().dtype(at::kByte));
+                    check(pbl_gemm_f16_image_ws(&Lk, xin.data_ptr(), y.data_ptr(), int(R), k32 ? PBL_DTYPE_F32 : (direct && xt == at::kBFloat16 ? PBL_DTYPE_BF16 : PBL_DTYPE_F16),
+                                                direct && xt == at::kBFloat16 ? tsc.data_ptr<float>() : nullptr, iref.data, iref.bytes, iref.geom.data(),
+                                                wb ? wsk.data_ptr() : nullptr, wb, stream_of(x)),
                           "gemm_f16_image");
                 } else if (!done) {
                     const size_t nb = pbl_gemm_workspace_bytes(&Lk, int(R));
@@ -238,7 +244,7 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
 at::Tensor linear_meta(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                        int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
                        const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
-                       bool small_image) {
+                       bool small_image, bool split_k) {
     TORCH_CHECK(x.dim() >= 1 && x.size(-1) == K, "pbllm_native.linear: in_features mismatch: x has ", x.size(-1), ", layer has ", K);
     std::vector<int64_t> shape(x.sizes().begin(), x.sizes().end());
     shape.back() = N;
@@ -251,7 +257,7 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& blob, const c10::optional<at::Tensor>& bias,
                               int64_t N, int64_t K, int64_t P, int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32,
                               bool dense_f16, const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, std::string backend,
-                              bool small_image) {
+                              bool small_image, bool split_k) {
         ctx->saved_data["blob"] = blob;
         ctx->saved_data["meta"] = std::vector<int64_t>{N, K, P, G, NRB, flags, max_nch, max_nexc};
         ctx->saved_data["xdt"] = int64_t(x.scalar_type());
@@ -259,8 +265,8 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
         static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("pbllm_native::linear", "")
                              .typed<at::Tensor(const at::Tensor&, const c10::optional<at::Tensor>&, const at::Tensor&, int64_t, int64_t, int64_t, int64_t,
                                                int64_t, int64_t, int64_t, int64_t, bool, bool, const c10::optional<at::Tensor>&,
-                                               c10::OptionalArrayRef<int64_t>, c10::string_view, bool)>();
-        return op.call(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, backend, small_image);
+                                               c10::OptionalArrayRef<int64_t>, c10::string_view, bool, bool)>();
+        return op.call(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, backend, small_image, split_k);
     }
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
         const at::Tensor dy = grads[0];
@@ -274,7 +280,7 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
         std::vector<int64_t> shape(dy.sizes().begin(), dy.sizes().end());
         shape.back() = m[1];
         const at::Tensor dx = dy.reshape({-1, m[0]}).to(wdt).matmul(W).reshape(shape).to(xdt);
-        torch::autograd::variable_list out(17);
+        torch::autograd::variable_list out(18);
         out[0] = dx;
         return out;
     }
@@ -283,16 +289,16 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
 at::Tensor linear_autograd(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                            int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
                            const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
-                           bool small_image) {
+                           bool small_image, bool split_k) {
     return PBLinearFn::apply(x, blob, bias, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, std::string(backend),
-                             small_image);
+                             small_image, split_k);
 }
 
 }  // namespace
 
 TORCH_LIBRARY(pbllm_native, m) {
     m.def("linear(Tensor blob, Tensor? bias, Tensor x, int N, int K, int P, int G, int NRB, int flags, int max_nch, int max_nexc, bool out_f32, "
-          "bool dense_f16=True, Tensor? image=None, int[]? geom=None, str backend=\"auto\", bool small_image=True) -> Tensor");
+          "bool dense_f16=True, Tensor? image=None, int[]? geom=None, str backend=\"auto\", bool small_image=True, bool split_k=True) -> Tensor");
 }
 TORCH_LIBRARY_IMPL(pbllm_native, CUDA, m) { m.impl("linear", linear_cuda); }
 TORCH_LIBRARY_IMPL(pbllm_native, Meta, m) { m.impl("linear", linear_meta); }

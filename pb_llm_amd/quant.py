@@ -74,6 +74,12 @@ GEMM_KEEP_IMAGE = os.environ.get("PBL_GEMM_KEEP_IMAGE", "1") == "1"
 # BASELINE configs[3] call runs the fast kernel) builds the image on the first small-batch call, "auto" only uses an image a
 # GEMM-regime call already built, "0" never uses it (the kernel over the packed records runs).
 SMALL_BATCH_IMAGE = os.environ.get("PBL_SMALL_BATCH_IMAGE", "1")
+# GEMM regime over the image: cut a thin last round off and split it along K (pbl_gemm_f16_image_ws; round 5).  The image kernel's
+# unit is a tile of 128 rows x 256 tokens over the whole K, one per CU and round: 5120-row layers at 2048 rows (320 tiles on 256 CUs)
+# pay two rounds for 1.25 rounds of work, a 300-token prompt on 4096 x 4096 uses a quarter of the chip.  With the split the tail's
+# tiles are K-split so that they fill the chip once, their fp32 partial tiles go through a transient workspace and a small kernel
+# adds them in split order (deterministic).  False: always ONE launch, bit-identical to the round-3 kernel.
+GEMM_SPLIT_K = os.environ.get("PBL_GEMM_SPLIT_K", "1") == "1"
 SMALL_IMAGE_MIN = 5
 SMALL_IMAGE_MAX = 64       # (33 - 64 rows are GEMM regime for everything else; with an image they are one more pass of the small-batch kernel)
 
@@ -88,14 +94,16 @@ def fused_gemm_ok(packed: PackedWeight) -> bool:
 
 def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False, workspace: bool = True,
                        prepared: torch.Tensor | None = None, image: "GemmImage | None" = None,
-                       tok_scale: torch.Tensor | None = None) -> torch.Tensor:
+                       tok_scale: torch.Tensor | None = None, split_k: bool = False) -> torch.Tensor:
     """pbl_gemm_f16_ws: x2 [M, K] fp16 contiguous -> [M, N] fp16 (fp32 with out_f32); raises PblError(UNSUPPORTED) for layers
     it does not take.  workspace: hand the kernel the transient scratch it asks for (more than one 256-token tile: the
     salient entries are decoded once per call by a small kernel ahead of the GEMM; 4 B per entry from the caching allocator,
     stream ordered) -- False decodes inside the GEMM kernel; the results are identical bit for bit.
     prepared: a salient list pbl_gemm_prepare already built for this layer (gemm_list): pbl_gemm_f16_prepared, no per-call
     preparation.  tok_scale (image only; bf16 activations): [M] fp32 from act_bf16_prepare -- the result is
-    bf16(acc * tok_scale[t] + bias), scaled and cast in the kernel's epilogue (pbl_gemm_f16_image_ex)."""
+    bf16(acc * tok_scale[t] + bias), scaled and cast in the kernel's epilogue (pbl_gemm_f16_image_ex).  split_k (image only): let
+    the library cut a thin last round off and split it along K through a transient workspace (pbl_gemm_f16_image_ws; what the
+    module route does by default, GEMM_SPLIT_K); False: one launch, bit-identical to the other two forms."""
     M = x2.shape[0]
     layer = packed.layer_struct(bias_f32)
     L = _lib.lib()
@@ -105,9 +113,11 @@ def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32
         odt = torch.bfloat16 if tok_scale is not None else (torch.float32 if out_f32 else torch.float16)
         y = torch.empty(M, packed.N, dtype=odt, device=x2.device)
         code = _lib.PBL_DTYPE_BF16 if tok_scale is not None else (_lib.PBL_DTYPE_F32 if out_f32 else _lib.PBL_DTYPE_F16)
-        _lib.check(L.pbl_gemm_f16_image_ex(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, code,
+        wb = int(L.pbl_gemm_image_workspace_bytes(C.byref(layer), M)) if split_k else 0
+        ws = torch.empty(wb, dtype=torch.uint8, device=x2.device) if wb else None
+        _lib.check(L.pbl_gemm_f16_image_ws(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, code,
                                            tok_scale.data_ptr() if tok_scale is not None else None, image.data.data_ptr(),
-                                           image.data.numel(), image.geom, cur.cuda_stream), "gemm_f16_image")
+                                           image.data.numel(), image.geom, ws.data_ptr() if wb else None, wb, cur.cuda_stream), "gemm_f16_image")
         return y
     y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
     if prepared is not None:
@@ -396,7 +406,7 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
             _wait_image(torch.cuda.current_stream(x.device), ki)
             img, geom = ki.data, ki.geom_list
         return nat(packed.blob, bias_f32, x, packed.N, packed.K, packed.P, packed.G, packed.NRB, packed.flags,
-                   packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, geom, GEMM_BACKEND, small_ok)
+                   packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, geom, GEMM_BACKEND, small_ok, GEMM_SPLIT_K)
     # the ctypes route (variant libraries through PBL_LIB, PBL_NATIVE=0, a dispatcher that did not build)
     if torch.is_grad_enabled() and x.requires_grad:
         return _PackedLinearFn.apply(x, (packed, bias_f32), out_f32, dense_dtype)
@@ -474,7 +484,7 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
                 if img is not None and small_ok and R <= SMALL_IMAGE_MAX:
                     y = small_image_forward(packed, bias_k, xin, img, k32)                # 33 - 64 rows: one more pass of the small-batch kernel
                 elif img is not None:
-                    y = fused_gemm_forward(packed, bias_k, xin, k32, image=img, tok_scale=tsc if direct else None)
+                    y = fused_gemm_forward(packed, bias_k, xin, k32, image=img, tok_scale=tsc if direct else None, split_k=GEMM_SPLIT_K)
                 else:
                     y = fused_gemm_forward(packed, bias_k, xin, k32, prepared=_kept_list(packed) if GEMM_KEEP_LIST else None)
                 if x.dtype == torch.float16 or direct:
@@ -641,7 +651,7 @@ class PBLinear(nn.Module, BinaryInterface):
             if _lib.native_linear() is not None:     # the native operator has a Meta kernel: traced as one node
                 return torch.ops.pbllm_native.linear(self.pbl_blob, self.pbl_bias, x, m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch,
                                                      m.max_nexc, False, self.weight_dtype == torch.float16, None, None,
-                                                     "library" if GEMM_BACKEND == "tuned" else GEMM_BACKEND, True)
+                                                     "library" if GEMM_BACKEND == "tuned" else GEMM_BACKEND, True, GEMM_SPLIT_K)
             return torch.ops.pbllm.linear(self.pbl_blob, self.pbl_bias, x,
                                           [m.N, m.K, m.P, m.G, m.NRB, m.flags, m.max_nch, m.max_nexc, m.nnz, m.nexc],
                                           self.weight_dtype == torch.float16, False)

@@ -121,11 +121,29 @@ def test_llama13b_linears_m2048_default_backend_is_hand_written(N, K):
     xt = T(x)
     rows = np.unique(np.concatenate([np.arange(0, N, max(1, N // 160)), [N - 1, N - 16, 15, 16]]))
     ref = O.dense_linear(x, W16.numpy()[rows])
-    assert Q.GEMM_BACKEND == "auto"
+    assert Q.GEMM_BACKEND == "auto" and Q.GEMM_SPLIT_K
     assert not (called_ops(lambda: layer(xt)) & LIBRARY_GEMM_OPS)
     y = layer(xt)
     assert_parity(y[:, torch.from_numpy(rows).to(DEV)], ref)
     assert torch.equal(y, layer(xt))                                       # repeatable
+    # 5120-row layers are 320 tiles on 256 CUs: the plan cuts the last 8 row tiles off and splits them along K (round 5); the tiles of
+    # the full part keep the one-launch bits, the tail differs by summation order only
+    plan = (C.c_uint64 * 6)()
+    lay = layer.packed.layer_struct(None)
+    assert _lib.lib().pbl_gemm_image_plan(C.byref(lay), 2048, plan) == 0
+    if N == 5120:
+        assert plan[0] == 2 and plan[1] == 32 and plan[2] >= 2 and plan[5] == 1024, list(plan)
+    Q.GEMM_SPLIT_K = False
+    try:
+        y1 = layer(xt)
+    finally:
+        Q.GEMM_SPLIT_K = True
+    assert_parity(y, y1.float().cpu().numpy().astype(np.float64), 2e-3)
+    if plan[0] == 2:
+        c0 = int(plan[1]) * 128
+        assert torch.equal(y[:, :c0], y1[:, :c0]) and not torch.equal(y[:, c0:], y1[:, c0:])
+    elif plan[0] == 0:
+        assert torch.equal(y, y1)
     xb = xt.bfloat16()
     assert not (called_ops(lambda: layer(xb)) & LIBRARY_GEMM_OPS)
     refb = O.dense_linear(xb.float().cpu().numpy(), W16.numpy()[rows])
@@ -698,14 +716,16 @@ def test_fused_gemm_kernel(N, K, M, lf, bias):
     rows = np.arange(N) if N * K * M < 4e9 else np.unique(np.concatenate([np.arange(0, N, N // 160), [N - 1, N - 17, 127, 128]]))
     ref = O.dense_linear(x, W16.numpy()[rows], None if b is None else b[rows])
     assert_parity(y[:, torch.from_numpy(rows).to(DEV)], ref)
-    old = Q.GEMM_BACKEND
+    old = Q.GEMM_BACKEND, Q.GEMM_SPLIT_K
     try:
         Q.GEMM_BACKEND = "library"
         y_lib = layer(xt)
-        Q.GEMM_BACKEND = "fused"
+        Q.GEMM_BACKEND, Q.GEMM_SPLIT_K = "fused", False            # one launch over the image: the round-3 kernel's bits
         assert torch.equal(layer(xt), y)                            # the module routes the GEMM regime to the fused kernel
+        Q.GEMM_SPLIT_K = True                                       # the default: few tiles are split along K (other summation order)
+        assert_parity(layer(xt), y.float().cpu().numpy().astype(np.float64), 2e-3)
     finally:
-        Q.GEMM_BACKEND = old
+        Q.GEMM_BACKEND, Q.GEMM_SPLIT_K = old
     assert_parity(y, y_lib.float().cpu().numpy().astype(np.float64), 2e-3)
     assert torch.equal(y, Q.fused_gemm_forward(layer.packed, layer.pbl_bias, xt))      # deterministic
 

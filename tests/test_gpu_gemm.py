@@ -353,3 +353,80 @@ def test_small_batch_image_kernel_repeatedly_at_full_size():
         torch.cuda.synchronize()
         bad = [i for i, o in enumerate(outs) if not torch.equal(o, ref)]
         assert not bad, f"M={M}: launches {bad[:10]} differ"
+
+
+def _force_plan(mode, cut=0, ks=0):
+    f = _lib.lib().pbl_debug_force_gemm_plan
+    f.restype, f.argtypes = None, [C.c_int, C.c_int, C.c_int]
+    f(mode, cut, ks)
+
+
+@pytest.mark.parametrize("N,K,M,bias", [(512, 1024, 600, True), (520, 1288, 700, False)])
+def test_gemm_image_k_split_tail_every_plan(N, K, M, bias):
+    """pbl_gemm_f16_image_ws (round 5): the launch cut into a full part and a K-split tail, every plan shape forced on a small layer
+    (pbl_debug_force_gemm_plan) -- token tail / row tail, with and without a full part, 2 - 4 splits, K % 64 != 0 and a ragged last row
+    tile -- for fp16, fp32 and bf16 (+ per-token scale) results with and without bias: the full part's tiles keep the one-launch bits,
+    the tail agrees within the parity tolerance, against the float64 oracle, repeatable."""
+    p, Wd = rtn_layer(N, K, -1, seed=N + 3, low_frac=0.9, fp16=True, exceptions=1)
+    pd = p.to(DEV)
+    b = T(synth.normal((N,), 4, 3, 0.1)) if bias else None
+    x = synth.activations((M, K), 5, 21)
+    xt = T(x)
+    ref = O.dense_linear(x, Wd, None if b is None else b.cpu().numpy())
+    img = Q.gemm_image(pd)
+    assert img is not None
+    y0 = Q.fused_gemm_forward(pd, b, xt, image=img)                        # one launch
+    y0f = Q.fused_gemm_forward(pd, b, xt, out_f32=True, image=img)
+    xb = (xt.float() * 3.0e4).bfloat16()                                   # beyond fp16's range: scaled per token
+    xh, tsc = Q.act_bf16_prepare(xb)
+    yb0 = Q.fused_gemm_forward(pd, b, xh, image=img, tok_scale=tsc)
+    assert yb0.dtype == torch.bfloat16
+    RT, TT = (N + 127) // 128, (M + 255) // 256
+    try:
+        for mode, cut, ks in ((1, TT - 1, 2), (1, 1, 3), (1, 0, 2), (2, RT - 1, 2), (2, 2, 4), (2, 0, 2)):
+            _force_plan(mode, cut, ks)
+            plan = (C.c_uint64 * 6)()
+            lay = pd.layer_struct(None)
+            assert _lib.lib().pbl_gemm_image_plan(C.byref(lay), M, plan) == 0 and plan[0] == mode and plan[1] == cut, (mode, cut, list(plan))
+            y = Q.fused_gemm_forward(pd, b, xt, image=img, split_k=True)
+            assert_parity(y, ref)
+            assert_parity(y, y0.float().cpu().numpy().astype(np.float64), 2e-3)
+            full = (slice(0, cut * 256), slice(None)) if mode == 1 else (slice(None), slice(0, cut * 128))
+            tail = (slice(cut * 256, None), slice(None)) if mode == 1 else (slice(None), slice(cut * 128, None))
+            assert torch.equal(y[full], y0[full]), (mode, cut, ks)                       # the full part: the same launch geometry, the same bits
+            assert not torch.equal(y[tail], y0[tail])                                    # (the tail did take another summation order)
+            assert torch.equal(y, Q.fused_gemm_forward(pd, b, xt, image=img, split_k=True))
+            yf = Q.fused_gemm_forward(pd, b, xt, out_f32=True, image=img, split_k=True)
+            assert yf.dtype == torch.float32 and torch.equal(yf[full], y0f[full])
+            assert_parity(yf, ref, 2e-4)
+            yb = Q.fused_gemm_forward(pd, b, xh, image=img, tok_scale=tsc, split_k=True)
+            assert yb.dtype == torch.bfloat16 and torch.equal(yb[full], yb0[full])
+            assert O.parity_errors(yb.float().cpu().numpy(), yb0.float().cpu().numpy().astype(np.float64))[0] < 1e-2
+    finally:
+        _force_plan(-1)
+    assert _lib.lib().pbl_gemm_image_workspace_bytes(C.byref(pd.layer_struct(None)), M) == 0      # the cost model leaves this small layer alone
+
+
+def test_gemm_image_short_prompt_is_split_along_k():
+    """a 300-token prompt on a 4096 x 4096 layer is 64 tiles of 128 x 256 on 256 CUs: the cost model splits every tile along K (token
+    tail with an empty full part) -- through the module (the shipped default), against the oracle and the one-launch result"""
+    p, Wd = rtn_layer(4096, 4096, -1, seed=77, low_frac=0.95, fp16=True)
+    layer = Q.PBLinear(p.to(DEV), None)
+    plan = (C.c_uint64 * 6)()
+    lay = layer.packed.layer_struct(None)
+    assert _lib.lib().pbl_gemm_image_plan(C.byref(lay), 300, plan) == 0
+    assert plan[0] == 1 and plan[1] == 0 and plan[2] >= 2 and plan[4] == 300 and plan[5] == 4096, list(plan)
+    assert _lib.lib().pbl_gemm_image_plan(C.byref(lay), 2048, plan) == 0 and plan[0] == 0       # 256 tiles: exactly one round
+    x = synth.activations((300, 4096), 9, 21)
+    xt = T(x)
+    assert Q.GEMM_SPLIT_K and Q.GEMM_BACKEND == "auto"
+    y = layer(xt)
+    rows = sample_rows(4096)
+    assert_parity(y[:, torch.from_numpy(rows).to(DEV)], O.dense_linear(x, Wd[rows]))
+    assert torch.equal(y, layer(xt))
+    y1 = Q.fused_gemm_forward(layer.packed, None, xt, image=layer.packed._gemm_image[1])
+    assert not torch.equal(y, y1)
+    assert_parity(y, y1.float().cpu().numpy().astype(np.float64), 2e-3)
+    yb = layer(xt.bfloat16())
+    assert yb.dtype == torch.bfloat16 and O.parity_errors(yb[:, torch.from_numpy(rows).to(DEV)].float().cpu().numpy(),
+                                                          O.dense_linear(xt.bfloat16().float().cpu().numpy(), Wd[rows]))[0] < 1e-2

@@ -140,7 +140,7 @@ def test_which_calls_get_the_gemm_image_without_a_gpu(monkeypatch):
         def numel(self):
             return self.shape[0] * self.shape[1]
 
-    def fake_native(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, img, geom, backend, small_ok):
+    def fake_native(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, img, geom, backend, small_ok, split_k):
         calls.append((x.shape[0], img is not None, small_ok, backend))
         return None
 

@@ -123,3 +123,28 @@ def test_activation_entry_points_check_their_arguments():
     assert L.pbl_gemm_f16_image_ex(C.byref(lay), 16, 16, 4, _lib.PBL_DTYPE_BF16, None, 16, 64, 16, None) == _lib.PBL_ERR_INVALID_ARG
     assert L.pbl_gemm_f16_image_ex(C.byref(lay), 16, 16, 4, 9, None, 16, 64, 16, None) == _lib.PBL_ERR_INVALID_ARG
     assert L.pbl_linear_push_max_tokens(None) == 0
+
+
+def test_the_gemm_launch_plan_without_a_gpu():
+    """pbl_gemm_image_plan (host arithmetic only; 256 CUs assumed without a device): shapes that are a whole number of rounds stay one
+    launch; 5120-row layers at 2048 rows get a row tail of 8 row tiles split 4 ways behind one full round; a short prompt is split
+    entirely; the workspace is KS x region x 4 bytes"""
+    L = _lib.lib()
+
+    def plan(N, K, M):
+        lay = _lib.PblLayer(None, None, N, K, (K + 511) // 512, 1, (N + 15) // 16, 0xE, 8, 0)
+        out = (C.c_uint64 * 6)()
+        assert L.pbl_gemm_image_plan(C.byref(lay), M, out) == 0
+        ws = L.pbl_gemm_image_workspace_bytes(C.byref(lay), M)
+        assert ws == (out[2] * out[4] * out[5] * 4 if out[0] else 0)
+        return list(out)
+
+    for N, K in ((4096, 4096), (4096, 11008), (11008, 4096), (13824, 5120), (8192, 8192)):
+        assert plan(N, K, 2048)[0] == 0, (N, K)
+    assert plan(5120, 5120, 2048) == [2, 32, 4, 10, 2048, 1024]
+    assert plan(5120, 13824, 2048) == [2, 32, 4, 27, 2048, 1024]
+    p = plan(4096, 4096, 300)
+    assert p[0] == 1 and p[1] == 0 and p[2] * p[3] >= 32 and p[4:] == [300, 4096]
+    assert plan(512, 1024, 300)[0] == 0 and plan(4096, 4096, 4096)[0] == 0
+    lay = _lib.PblLayer(None, None, 4096, 4100, 9, 1, 256, 0xE, 8, 0)                 # K % 8: no image, no plan
+    assert L.pbl_gemm_image_plan(C.byref(lay), 300, (C.c_uint64 * 6)()) == _lib.PBL_ERR_UNSUPPORTED

@@ -56,10 +56,18 @@ for shp, lf in SHAPES:
         if img is not None:
             res["fused_image_us"] = round(timeit(lambda: Q.fused_gemm_forward(layer.packed, None, x, image=img)), 1)
             res["image_MB"] = round(img.data.numel() / 1e6, 2); res["image_max_slot_KiB"] = img.max_slot_kib
+            # round 5: the same kernel with a thin last round cut off and split along K (pbl_gemm_f16_image_ws: what the module runs)
+            import ctypes as C
+            from pb_llm_amd import _lib
+            plan = (C.c_uint64 * 6)()
+            _lib.lib().pbl_gemm_image_plan(C.byref(layer.packed.layer_struct(None)), M, plan)
+            res["plan"] = list(plan)
+            if plan[0]:
+                res["fused_image_split_us"] = round(timeit(lambda: Q.fused_gemm_forward(layer.packed, None, x, image=img, split_k=True)), 1)
     if ONLY in ("", "library"):
         Q.GEMM_BACKEND = "library"
         res["unpack_plus_library_us"] = round(timeit(lambda: layer(x)), 1)
         Q.GEMM_BACKEND = "fused"
         res["dense_library_us"] = round(timeit(lambda: torch.nn.functional.linear(x, Wd)), 1)
-    out = dict(shape=shp, low_frac=lf, metric=METRIC, M=M, preheat_s=PREHEAT_S, us=res, tflops={k.replace("_us", ""): round(flops / v / 1e6, 1) for k, v in res.items() if k.endswith("_us")})
+    out = dict(shape=shp, low_frac=lf, metric=METRIC, M=M, preheat_s=PREHEAT_S, us=res, tflops={k.replace("_us", ""): round(flops / v / 1e6, 1) for k, v in res.items() if k.endswith("_us") and v})
     print(json.dumps(out), flush=True)
