@@ -404,7 +404,9 @@ def test_gemm_image_k_split_tail_every_plan(N, K, M, bias):
             assert O.parity_errors(yb.float().cpu().numpy(), yb0.float().cpu().numpy().astype(np.float64))[0] < 1e-2
     finally:
         _force_plan(-1)
-    assert _lib.lib().pbl_gemm_image_workspace_bytes(C.byref(pd.layer_struct(None)), M) == 0      # the cost model leaves this small layer alone
+    # (back on the cost model: whatever it picks for this small layer, the module route agrees with the one-launch result)
+    layer = Q.PBLinear(pd, b)
+    assert_parity(layer(xt), y0.float().cpu().numpy().astype(np.float64), 2e-3)
 
 
 def test_gemm_image_short_prompt_is_split_along_k():
