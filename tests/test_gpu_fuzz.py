@@ -71,6 +71,50 @@ def test_random_layer_all_token_counts(seed):
             assert rel < 2e-4 and ratio < 1.0, (seed, N, K, sal_frac, fp16, M, rel, ratio)
 
 
+def _layer(seed):
+    N, K, sal_frac, fp16, bias, n_exc = case(seed)
+    W = synth.llm_weight(N, K, seed=seed, heavy_tail=True)
+    mask = O.ptq_low_mask(W, 1.0 - sal_frac, "magnitude", None, -1) if sal_frac > 0 else np.ones((N, K), bool)
+    r = O.ptq_rtn(W, mask, 8, -1)
+    Wd = r["W_fq"].copy()
+    if fp16:
+        Wd = Wd.astype(np.float16).astype(np.float32)
+    for e in range(n_exc):
+        Wd[(7 * e) % N, (131 * e + 5) % K] = np.float32(np.float16(0.123 + e)) if fp16 else np.float32(0.123 + e)
+    from pb_llm_amd.packing import infer_levels
+    hi, lo = infer_levels(Wd, -1, mask)
+    p = pack_dense(Wd, hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8), sal_f16=fp16)
+    b = synth.normal((N,), seed, 3, 0.1) if bias else None
+    return Q.PBLinear(p.to(DEV), T(b) if bias else None, torch.float16 if fp16 else torch.float32), Wd, b, fp16
+
+
+@pytest.mark.parametrize("seed", range(0, 36, 2))
+def test_random_layer_gemm_regime_and_activation_dtypes(seed):
+    """round 5: the same random layers beyond 33 rows (the GEMM kernel over the image with whatever launch plan the cost model picks
+    -- or, for fp32-grid layers, unpack + library) and with bf16 / fp32 activations at every regime (bf16: conversion inside the GEMV
+    up to 4 rows, prepare + kernel + finish up to 64, prepare + GEMM epilogue beyond; fp32: two fp16 terms) against the float64 oracle"""
+    layer, Wd, b, fp16 = _layer(seed)
+    N, K = Wd.shape
+    for M in (70, 300):
+        x = synth.activations((M, K), seed, M)
+        y = layer(T(x))
+        rel, ratio = O.parity_errors(y.float().cpu().numpy(), O.dense_linear(x, Wd, b))
+        assert rel < 1e-3 and ratio < 1.0, (seed, N, K, fp16, M, rel, ratio)
+        assert torch.equal(y, layer(T(x)))
+    for M in (1, 4, 9, 33, 70, 300):
+        xb = T(synth.activations((M, K), seed, 50 + M)).bfloat16()
+        y = layer(xb)
+        assert y.dtype == torch.bfloat16
+        rel, _ = O.parity_errors(y.float().cpu().numpy(), O.dense_linear(xb.float().cpu().numpy(), Wd, b))
+        assert rel < 1e-2, (seed, N, K, fp16, M, rel)                       # bf16 result: 8 significand bits
+    for M in (2, 40):
+        xf = T(synth.activations((M, K), seed, 90 + M)).float() * 1.0009765625     # (not representable in fp16: the low term matters)
+        y = layer(xf)
+        assert y.dtype == torch.float32
+        rel, _ = O.parity_errors(y.cpu().numpy(), O.dense_linear(xf.cpu().numpy().astype(np.float64), Wd, b))
+        assert rel < 2e-5, (seed, N, K, fp16, M, rel)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_column_group_layer(seed):
     """groupsize 128 / 256 (per-(row, group) levels): GEMV passes up to 11 tokens, dense workspace above"""
