@@ -153,14 +153,20 @@ class _FusedMember(nn.Module):
     def forward(self, x):
         g = self._group[0]
         rows = x.numel() // x.shape[-1]
-        if rows > 4 or not x.is_cuda or (torch.is_grad_enabled() and x.requires_grad) or \
-                not (x.dtype == torch.float16 or (x.dtype == torch.bfloat16 and g.fused.bf16_ok)):
+        if not x.is_cuda or (torch.is_grad_enabled() and x.requires_grad):
+            return self.own(x)
+        fused_ok = rows <= 4 and (x.dtype == torch.float16 or (x.dtype == torch.bfloat16 and g.fused.bf16_ok))
+        # batched decode (5 .. MERGE_MAX_ROWS rows, any activation dtype): ONE call of the row-wise concatenation of the members
+        # (packing.concat_rows: a record is 16 rows with everything it needs inside it) instead of one small-batch launch + reduce
+        # per projection
+        merged_ok = not fused_ok and g.merge_batched and 4 < rows <= g.MERGE_MAX_ROWS
+        if not (fused_ok or merged_ok):
             return self.own(x)
         if g.x_ref is x and g.x_version == x._version and self._index in g.pending:     # each launch serves each member once
             g.pending.discard(self._index)
             g.served += 1
             return g.outs[self._index].reshape(*x.shape[:-1], self.out_features)
-        g.launch(x, rows, self._index)
+        g.launch(x, rows, self._index, merged=merged_ok)
         return g.outs[self._index].reshape(*x.shape[:-1], self.out_features)
 
 
@@ -168,12 +174,16 @@ class _FusedGroup:
     """One fused launch (runtime.FusedGemv) over the member PBLinears.  The launch descriptors snapshot the members' blobs
     (device pointers, LDS sizing): they are rebuilt when a member's blob moved or was rewritten (.to(), load_state_dict)."""
     SOLO_WARN_AFTER = 32
+    MERGE_MAX_ROWS = 64            # the small-batch kernel's range: beyond it a merged layer has nothing on its members (same tiles, same rounds)
 
-    def __init__(self, mods: list[PBLinear]):
+    def __init__(self, mods: list[PBLinear], merge_batched: bool = True):
         self.mods = mods
         self.x_ref, self.x_version, self.outs, self.pending = None, -1, None, set()
-        self.launches = self.served = self.solo_launches = 0
+        self.launches = self.served = self.solo_launches = self.merged_launches = 0
         self._warned = False
+        self.merged = None          # the members as ONE PBLinear (rows concatenated), built on the first batched call
+        self.merge_batched = merge_batched and all(m.out_features % 16 == 0 for m in mods[:-1]) and \
+            len({(m.packed.K, m.packed.G, m.packed.flags) for m in mods}) == 1
         self._build()
 
     def _stamp(self):
@@ -184,9 +194,24 @@ class _FusedGroup:
         from .runtime import FusedGemv
         dev = self.mods[0].pbl_blob.device
         self.fused = FusedGemv([m.packed for m in self.mods], [m.pbl_bias for m in self.mods], dev)
+        self.merged = None
         self.stamp = self._stamp()
 
-    def launch(self, x, rows, index):
+    def _merged(self) -> PBLinear:
+        if self.merged is None:
+            from .packing import concat_rows
+            biases = [m.pbl_bias for m in self.mods]
+            bias = None
+            if any(b is not None for b in biases):
+                dev = self.mods[0].pbl_blob.device
+                bias = torch.cat([b if b is not None else torch.zeros(m.out_features, device=dev) for b, m in zip(biases, self.mods)])
+            self.merged = PBLinear(concat_rows([m.packed for m in self.mods]), bias, self.mods[0].weight_dtype)
+            self.offs = [0]
+            for m in self.mods:
+                self.offs.append(self.offs[-1] + m.out_features)
+        return self.merged
+
+    def launch(self, x, rows, index, merged: bool = False):
         if self.pending and self.launches and len(self.pending) == len(self.mods) - 1:
             self.solo_launches += 1          # the previous launch served nobody but its caller
             if self.solo_launches == self.SOLO_WARN_AFTER and not self._warned:
@@ -196,7 +221,12 @@ class _FusedGroup:
                               "not pass one tensor object to its q/k/v (gate/up) projections; fuse_decode_ gains nothing here")
         if self._stamp() != self.stamp:
             self._build()
-        self.outs = self.fused(x.reshape(rows, x.shape[-1]).contiguous())
+        if merged:
+            y = self._merged()(x.reshape(rows, x.shape[-1]))
+            self.outs = [y[:, self.offs[i]:self.offs[i + 1]] for i in range(len(self.mods))]
+            self.merged_launches += 1
+        else:
+            self.outs = self.fused(x.reshape(rows, x.shape[-1]).contiguous())
         self.x_ref, self.x_version = x, x._version
         self.pending = set(range(len(self.mods))) - {index}
         self.launches += 1
@@ -205,11 +235,14 @@ class _FusedGroup:
 FUSE_SETS = (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))     # LLaMA naming (HF)
 
 
-def fuse_decode_(model: nn.Module, sets=FUSE_SETS) -> int:
+def fuse_decode_(model: nn.Module, sets=FUSE_SETS, merge_batched: bool = True) -> int:
     """Decode-time fusion: in every module that holds all the projections of a set as PBLinears with one
     in_features (HF LlamaAttention: q/k/v_proj; LlamaMLP: gate/up_proj), replace them by members of one fused launch.
     7 launches per decoder layer become 4.  Returns the number of groups created.  The caller this serves is the token
-    loop of gptq_pb/eval_ppl_utils.py:55-64 / qat/eval_after_qat.py:11-33 at batch 1."""
+    loop of gptq_pb/eval_ppl_utils.py:55-64 / qat/eval_after_qat.py:11-33 at batch 1.
+    merge_batched (round 5): a decode BATCH (5 - 64 rows) runs each group as ONE call of the members' row-wise concatenation
+    (packing.concat_rows; built on the first such call, costs the members' packed bytes once more plus its GEMM image) instead of
+    one small-batch launch + reduce per projection."""
     n = 0
     for mod in list(model.modules()):
         for names in sets:
@@ -218,7 +251,7 @@ def fuse_decode_(model: nn.Module, sets=FUSE_SETS) -> int:
                 continue
             if len({m_.in_features for m_ in subs}) != 1 or not subs[0].pbl_blob.is_cuda:
                 continue
-            grp = _FusedGroup(subs)
+            grp = _FusedGroup(subs, merge_batched)
             for i, (nm, m_) in enumerate(zip(names, subs)):
                 setattr(mod, nm, _FusedMember(grp, i, m_))
             n += 1

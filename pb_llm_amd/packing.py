@@ -83,6 +83,50 @@ class PackedWeight:
         return PackedWeight(blob, h.N, h.K, h.P, h.G, h.NRB, h.flags, h.max_nch, h.max_nexc, h.nnz, h.nexc)
 
 
+def concat_rows(parts: "list[PackedWeight]") -> PackedWeight:
+    """ONE packed layer whose output rows are the rows of `parts` in order (q | k | v, gate | up: projections that read the same
+    activation; the reference calls them as separate nn.Linear modules, gptq_pb/eval_ppl_utils.py:55-64 through the HF attention /
+    MLP blocks).  A record is 16 output rows with everything it needs inside it, so this is byte surgery, not re-packing: the
+    records are copied behind one another and the record table is rebuilt with shifted offsets -- on whatever device the blobs live
+    on.  Needs equal in_features, column groups and flags, and every part but the last a whole number of 16-row records.  The
+    result unpacks to the row-wise concatenation of the parts' matrices, bit for bit."""
+    if not parts:
+        raise ValueError("nothing to concatenate")
+    p0 = parts[0]
+    for p in parts:
+        if (p.K, p.G, p.P, p.flags) != (p0.K, p0.G, p0.P, p0.flags) or p.blob.device != p0.blob.device:
+            raise _lib.PblError("concat_rows: parts must share in_features, column groups, flags and device")
+    for p in parts[:-1]:
+        if p.N % 16:
+            raise _lib.PblError("concat_rows: every part but the last must be a whole number of 16-row records")
+    NRB = sum(p.NRB for p in parts)
+    N = sum(p.N for p in parts)
+    _check_limits(N, p0.K, p0.G)
+    rec0 = (80 + 16 * (NRB + 1) + 127) & ~127
+    dev = p0.blob.device
+    infos, recs, cur = [], [], rec0
+    for p in parts:
+        r0 = (80 + 16 * (p.NRB + 1) + 127) & ~127                        # where this part's records start
+        info = p.blob[80:80 + 16 * p.NRB].view(torch.int32).reshape(p.NRB, 4).clone()
+        info[:, 0] += (cur - r0) // 16                                   # off16: record offsets in units of 16 bytes (both multiples of 128)
+        infos.append(info)
+        recs.append(p.blob[r0:])
+        cur += p.nbytes - r0
+    if cur // 16 >= 1 << 31:
+        raise _lib.PblError("concat_rows: the concatenated blob exceeds the record table's 32-bit offsets")
+    infos.append(torch.tensor([[cur // 16, 0, 0, 0]], dtype=torch.int32, device=dev))
+    hdr = _lib.PblBlobHeader.from_buffer_copy(bytes(p0.blob[:80].cpu().numpy()))
+    hdr.N, hdr.NRB = N, NRB
+    hdr.max_nch, hdr.max_nexc = max(p.max_nch for p in parts), max(p.max_nexc for p in parts)
+    hdr.nnz, hdr.nexc, hdr.blob_bytes = sum(p.nnz for p in parts), sum(p.nexc for p in parts), cur
+    head = torch.zeros(rec0, dtype=torch.uint8, device=dev)
+    head[:80] = torch.frombuffer(bytearray(bytes(hdr)), dtype=torch.uint8).to(dev)
+    table = torch.cat(infos, 0).contiguous().view(torch.uint8).reshape(-1)
+    head[80:80 + table.numel()] = table
+    blob = torch.cat([head] + recs)
+    return PackedWeight(blob, N, p0.K, p0.P, p0.G, NRB, p0.flags, hdr.max_nch, hdr.max_nexc, hdr.nnz, hdr.nexc)
+
+
 MAX_IN_FEATURES = 32767          # 16-bit column indices in the salient list (include/pbl.h, "Limits")
 MAX_OUT_FEATURES = 1 << 24
 

@@ -637,6 +637,71 @@ def test_fused_decode_and_graph_replay_bit_for_bit():
             assert torch.equal(g.replay(tok), plain(tok, use_cache=False).logits), t
 
 
+def test_batched_decode_runs_the_projections_as_one_merged_layer():
+    """round 5: with fuse_decode_ a decode BATCH (5 - 64 rows) runs q/k/v (gate/up) as ONE call of their row-wise concatenation
+    (packing.concat_rows on the device: byte surgery, validated; harness._FusedGroup.merged) -- one small-batch launch + reduce per
+    group instead of one per projection.  The merged layer's blob equals the host-side concatenation byte for byte, its rows are
+    the members' rows (against the oracle; another K split than the members' own launches, so tolerance, not bits), a model's
+    logits at 16 and 48 rows agree with the unfused model, biases are carried, 2 rows still take the fused GEMV and 300 rows the
+    members' own kernels."""
+    import copy
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from pb_llm_amd import harness as H
+    from pb_llm_amd.packing import concat_rows
+    ps, Ws, bs = [], [], []
+    for i, N in enumerate((96, 160, 64)):
+        W = synth.llm_weight(N, 1024, seed=30 + i)
+        mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        lay = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), torch.from_numpy(synth.normal((N,), 7 + i, 3, 0.1)) if i != 1 else None,
+                                    torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
+        ps.append(lay); Ws.append(r["W_fq"].astype(np.float16).astype(np.float32)); bs.append(lay.pbl_bias)
+    host = concat_rows([l.packed for l in ps])
+    devl = [l.to(DEV) for l in ps]
+    onde = concat_rows([l.packed for l in devl])
+    assert torch.equal(onde.blob.cpu(), host.blob) and PackedWeight.from_blob(onde.blob).NRB == 20
+    grp = H._FusedGroup(devl)
+    x = synth.activations((16, 1024), 3, 21)
+    xt = T(x)
+    grp.launch(xt, 16, 0, merged=True)
+    for o, W, b in zip(grp.outs, Ws, bs):
+        assert_parity(o, O.dense_linear(x, W, None if b is None else b.cpu().numpy()))
+    assert grp.merged.pbl_bias is not None and grp.merged_launches == 1
+    # model level
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8,
+                      num_key_value_heads=8, vocab_size=1000, max_position_embeddings=256)
+    model = LlamaForCausalLM(cfg).half().eval()
+
+    def producer(name, W):
+        Wn = W.float().numpy()
+        mask = O.ptq_low_mask(Wn, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(Wn, mask, 8, -1)
+        return dict(W_fq=torch.from_numpy(r["W_fq"]), low_mask=torch.from_numpy(mask), hscale=r["hscale"], hzero=r["hzero"])
+
+    side = H.quantize_dense_(model, producer)
+    plain = H.to_pb_(model, side).to(DEV)
+    fused = copy.deepcopy(plain)
+    assert H.fuse_decode_(fused) == 4
+    ids = torch.from_numpy((synth.uniform01(320, 7, 1) * 1000).astype(np.int64)).view(1, -1).to(DEV)
+    g0 = fused.model.layers[0].self_attn.q_proj._group[0]
+    with torch.no_grad():
+        for T_ in (16, 48):                                                 # a batch of decode rows: the merged layers
+            a, b = fused(ids[:, :T_], use_cache=False).logits.float(), plain(ids[:, :T_], use_cache=False).logits.float()
+            assert float((a - b).abs().max() / b.abs().max()) < 5e-3, T_
+        assert g0.merged is not None and g0.merged_launches == 2 and g0.served >= 4
+        n_merged = g0.merged_launches
+        assert torch.equal(fused(ids[:, :2], use_cache=False).logits, plain(ids[:, :2], use_cache=False).logits)      # the fused GEMV launch
+        assert torch.equal(fused(ids[:, :300], use_cache=False).logits, plain(ids[:, :300], use_cache=False).logits)  # prefill: the members' own kernels
+        assert g0.merged_launches == n_merged
+        ab = fused(ids[:, :16], use_cache=False).logits                     # (bf16 hidden states would take the same path; fp16 here)
+        assert torch.equal(ab, fused(ids[:, :16], use_cache=False).logits)
+    nofuse = copy.deepcopy(plain)
+    assert H.fuse_decode_(nofuse, merge_batched=False) == 4
+    with torch.no_grad():
+        assert torch.equal(nofuse(ids[:, :16], use_cache=False).logits, plain(ids[:, :16], use_cache=False).logits)   # off: the members' own launches
+
+
 def test_fused_members_in_any_call_order_and_after_moves():
     """harness._FusedMember: whichever member is called first launches the group, the others are served only for the SAME
     tensor object (held by the group, so a recycled device address cannot match); followers called before the leader,

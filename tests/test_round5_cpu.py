@@ -148,3 +148,36 @@ def test_the_gemm_launch_plan_without_a_gpu():
     assert plan(512, 1024, 300)[0] == 0 and plan(4096, 4096, 4096)[0] == 0
     lay = _lib.PblLayer(None, None, 4096, 4100, 9, 1, 256, 0xE, 8, 0)                 # K % 8: no image, no plan
     assert L.pbl_gemm_image_plan(C.byref(lay), 300, (C.c_uint64 * 6)()) == _lib.PBL_ERR_UNSUPPORTED
+
+
+def test_concat_rows_is_byte_surgery_that_validates():
+    """packing.concat_rows: q | k | v as ONE packed layer without re-packing -- records copied behind one another, record table
+    rebuilt; the result passes the structural validation (pbl_blob_describe), and both the host unpacker and the independent
+    decoder read the row-wise concatenation of the parts, bit for bit; mismatched parts are refused"""
+    import numpy as np
+    from oracle import pb_oracle as O
+    from oracle import pb_format_ref as FR
+    from pb_llm_amd import synth
+    from pb_llm_amd.packing import PackedWeight, concat_rows, infer_levels, pack_dense
+    parts, Ws = [], []
+    for i, (N, K) in enumerate([(64, 1024), (32, 1024), (40, 1024)]):       # the last part may end in a partial record
+        W = synth.llm_weight(N, K, seed=i + 1, heavy_tail=True)
+        mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        Wd = r["W_fq"].astype(np.float16).astype(np.float32)
+        if i == 1:
+            Wd[3, 77] = 0.4321                                              # an exception
+        hi, lo = infer_levels(Wd, -1, mask)
+        parts.append(pack_dense(Wd, hi, lo, r["hscale"], r["hzero"], (~mask).astype(np.uint8), sal_f16=True))
+        Ws.append(Wd)
+    m = concat_rows(parts)
+    v = PackedWeight.from_blob(m.blob)
+    assert (v.N, v.K, v.NRB, v.max_nch, v.max_nexc, v.nnz, v.nexc) == (136, 1024, 9, m.max_nch, 1, sum(p.nnz for p in parts), 1)
+    want = np.concatenate(Ws, 0)
+    assert np.array_equal(m.unpack().numpy(), want) and np.array_equal(FR.decode(m.blob.numpy()), want)
+    assert concat_rows(parts[:1]).blob.equal(parts[0].blob)                 # one part: the same bytes
+    with pytest.raises(_lib.PblError):
+        concat_rows([parts[2], parts[0]])                                   # 40 rows in front: not a whole number of records
+    other = pack_dense(Ws[0][:, :512], *infer_levels(Ws[0][:, :512], -1, None))
+    with pytest.raises(_lib.PblError):
+        concat_rows([parts[0], other])                                      # another in_features

@@ -55,6 +55,45 @@ def main():
     print(json.dumps(dict(mode="decode M=1, 4 launches per decoder layer (hipGraph)", us_per_decoder_layer=round(us_layer, 2),
                           packed_MB_per_layer=round(layer_bytes / 1e6, 1), alg_GBps=round(alg / us_layer / 1e3),
                           tokens_per_s_32_layers_linears_only=round(1e6 / (32 * us_layer)))), flush=True)
+    # batched decode (M = 16 rows per forward): seven separate small-batch calls per decoder layer vs q|k|v and gate|up as ONE merged
+    # layer each (packing.concat_rows, round 5) -- both captured in a hipGraph, linears only
+    from pb_llm_amd.packing import concat_rows
+    Mb = int(os.environ.get("PBL_BENCH_MB", 16))
+    xb = torch.from_numpy(synth.activations((Mb, H), 5, 21)).to(dev); xbi = torch.from_numpy(synth.activations((Mb, I), 6, 21)).to(dev)
+    sep, mer = [], []
+    for c in range(a.copies):
+        q3 = [Q.PBLinear(pk["q"].to(dev), None) for _ in range(3)]
+        o_ = Q.PBLinear(pk["o"].to(dev), None)
+        gu = [Q.PBLinear(pk["gate"].to(dev), None) for _ in range(2)]
+        dn = Q.PBLinear(pk["down"].to(dev), None)
+        sep.append((q3, o_, gu, dn))
+        mer.append((Q.PBLinear(concat_rows([m.packed for m in q3]), None), o_, Q.PBLinear(concat_rows([m.packed for m in gu]), None), dn))
+    def run_sep():
+        for q3, o_, gu, dn in sep:
+            for m in q3: m(xb)
+            o_(xb)
+            for m in gu: m(xb)
+            dn(xbi)
+    def run_mer():
+        for qm, o_, gm, dn in mer:
+            qm(xb); o_(xb); gm(xb); dn(xbi)
+    res = {}
+    for name, fn in (("separate", run_sep), ("merged", run_mer)):
+        with torch.no_grad():
+            fn(); torch.cuda.synchronize()
+            s2 = torch.cuda.Stream()
+            with torch.cuda.stream(s2): fn()
+            torch.cuda.synchronize()
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb): fn()
+            for _ in range(10): gb.replay()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(100): gb.replay()
+            e1.record(); torch.cuda.synchronize()
+        res[name] = round(e0.elapsed_time(e1) * 1e3 / (100 * a.copies), 2)
+    print(json.dumps(dict(mode=f"batched decode M={Mb}, linears of a decoder layer (hipGraph): 7 separate calls vs q|k|v and gate|up merged",
+                          us_per_decoder_layer=res)), flush=True)
     # prefill
     M = 2048
     xp = torch.from_numpy(synth.activations((M, H), 3, 21)).to(dev); xpi = torch.from_numpy(synth.activations((M, I), 4, 21)).to(dev)
