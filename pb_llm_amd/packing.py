@@ -37,6 +37,17 @@ class PackedWeight:
     nnz: int
     nexc: int
 
+    _FIELDS = ("blob", "N", "K", "P", "G", "NRB", "flags", "max_nch", "max_nexc", "nnz", "nexc")
+
+    def __getstate__(self):
+        """state = the dataclass fields; what a forward hangs on the object (the cached ctypes descriptor, a kept GEMM image or
+        salient list with its stream event) is derived data: copy.deepcopy / pickle of a layer that has already run must not trip
+        over a ctypes pointer or drag an image along -- the copy rebuilds them on first use"""
+        return {f: getattr(self, f) for f in self._FIELDS}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
     @property
     def nbytes(self) -> int:
         return int(self.blob.numel())

@@ -181,3 +181,22 @@ def test_concat_rows_is_byte_surgery_that_validates():
     other = pack_dense(Ws[0][:, :512], *infer_levels(Ws[0][:, :512], -1, None))
     with pytest.raises(_lib.PblError):
         concat_rows([parts[0], other])                                      # another in_features
+
+
+def test_a_layer_that_has_run_can_be_deep_copied_and_pickled():
+    """a forward caches a ctypes descriptor (and, on the GPU, the GEMM image with its stream event) on the PackedWeight: derived data,
+    not state -- copy.deepcopy(model) after a forward used to fail with "ctypes objects containing pointers cannot be pickled" """
+    import copy
+    import pickle
+    from pb_llm_amd.packing import PackedWeight
+    from pb_llm_amd.quant import PBLinear
+    p = PackedWeight(torch.zeros(256, dtype=torch.uint8), 16, 512, 1, 1, 1, 0xE, 8, 0, 0, 0)
+    p.layer_struct(None)
+    p._gemm_image = (("key",), object())
+    q = copy.deepcopy(p)
+    assert set(q.__dict__) == set(PackedWeight._FIELDS) and torch.equal(q.blob, p.blob) and q.blob is not p.blob
+    assert pickle.loads(pickle.dumps(p)).K == 512
+    lin = PBLinear(p, torch.zeros(16))
+    lin.packed.layer_struct(lin.pbl_bias)
+    twin = copy.deepcopy(lin)
+    assert twin.packed.blob is twin.pbl_blob and "_struct" not in twin.packed.__dict__
