@@ -196,7 +196,12 @@ def test_a_layer_that_has_run_can_be_deep_copied_and_pickled():
     q = copy.deepcopy(p)
     assert set(q.__dict__) == set(PackedWeight._FIELDS) and torch.equal(q.blob, p.blob) and q.blob is not p.blob
     assert pickle.loads(pickle.dumps(p)).K == 512
-    lin = PBLinear(p, torch.zeros(16))
+    import numpy as np
+    from pb_llm_amd.packing import pack_dense
+    W = np.where(np.arange(32 * 512).reshape(32, 512) % 3 == 0, 0.5, -0.5).astype(np.float32)
+    real = pack_dense(W, np.full((32, 1), 0.5, np.float32), np.full((32, 1), -0.5, np.float32))
+    lin = PBLinear(real, torch.zeros(32))
     lin.packed.layer_struct(lin.pbl_bias)
     twin = copy.deepcopy(lin)
     assert twin.packed.blob is twin.pbl_blob and "_struct" not in twin.packed.__dict__
+    assert torch.equal(twin.packed.unpack(), lin.packed.unpack())
