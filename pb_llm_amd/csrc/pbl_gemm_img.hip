@@ -1181,7 +1181,7 @@ ImgPlan img_plan(const pbl_layer* layer, int M) {
     const double t_hs = 2.06, c0 = 6.0;
     auto rounds = [&](double items) { return items <= 0 ? 0.0 : double(uint64_t((items + cus - 1) / cus)); };
     const double unsplit = rounds(T) * (NH * t_hs + c0);
-    double best = unsplit * 0.93;                       // a split has to be worth at least 7 %
+    double best = unsplit * 0.95;                       // a split has to be worth 5 % in the model (which over-prices thin one-launch rounds: call r5-10)
     for (int mode = 1; mode <= 2; ++mode) {
         const uint32_t n = mode == 1 ? p.TT : p.RT, other = mode == 1 ? p.RT : p.TT;
         for (uint32_t cut = 0; cut < n; ++cut) {

@@ -139,10 +139,12 @@ def test_the_gemm_launch_plan_without_a_gpu():
         assert ws == (out[2] * out[4] * out[5] * 4 if out[0] else 0)
         return list(out)
 
-    for N, K in ((4096, 4096), (4096, 11008), (11008, 4096), (13824, 5120), (8192, 8192)):
+    for N, K in ((4096, 4096), (4096, 11008), (11008, 4096), (8192, 8192)):
         assert plan(N, K, 2048)[0] == 0, (N, K)
     assert plan(5120, 5120, 2048) == [2, 32, 4, 10, 2048, 1024]
     assert plan(5120, 13824, 2048) == [2, 32, 4, 27, 2048, 1024]
+    assert plan(13824, 5120, 2048) == [2, 96, 2, 20, 2048, 1536]          # 864 tiles: three full rounds (96 row tiles) + 12 row tiles split in two
+    assert plan(11008, 4096, 1536) == [2, 85, 8, 4, 1536, 128]            # 516 tiles: the 6 tiles beyond two rounds are cut off and split 8 ways
     p = plan(4096, 4096, 300)
     assert p[0] == 1 and p[1] == 0 and p[2] * p[3] >= 32 and p[4:] == [300, 4096]
     assert plan(512, 1024, 300)[0] == 0 and plan(4096, 4096, 4096)[0] == 0
