@@ -104,6 +104,14 @@ def test_config3_llama7b_linears_hessian_m2048(name):
     # the decode-time regimes of the same layer: GEMV (1 token) and the matrix-core kernel (32 tokens)
     for M in (1, 32):
         assert_parity(layer(T(x[:M])), O.dense_linear(x[:M], W16.numpy()))
+    if name == "gate_proj":
+        # 1536 rows on 11008 x 4096 are 516 tiles -- 4 more than two rounds of the chip: the launch plan cuts the last row tile off and
+        # splits its 6 tiles 8 ways (4 half slabs per work item: the shortest K range a plan uses)
+        plan = (C.c_uint64 * 6)()
+        assert _lib.lib().pbl_gemm_image_plan(C.byref(layer.packed.layer_struct(None)), 1536, plan) == 0 and list(plan)[:4] == [2, 85, 8, 4]
+        y15 = layer(T(x[:1536]))
+        assert_parity(y15[:, torch.from_numpy(rows).to(DEV)], O.dense_linear(x[:1536], W16.numpy()[rows]))
+        assert torch.equal(y15[:, :85 * 128], y_auto[:1536, :85 * 128]) and torch.equal(y15, layer(T(x[:1536])))
 
 
 @pytest.mark.parametrize("N,K", [(5120, 5120), (13824, 5120), (5120, 13824)])
