@@ -274,6 +274,26 @@ def build_gemm_images_(model: nn.Module) -> tuple[int, int]:
     return n, nbytes
 
 
+def drop_gemm_images_(model: nn.Module) -> int:
+    """Release every kept GEMM image (and kept salient list) of `model`'s packed linears -- the memory knob next to
+    build_gemm_images_: with the round-5 defaults every fp16-exact linear gets an image on its first call with 5 rows or more
+    (1.7 - 2.4 x the blob's bytes; 4.2 GB for a 7B model at 5 % hessian salients), which a decode-only phase at batch <= 4 never
+    reads.  The next call that wants an image rebuilds it.  Not while a captured graph that uses the images may still be replayed.
+    Returns the bytes released."""
+    from . import quant as Q
+    n = 0
+    for m in model.modules():
+        if isinstance(m, Q.PBLinear):
+            p = m.packed
+            kept = p.__dict__.pop("_gemm_image", None)
+            if kept is not None and kept[1] is not None:
+                n += kept[1].data.numel()
+            lst = p.__dict__.pop("_gemm_list", None)
+            if lst is not None and lst[1] is not None:
+                n += lst[1].numel()
+    return n
+
+
 class GraphedForward:
     """One forward of `model` on a fixed input shape captured in a hipGraph (the C ABI launches are asynchronous and
     allocation free; torch's caching allocator serves the temporaries from the graph's private pool).  replay(ids) copies

@@ -521,6 +521,10 @@ def test_build_gemm_images_for_a_model_then_small_batches_use_them():
         g.replay(); torch.cuda.synchronize()
         assert torch.equal(y_cap, Q.small_image_forward(model[0].packed, None, x, img))
         assert_parity(y_cap, y_rec.float().cpu().numpy().astype(np.float64), 2e-3)
+        # the memory knob: drop the images again (nothing captured may still use them: this graph is done) ...
+        del g
+        assert H.drop_gemm_images_(model) == nbytes and getattr(model[0].packed, "_gemm_image", None) is None
+        assert torch.equal(model[0](x), y_rec)                                      # ... and "auto" is back on the kernel over the records
     finally:
         Q.SMALL_BATCH_IMAGE = old
 
