@@ -382,6 +382,13 @@ int pbl_gemm_f16_image_ex(const pbl_layer* layer, const void* x, void* y, int M,
 size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, int M);
 int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
                             const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream);
+/* The same for bf16 activations (see pbl_act_bf16_prepare below): x_f16 / tok_scale [M] are the prepare step's outputs, y [M, N] is
+ * out_dtype PBL_DTYPE_BF16 or PBL_DTYPE_F32 = cast(acc * tok_scale[token] + bias[row]) -- pbl_act_finish folded into the kernel
+ * that adds the K splits, i.e. two launches behind the prepare step instead of three, the same bits.  PBL_ERR_UNSUPPORTED, nothing
+ * launched, when the layer runs as ONE split (no workspace, or a layer that fills the device without a split): run
+ * pbl_gemm_small_image_ws with an fp32 result and pbl_act_finish instead. */
+int pbl_gemm_small_image_act(const pbl_layer* layer, const void* x_f16, void* y, int M, int out_dtype, const float* tok_scale,
+                             const void* image, size_t image_bytes, const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream);
 
 /* bf16 activations (round 5; csrc/pbl_act.hip).  The reference's QAT and evaluation run under bf16 (qat/run_qat.py:120; HF LLaMA
  * checkpoints), i.e. F.linear(x_bf16, w, b).  The packed kernels multiply fp16 tiles with fp32 accumulation; bf16 -> fp16 is exact

@@ -988,10 +988,14 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
 
 // y = the K splits' partial tiles added in split order; 4 elements per thread (MN % 4 == 0 whenever N % 4 == 0).  All splits'
 // values are requested together (ONE memory latency: the kernel is nothing but latency), up to 16 at a time.
-__global__ __launch_bounds__(256) void sb_reduce_kernel(const float* __restrict__ part, void* __restrict__ y, int KS, size_t MN, int y_f32) {
+// ACT (bf16 activations, round 5): y = cast(sum * tok_scale[token] + bias[row]) -- pbl_act_finish folded into the reduce (out: 1 fp32,
+// 2 bf16); the plain form (ACT == false) is round 4's kernel.
+template <bool ACT>
+__global__ __launch_bounds__(256) void sb_reduce_kernel(const float* __restrict__ part, void* __restrict__ y, int KS, size_t MN, int y_f32,
+                                                        const float* __restrict__ tok_scale, const float* __restrict__ bias, uint32_t N) {
     const size_t i = (size_t(blockIdx.x) * 256 + threadIdx.x) * 4;
     if (i >= MN) return;
-    if (!(MN & 3)) {
+    if (ACT ? !(N & 3) : !(MN & 3)) {
         v4f sum = {0.f, 0.f, 0.f, 0.f};
         for (int k0 = 0; k0 < KS; k0 += 16) {
             v4f v[16];
@@ -999,6 +1003,22 @@ __global__ __launch_bounds__(256) void sb_reduce_kernel(const float* __restrict_
             for (int j = 0; j < 16; ++j) v[j] = k0 + j < KS ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(part + size_t(k0 + j) * MN + i)) : v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 16; ++j) if (k0 + j < KS) sum = (k0 + j) ? sum + v[j] : v[j];
+        }
+        if constexpr (ACT) {                                  // (N % 4 == 0 here: the four elements are one token's)
+            const size_t t = i / N;
+            const uint32_t r = uint32_t(i - t * N);
+            const float sc = tok_scale[t];
+            v4f b = {0.f, 0.f, 0.f, 0.f};
+            if (bias) b = v4f{bias[r], bias[r + 1], bias[r + 2], bias[r + 3]};
+#pragma unroll
+            for (int e_ = 0; e_ < 4; ++e_) sum[e_] = __builtin_fmaf(sum[e_], sc, b[e_]);
+            if (y_f32 == 1) *reinterpret_cast<v4f*>(static_cast<float*>(y) + i) = sum;
+            else {
+                uint2 pk;
+                pk.x = bf16_bits(sum[0]) | (bf16_bits(sum[1]) << 16); pk.y = bf16_bits(sum[2]) | (bf16_bits(sum[3]) << 16);
+                *reinterpret_cast<uint2*>(static_cast<uint16_t*>(y) + i) = pk;
+            }
+            return;
         }
         if (y_f32) *reinterpret_cast<v4f*>(static_cast<float*>(y) + i) = sum;
         else {
@@ -1011,6 +1031,13 @@ __global__ __launch_bounds__(256) void sb_reduce_kernel(const float* __restrict_
     for (size_t j = i; j < MN && j < i + 4; ++j) {
         float sum = part[j];
         for (int k = 1; k < KS; ++k) sum += part[size_t(k) * MN + j];
+        if constexpr (ACT) {
+            const size_t t = j / N;
+            sum = __builtin_fmaf(sum, tok_scale[t], bias ? bias[j - t * N] : 0.f);
+            if (y_f32 == 1) static_cast<float*>(y)[j] = sum;
+            else static_cast<uint16_t*>(y)[j] = uint16_t(bf16_bits(sum));
+            continue;
+        }
         if (y_f32) static_cast<float*>(y)[j] = sum;
         else static_cast<_Float16*>(y)[j] = _Float16(sum);
     }
@@ -1352,12 +1379,9 @@ extern "C" size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, i
     return KS > 1 ? size_t(KS) * M * layer->N * sizeof(float) : 0;
 }
 
-// y[M, N] = x[M, K] . W^T (+ bias) for 1 <= M <= 64 rows over the GEMM image (the same image, the same geometry words as
-// pbl_gemm_f16_image).  `workspace` (pbl_gemm_small_image_workspace_bytes(layer, M), 16-byte aligned; any content) holds the K
-// splits' partial outputs; NULL / too small: one split (slow for layers with few rows).  The same numbers as the other kernels up
-// to fp32 summation order (within the parity tolerance of tests/test_gpu_gemm.py); repeatable run to run.
-extern "C" int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
-                                       const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream) {
+// the small-batch kernel's launches behind pbl_gemm_small_image_ws / _act (tok_scale: the _act form)
+static int sb_launch(const pbl_layer* layer, const void* x, void* y, int M, int out_dtype, const float* tok_scale, const void* image, size_t image_bytes,
+                     const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream) {
     if (!layer || !layer->blob || !x || !y || !image || !geom || M < 1 || M > 64) return PBL_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(image) & 15)) return PBL_ERR_MISALIGNED;
     if (!layer_ok(layer) || layer->K < 16) return PBL_ERR_UNSUPPORTED;
@@ -1367,12 +1391,16 @@ extern "C" int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, vo
     SbArgs a;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const uint8_t* ib = static_cast<const uint8_t*>(image);
-    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = y_f32;
+    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = out_dtype == PBL_DTYPE_F32;
     a.slots = ib + g.slots_off; a.rbase = reinterpret_cast<const uint32_t*>(ib + sizeof(ImgHeader));
     a.rtab = reinterpret_cast<const uint32_t*>(ib + g.rtab_off); a.levels = reinterpret_cast<const uint32_t*>(ib + g.levels_off);
     sb_split(layer, a.KS, a.hps);
     const uint32_t NH = (layer->K + GI_HS - 1) / GI_HS;
     if (a.KS > 1 && (!workspace || workspace_bytes < size_t(a.KS) * M * layer->N * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15))) { a.KS = 1; a.hps = int(NH); }
+    if (tok_scale) {                                         // scaled activations: scale and bias belong to the reduce
+        if (a.KS == 1) return PBL_ERR_UNSUPPORTED;
+        a.L.bias = nullptr;
+    }
     a.part = a.KS > 1 ? static_cast<float*>(workspace) : nullptr;
     const uint32_t nvk = geom[1];
     const bool kt = (layer->K & (GI_HS - 1)) != 0;
@@ -1387,9 +1415,31 @@ extern "C" int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, vo
     if (a.KS > 1) {
         const float* part = a.part;
         size_t MN = size_t(M) * layer->N;
-        int KS = a.KS;
-        void* rv[] = {&part, &y, &KS, &MN, &y_f32};
-        if (hipLaunchKernel(reinterpret_cast<const void*>(sb_reduce_kernel), dim3(uint32_t((MN + 1023) / 1024)), dim3(256), rv, 0, st) != hipSuccess) return PBL_ERR_LAUNCH;
+        int KS = a.KS, om = tok_scale ? (out_dtype == PBL_DTYPE_F32 ? 1 : 2) : a.y_f32;
+        const float* bias = layer->bias;
+        uint32_t N = layer->N;
+        void* rv[] = {&part, &y, &KS, &MN, &om, &tok_scale, &bias, &N};
+        const void* rk = tok_scale ? reinterpret_cast<const void*>(sb_reduce_kernel<true>) : reinterpret_cast<const void*>(sb_reduce_kernel<false>);
+        if (hipLaunchKernel(rk, dim3(uint32_t((MN + 1023) / 1024)), dim3(256), rv, 0, st) != hipSuccess) return PBL_ERR_LAUNCH;
     }
     return PBL_OK;
+}
+
+// y[M, N] = x[M, K] . W^T (+ bias) for 1 <= M <= 64 rows over the GEMM image (the same image, the same geometry words as
+// pbl_gemm_f16_image).  `workspace` (pbl_gemm_small_image_workspace_bytes(layer, M), 16-byte aligned; any content) holds the K
+// splits' partial outputs; NULL / too small: one split (slow for layers with few rows).  The same numbers as the other kernels up
+// to fp32 summation order (within the parity tolerance of tests/test_gpu_gemm.py); repeatable run to run.
+extern "C" int pbl_gemm_small_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
+                                       const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream) {
+    return sb_launch(layer, x, y, M, y_f32 ? PBL_DTYPE_F32 : PBL_DTYPE_F16, nullptr, image, image_bytes, geom, workspace, workspace_bytes, stream);
+}
+
+// The same for activations scaled per token by pbl_act_bf16_prepare: y = cast(acc * tok_scale[token] + bias) with out_dtype
+// PBL_DTYPE_BF16 / PBL_DTYPE_F32 -- pbl_act_finish folded into the K splits' reduce, so two launches after the prepare instead of
+// three.  PBL_ERR_UNSUPPORTED (nothing launched) when the layer runs as ONE split (no reduce to fold into: small workspace, or a
+// layer with enough rows to fill the device alone): the caller then runs pbl_gemm_small_image_ws (fp32) + pbl_act_finish.
+extern "C" int pbl_gemm_small_image_act(const pbl_layer* layer, const void* x_f16, void* y, int M, int out_dtype, const float* tok_scale,
+                                        const void* image, size_t image_bytes, const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!tok_scale || (out_dtype != PBL_DTYPE_F32 && out_dtype != PBL_DTYPE_BF16)) return PBL_ERR_INVALID_ARG;
+    return sb_launch(layer, x_f16, y, M, out_dtype, tok_scale, image, image_bytes, geom, workspace, workspace_bytes, stream);
 }

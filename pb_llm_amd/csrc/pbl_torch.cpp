@@ -92,6 +92,21 @@ bool run_small_image(const pbl_layer& L, const at::Tensor& xc, at::Tensor& y, in
     return rc == PBL_OK;
 }
 
+// bf16 activations, 5 - 64 rows over the image: pbl_gemm_small_image_act (scale, bias and cast inside the K splits' reduce: one
+// launch fewer than kernel + pbl_act_finish).  xh / tsc: prepare_bf16's; an undefined tensor: the layer runs as one split or is
+// not taken -- the caller runs the fp32 kernel + finish.
+at::Tensor run_small_image_act(const pbl_layer& L, const at::Tensor& xh, const at::Tensor& tsc, int64_t M, at::ScalarType out_dt, const ImageRef& img) {
+    if (!img || M < SMALL_IMAGE_MIN || M > SMALL_IMAGE_MAX || (reinterpret_cast<uintptr_t>(xh.data_ptr()) & 15)) return at::Tensor();
+    const size_t nbi = pbl_gemm_small_image_workspace_bytes(&L, int(M));
+    if (!nbi) return at::Tensor();
+    at::Tensor wsi = at::empty({int64_t(nbi)}, xh.options().dtype(at::kByte));
+    at::Tensor y = at::empty({M, int64_t(L.N)}, xh.options().dtype(out_dt));
+    const int rc = pbl_gemm_small_image_act(&L, xh.data_ptr(), y.data_ptr(), int(M), out_dt == at::kFloat ? PBL_DTYPE_F32 : PBL_DTYPE_BF16, tsc.data_ptr<float>(),
+                                            img.data, img.bytes, img.geom.data(), wsi.data_ptr(), nbi, stream_of(xh));
+    TORCH_CHECK(rc == PBL_OK || rc == PBL_ERR_UNSUPPORTED, "libpbl gemm_small_image_act: ", pbl_status_string(rc), " (", rc, ")");
+    return rc == PBL_OK ? y : at::Tensor();
+}
+
 at::Tensor run_small(const pbl_layer& L, const at::Tensor& xc, int64_t M, bool f32, const ImageRef& img) {
     at::Tensor y = at::empty({M, int64_t(L.N)}, xc.options().dtype(f32 ? at::kFloat : at::kHalf));
     if (img && M >= SMALL_IMAGE_MIN && (reinterpret_cast<uintptr_t>(xc.data_ptr()) & 15) == 0 && run_small_image(L, xc, y, M, f32, img)) return y;
@@ -195,6 +210,10 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
                 const pbl_layer& Lk = (xt == at::kHalf || direct) ? L : Lnb;     // (bias: in the kernel, or once behind it)
                 at::Tensor y = at::empty({R, N}, x.options().dtype(k32 ? at::kFloat : (xt == at::kBFloat16 ? at::kBFloat16 : at::kHalf)));
                 bool done = false;
+                if (xt == at::kBFloat16 && img && R <= SMALL_IMAGE_MAX && small_image) {
+                    const at::Tensor ya = run_small_image_act(L, xin, tsc, R, out_dt, iref);
+                    if (ya.defined()) return ya.reshape(shape);
+                }
                 if (img && R <= SMALL_IMAGE_MAX && small_image) done = run_small_image(Lk, xin, y, R, k32, iref);   // 33 - 64 rows: one pass over the image
                 if (!done && img) {
                     // a thin last round (5120-row layers at 2048 rows, short prompts) is cut off and split along K through a transient
@@ -235,6 +254,8 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
         }
         at::Tensor xh, tsc;
         std::tie(xh, tsc) = prepare_bf16(x2, M, K);
+        const at::Tensor ya = run_small_image_act(L, xh, tsc, M, out_dt, isml);
+        if (ya.defined()) return ya.reshape(shape);
         const at::Tensor y32 = run_small(Lnb, xh, M, true, isml);
         return finish(y32, tsc, L.bias, M, N, out_dt).reshape(shape);
     }

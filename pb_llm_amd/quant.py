@@ -192,6 +192,28 @@ def small_image_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, image:
     return y
 
 
+def small_image_act_forward(packed: PackedWeight, bias_f32, xh: torch.Tensor, tok_scale: torch.Tensor, image: "GemmImage", out_dtype):
+    """pbl_gemm_small_image_act: xh [5 <= M <= 64, K] (act_bf16_prepare's scaled fp16 copy) + tok_scale -> [M, N] bf16 / fp32 with
+    the scale, the bias and the cast inside the K splits' reduce (one launch fewer than kernel + act_finish).  None when the layer
+    runs as ONE split (nothing launched): the caller runs the fp32 kernel + act_finish."""
+    M = xh.shape[0]
+    layer = packed.layer_struct(bias_f32)
+    L = _lib.lib()
+    nb = int(L.pbl_gemm_small_image_workspace_bytes(C.byref(layer), M))
+    if not nb or xh.data_ptr() % 16:
+        return None
+    cur = torch.cuda.current_stream(xh.device)
+    _wait_image(cur, image)
+    ws = torch.empty(nb, dtype=torch.uint8, device=xh.device)
+    y = torch.empty(M, packed.N, dtype=out_dtype, device=xh.device)
+    rc = L.pbl_gemm_small_image_act(C.byref(layer), xh.data_ptr(), y.data_ptr(), M, _lib.PBL_DTYPE_F32 if out_dtype == torch.float32 else _lib.PBL_DTYPE_BF16,
+                                    tok_scale.data_ptr(), image.data.data_ptr(), image.data.numel(), image.geom, ws.data_ptr(), nb, cur.cuda_stream)
+    if rc == _lib.PBL_ERR_UNSUPPORTED:
+        return None
+    _lib.check(rc, "gemm_small_image_act")
+    return y
+
+
 def gemm_list(packed: PackedWeight) -> torch.Tensor | None:
     """pbl_gemm_prepare: the layer's salient list for pbl_gemm_f16_prepared (uint8 tensor, 4 B per salient entry + ranges), or None
     for a layer without one (K > 16256).  Valid until the blob changes; callers that run the same layers batch after batch
@@ -481,6 +503,10 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
                 direct = x.dtype == torch.float16 or (tsc is not None and not out_f32 and img is not None and R > SMALL_IMAGE_MAX)
                 k32 = out_f32 if x.dtype == torch.float16 else not direct
                 bias_k = bias_f32 if (x.dtype == torch.float16 or direct) else None
+                if tsc is not None and img is not None and small_ok and R <= SMALL_IMAGE_MAX:
+                    ya = small_image_act_forward(packed, bias_f32, xin, tsc, img, torch.float32 if out_f32 else x.dtype)
+                    if ya is not None:
+                        return ya.reshape(*lead, packed.N)
                 if img is not None and small_ok and R <= SMALL_IMAGE_MAX:
                     y = small_image_forward(packed, bias_k, xin, img, k32)                # 33 - 64 rows: one more pass of the small-batch kernel
                 elif img is not None:
@@ -521,6 +547,10 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
             if rc != _lib.PBL_ERR_UNSUPPORTED:
                 _lib.check(rc, "linear_bf16")
         xh, tsc = act_bf16_prepare(x2)
+        if img is not None and small_ok and M >= SMALL_IMAGE_MIN:
+            ya = small_image_act_forward(packed, bias_f32, xh, tsc, img, torch.float32 if out_f32 else x.dtype)
+            if ya is not None:
+                return ya.reshape(*lead, packed.N)
         y = small(xh, packed.layer_struct(None), None, M)
         return act_finish(y, tsc, bias_f32, torch.float32 if out_f32 else x.dtype).reshape(*lead, packed.N)
     return join_f32(small(split_f32(), packed.layer_struct(None), None, 2 * M))

@@ -763,6 +763,60 @@ def test_bf16_single_launch_gemv_equals_the_three_launch_form(llama7b_qproj):
     assert torch.equal(big(x3).reshape(2, 4096), big(x3.reshape(2, 4096)))
 
 
+def test_bf16_small_batch_finish_folded_into_the_k_split_reduce():
+    """round 5: bf16 activations at 5 - 64 rows over the GEMM image run prepare + small-batch kernel + reduce, the reduce applying
+    the token scale, the bias and the bf16 cast (pbl_gemm_small_image_act) -- bit for bit what kernel (fp32, no bias) + pbl_act_finish
+    gives, for a layer with bias, a ragged K, N not a multiple of 4, values beyond fp16's range and non-finite tokens; one split
+    (no workspace) is refused before anything is launched."""
+    Wq = synth.llm_weight(512, 4096, seed=5, heavy_tail=True)
+    mq = O.ptq_low_mask(Wq, 0.9, "magnitude", None, -1)
+    rq = O.ptq_rtn(Wq, mq, 8, -1)
+    sl = Q.PBLinear.from_dense(torch.from_numpy(rq["W_fq"]).half(), torch.from_numpy(synth.normal((512,), 3, 3, 0.1)),
+                               torch.from_numpy(mq), -1, rq["hscale"], rq["hzero"]).to(DEV)
+    Wr = synth.llm_weight(78, 1000, seed=12)
+    mr = O.ptq_low_mask(Wr, 0.9, "magnitude", None, -1)
+    rr = O.ptq_rtn(Wr, mr, 8, -1)
+    rag = Q.PBLinear.from_dense(torch.from_numpy(rr["W_fq"]).half(), torch.from_numpy(synth.normal((78,), 4, 3, 0.1)),
+                                torch.from_numpy(mr), -1, rr["hscale"], rr["hzero"]).to(DEV)
+    for layer in (sl, rag):
+        p, K = layer.packed, layer.in_features
+        for M in (5, 12, 32, 33, 64):
+            x = torch.from_numpy(synth.activations((M, K), 60 + M, 21)).float().to(DEV)
+            x[0, 5] = 7.0e4
+            x[M - 1, 9] = float("-inf")
+            x[2, 11] = float("nan")
+            xb = x.bfloat16()
+            xh, tsc = Q.act_bf16_prepare(xb)
+            img, small_ok = Q._route_image(p, M, xb.dtype, True, xb.device)
+            assert img is not None and small_ok
+            want32 = Q.small_image_forward(p, None, xh, img, True)
+            for out_f32 in (False, True):
+                odt = torch.float32 if out_f32 else torch.bfloat16
+                want = Q.act_finish(want32, tsc, layer.pbl_bias, odt)
+                got = Q.small_image_act_forward(p, layer.pbl_bias, xh, tsc, img, odt)
+                assert got is not None and got.dtype == odt, (K, M)             # (these layers split K: few rows)
+                assert torch.equal(torch.nan_to_num(got.float(), nan=3.0), torch.nan_to_num(want.float(), nan=3.0)), (K, M, out_f32)
+                y = Q.pb_linear_forward(p, layer.pbl_bias, xb, out_f32=out_f32)
+                assert torch.equal(torch.nan_to_num(y.float(), nan=3.0), torch.nan_to_num(want.float(), nan=3.0)), (K, M, out_f32)
+            y = layer(xb)                                                        # the registered operator's route: the same bits
+            assert y.dtype == torch.bfloat16
+            assert torch.equal(torch.nan_to_num(y.float(), nan=3.0), torch.nan_to_num(Q.act_finish(want32, tsc, layer.pbl_bias, torch.bfloat16).float(), nan=3.0))
+            assert torch.isnan(y[2]).all() and torch.isinf(y[M - 1]).any()
+            fin = torch.ones(M, dtype=torch.bool); fin[2] = False; fin[M - 1] = False
+            ref = O.dense_linear(xb[fin.to(DEV)].float().cpu().numpy(), layer.weight.float().cpu().numpy(), layer.pbl_bias.cpu().numpy())
+            assert O.parity_errors(y[fin.to(DEV)].float().cpu().numpy(), ref)[0] < 1e-2
+    # without a workspace the layer runs as one split: refused, y untouched
+    p = sl.packed
+    xh, tsc = Q.act_bf16_prepare(torch.from_numpy(synth.activations((8, 4096), 1, 2)).to(DEV).bfloat16())
+    img, _ = Q._route_image(p, 8, torch.bfloat16, True, xh.device)
+    y = torch.full((8, 512), 7.0, dtype=torch.bfloat16, device=DEV)
+    lay = p.layer_struct(sl.pbl_bias)
+    rc = _lib.lib().pbl_gemm_small_image_act(C.byref(lay), xh.data_ptr(), y.data_ptr(), 8, _lib.PBL_DTYPE_BF16, tsc.data_ptr(), img.data.data_ptr(),
+                                             img.data.numel(), img.geom, None, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == _lib.PBL_ERR_UNSUPPORTED and bool((y == 7.0).all())
+
+
 def test_bf16_fused_decode_of_a_bf16_model():
     """a bf16 HF LLaMA (how the checkpoints ship; qat/run_qat.py:120 trains under bf16) through fuse_decode_ + GraphedForward: the
     fused q/k/v and gate/up launches take bf16 activations directly (pbl_gemv_bf16_fused_host) -- logits of the fused model, eager and

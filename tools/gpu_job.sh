@@ -22,11 +22,12 @@ P
 }
 case $MODE in
 validate)
-  for i in 1 2; do timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 900 > $O/pytest$i.txt 2>&1; tail -3 $O/pytest$i.txt | cut -c1-300; grep -E "^(FAILED|ERROR)" $O/pytest$i.txt | cut -c1-300; done
+  for i in $(seq 1 ${REPS:-2}); do timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 900 > $O/pytest$i.txt 2>&1; tail -3 $O/pytest$i.txt | cut -c1-300; grep -E "^(FAILED|ERROR)" $O/pytest$i.txt | cut -c1-300; done
   timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
   timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; line $O/bench_driver.json
   timeout 300 python bench.py --workload cfg4 --steps 20 --warmup 5 > $O/cfg4.json 2> $O/cfg4.err; line $O/cfg4.json
   timeout 300 python bench.py --workload cfg3 --steps 10 --warmup 3 > $O/cfg3.json 2> $O/cfg3.err; line $O/cfg3.json
+  timeout 200 python tools/bench_host.py > $O/host.json 2> $O/host.err; cut -c1-700 $O/host.json
   for n in 2 4; do
     PBL_BENCH_BACKEND=gloo PBL_BENCH_BASELINE=1 MASTER_PORT=296$n timeout 400 python bench.py --gpus $n --steps 5 --warmup 2 --preheat-s 0.3 --no-cpu-baseline > $O/tp${n}_plumbing.json 2> $O/tp${n}_plumbing.err
     echo tp$n rc=$?; line $O/tp${n}_plumbing.json
