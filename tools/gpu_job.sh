@@ -6,6 +6,7 @@
 #              7B-shaped forward fp16 + bf16                                                                   (calls r5-1, r5-3, r5-4)
 #   profiles   rocprofv3 kernel trace + PMC passes of the driver's command, of cfg4 and a kernel trace of cfg3            (call r5-3)
 #   variants   A/B builds from tools/build_variant.sh (build/libpbl_<name>.so, PBL_LIB): cfg4 per variant                 (call r5-5)
+#   bf16trace  kernel trace of a small decode batch with bf16 activations (tools/trace_bf16_small.py)                      (call r5x)
 #   plumbing8  eight ranks of `bench.py --gpus 8` time-slicing one device (PBL_BENCH_BACKEND=gloo)                        (call r5-1)
 set -u
 export TMPDIR=/tmp
@@ -54,5 +55,10 @@ variants)
     if [ $v = default ]; then unset PBL_LIB; else export PBL_LIB=build/libpbl_$v.so; fi
     timeout 300 python bench.py --workload cfg4 --steps 20 --warmup 5 > $O/cfg4_$v.json 2> $O/cfg4_$v.err; echo cfg4 $v; line $O/cfg4_$v.json
   done ;;
+bf16trace)
+  mkdir -p gpurun_out/prof_r05_bf16
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r05_bf16/trace -o trace -- python tools/trace_bf16_small.py > gpurun_out/prof_r05_bf16/trace.log 2>&1
+  tail -2 gpurun_out/prof_r05_bf16/trace.log | cut -c1-400
+  python tools/summarize_prof.py gpurun_out/prof_r05_bf16 > gpurun_out/prof_r05_bf16/summary.txt 2>&1; cut -c1-300 gpurun_out/prof_r05_bf16/summary.txt | head -24 ;;
 *) echo "unknown mode $MODE"; exit 2 ;;
 esac
