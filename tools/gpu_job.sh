@@ -6,6 +6,7 @@
 #              7B-shaped forward fp16 + bf16                                                                   (calls r5-1, r5-3, r5-4)
 #   profiles   rocprofv3 kernel trace + PMC passes of the driver's command, of cfg4 and a kernel trace of cfg3            (call r5-3)
 #   variants   A/B builds from tools/build_variant.sh (build/libpbl_<name>.so, PBL_LIB): cfg4 per variant                 (call r5-5)
+#   sbsplit    A/B builds of the small-batch kernel's K-split rule (-DPBL_SB_MIN_HPS) on llama-7b shapes, tools/bench_small.py   (call r5z)
 #   bf16trace  kernel trace of a small decode batch with bf16 activations (tools/trace_bf16_small.py)                      (call r5x)
 #   plumbing8  eight ranks of `bench.py --gpus 8` time-slicing one device (PBL_BENCH_BACKEND=gloo)                        (call r5-1)
 set -u
@@ -54,6 +55,15 @@ variants)
   for v in default ${VARIANTS:-sbw5 sbw6 sbw7}; do
     if [ $v = default ]; then unset PBL_LIB; else export PBL_LIB=build/libpbl_$v.so; fi
     timeout 300 python bench.py --workload cfg4 --steps 20 --warmup 5 > $O/cfg4_$v.json 2> $O/cfg4_$v.err; echo cfg4 $v; line $O/cfg4_$v.json
+  done ;;
+sbsplit)
+  for v in default ${VARIANTS:-hps2 hps3 hps6}; do
+    if [ $v = default ]; then unset PBL_LIB; else export PBL_LIB=build/libpbl_$v.so; fi
+    PBL_BENCH_SHAPES=${SHAPES:-4096x4096:0.95,11008x4096:0.95,4096x11008:0.95,4096x4096:0.9} PBL_BENCH_MS=${MS:-32,16} timeout 300 python tools/bench_small.py > $O/small_$v.jsonl 2> $O/small_$v.err
+    echo "== $v"; python -c "
+import json,sys
+for l in open('$O/small_$v.jsonl'):
+    d=json.loads(l); print(d['shape'], d['low_frac'], d['M'], 'image', d.get('image_us_w2048'), 'records', d['records_us'], 'dense', d['dense_us'])"
   done ;;
 bf16trace)
   mkdir -p gpurun_out/prof_r05_bf16
