@@ -407,6 +407,16 @@ int pbl_gemm_small_image_act(const pbl_layer* layer, const void* x_f16, void* y,
 int pbl_act_bf16_prepare(const void* x_bf16, int M, uint32_t K, size_t ldx, void* x_f16, float* tok_scale, void* stream);
 int pbl_act_finish(const float* y_f32, const float* tok_scale, const float* bias, int M, uint32_t N, void* y_out, int out_dtype,
                    void* stream);
+/* fp32 activations (the reference's fp32-only module classes, quant/quantizer.py:78-80,175-177; QAT's fp32 master weights,
+ * utils.py:34-36): F.linear(x_f32, w, b).  The packed kernels are linear in x, so x is split into two fp16 terms, both run through
+ * the kernel in ONE call with an fp32 result, and the halves are added:
+ *   pbl_act_f32_split  x [M, K] fp32 (rows ldx elements apart) -> x_f16 [2 M, K] fp16 contiguous: rows [0, M) = fp16(x),
+ *                      rows [M, 2 M) = fp16(x - fp16(x));
+ *   pbl_act_f32_join   y_out [M, N] (out_dtype) = cast((y_f32[t, r] + y_f32[M + t, r]) + bias[r]) for y_f32 [2 M, N] (16-byte
+ *                      aligned, like bias and y_out); bias may be NULL.
+ * One small kernel each, no host synchronisation. */
+int pbl_act_f32_split(const float* x, int M, uint32_t K, size_t ldx, void* x_f16, void* stream);
+int pbl_act_f32_join(const float* y_f32, const float* bias, int M, uint32_t N, void* y_out, int out_dtype, void* stream);
 
 /* bf16 activations in ONE launch (decode: one GEMV pass, M <= 4 rows of a group-free layer): x [M, K] bf16 -> y [M, N] bf16 (fp32 with
  * y_f32).  The kernel's staging phase does what pbl_act_bf16_prepare does and its epilogue what pbl_act_finish does -- the same bits

@@ -51,7 +51,7 @@ EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_pack_d
            "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_linear_f16_ws", "pbl_gemm_mfma_f16",
            "pbl_gemm_mfma_f16_ws", "pbl_mfma_workspace_bytes", "pbl_linear_workspace_bytes", "pbl_gemv_f16_grouped", "pbl_gemv_f16_fused", "pbl_gemv_f16_fused_host", "pbl_gemm_f16", "pbl_gemm_f16_ex", "pbl_gemm_f16_ws", "pbl_gemm_workspace_bytes", "pbl_gemm_list_bytes", "pbl_gemm_prepare", "pbl_gemm_f16_prepared",
            "pbl_gemm_image_stats_bytes", "pbl_gemm_image_stats", "pbl_gemm_image_bytes", "pbl_gemm_image_build", "pbl_gemm_f16_image",
-           "pbl_gemm_small_image_workspace_bytes", "pbl_gemm_small_image_ws", "pbl_gemm_small_image_act",
+           "pbl_gemm_small_image_workspace_bytes", "pbl_gemm_small_image_ws", "pbl_gemm_small_image_act", "pbl_act_f32_split", "pbl_act_f32_join",
            "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad",
            "pbl_prep_workspace_bytes", "pbl_kth_pair", "pbl_outlier_mask", "pbl_quant8_rows", "pbl_high_calibrate", "pbl_gptq_block",
            "pbl_p2p_buffer_bytes", "pbl_comm_alloc", "pbl_comm_free", "pbl_ipc_export", "pbl_ipc_open", "pbl_ipc_close",
@@ -133,6 +133,10 @@ def lib() -> C.CDLL:
     L.pbl_gemm_small_image_workspace_bytes.argtypes = [C.POINTER(PblLayer), C.c_int]
     L.pbl_gemm_small_image_ws.restype = C.c_int
     L.pbl_gemm_small_image_ws.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, sz, vp, vp, sz, vp]
+    L.pbl_act_f32_split.restype = C.c_int
+    L.pbl_act_f32_split.argtypes = [vp, C.c_int, u32, sz, vp, vp]
+    L.pbl_act_f32_join.restype = C.c_int
+    L.pbl_act_f32_join.argtypes = [vp, vp, C.c_int, u32, vp, C.c_int, vp]
     L.pbl_gemm_small_image_act.restype = C.c_int
     L.pbl_gemm_small_image_act.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, vp, sz, vp, vp, sz, vp]
     L.pbl_gemv_f16_fused.restype = C.c_int

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(ACT_THREADS) void act_bf16_prepare_kernel(const uin
 
 template <int OUT>       // PBL_DTYPE_F32 / _F16 / _BF16
 __global__ __launch_bounds__(ACT_THREADS) void act_finish_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                                                 const float* __restrict__ bias, uint32_t N, size_t MN, void* __restrict__ out) {
+                                                                 const float* __restrict__ bias, uint32_t N, size_t MN, void* __restrict__ out,
+                                                                 const float* __restrict__ y2) {      // y2: a second term added to y first (pbl_act_f32_join)
     const size_t i = (size_t(blockIdx.x) * ACT_THREADS + threadIdx.x) * 4;
     if (i >= MN) return;
     auto put = [&](size_t j, float v) {
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(ACT_THREADS) void act_finish_kernel(const float* __
         const size_t t = i / N;
         const uint32_t r = uint32_t(i - t * N);
         const float s = scale ? scale[t] : 1.f;
-        const v4f v = *reinterpret_cast<const v4f*>(y + i);
+        v4f v = *reinterpret_cast<const v4f*>(y + i);
+        if (y2) v += *reinterpret_cast<const v4f*>(y2 + i);
         v4f b = {0.f, 0.f, 0.f, 0.f};
         if (bias) b = *reinterpret_cast<const v4f*>(bias + r);
         float o[4];
@@ -153,7 +155,37 @@ __global__ __launch_bounds__(ACT_THREADS) void act_finish_kernel(const float* __
     for (size_t j = i; j < MN && j < i + 4; ++j) {
         const size_t t = j / N;
         const float b = bias ? bias[j - t * N] : 0.f;
-        put(j, scale ? __builtin_fmaf(y[j], scale[t], b) : y[j] + b);
+        const float v = y2 ? y[j] + y2[j] : y[j];
+        put(j, scale ? __builtin_fmaf(v, scale[t], b) : v + b);
+    }
+}
+
+// fp32 activations as two fp16 terms (the kernels are linear in x: W x = W hi + W lo, accumulated in fp32): hi = fp16(x),
+// lo = fp16(x - hi), written as rows [0, M) and [M, 2 M) of xh.  Four elements per thread.
+__global__ __launch_bounds__(ACT_THREADS) void act_f32_split_kernel(const float* __restrict__ x, uint32_t K, size_t ldx, size_t MK,
+                                                                    uint16_t* __restrict__ xh, int vec) {
+    const size_t i = (size_t(blockIdx.x) * ACT_THREADS + threadIdx.x) * 4;
+    if (i >= MK) return;
+    auto two = [&](float v, uint32_t& hi, uint32_t& lo) {
+        const _Float16 h = _Float16(v);
+        hi = uint32_t(__builtin_bit_cast(uint16_t, h));
+        lo = uint32_t(__builtin_bit_cast(uint16_t, _Float16(v - float(h))));
+    };
+    if (vec) {                                                  // K % 4 == 0, ldx % 4 == 0, 16-byte bases: four elements of one row
+        const size_t t = i / K;
+        const v4f v = *reinterpret_cast<const v4f*>(x + t * ldx + (i - t * K));
+        uint32_t h[4], l[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) two(v[k], h[k], l[k]);
+        *reinterpret_cast<uint2*>(xh + i) = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        *reinterpret_cast<uint2*>(xh + MK + i) = uint2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+        return;
+    }
+    for (size_t j = i; j < MK && j < i + 4; ++j) {
+        const size_t t = j / K;
+        uint32_t h, l;
+        two(x[t * ldx + (j - t * K)], h, l);
+        xh[j] = uint16_t(h); xh[MK + j] = uint16_t(l);
     }
 }
 
@@ -184,7 +216,40 @@ extern "C" int pbl_act_finish(const float* y_f32, const float* tok_scale, const 
                   : out_dtype == PBL_DTYPE_BF16 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_BF16>) : nullptr;
     if (!k) return PBL_ERR_INVALID_ARG;
     size_t MN = size_t(M) * N;
-    void* argv[] = {&y_f32, &tok_scale, &bias, &N, &MN, &y_out};
+    const float* y2 = nullptr;
+    void* argv[] = {&y_f32, &tok_scale, &bias, &N, &MN, &y_out, &y2};
+    return hipLaunchKernel(k, dim3(uint32_t((MN + 4 * ACT_THREADS - 1) / (4 * ACT_THREADS))), dim3(ACT_THREADS), argv, 0,
+                           static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+// fp32 activations (the reference's fp32-only module classes, quant/quantizer.py:78-80,175-177, and QAT's fp32 master weights,
+// utils.py:34-36): x [M, K] fp32 (rows ldx elements apart) -> x_f16 [2 M, K] fp16 contiguous, rows [0, M) = fp16(x), rows [M, 2 M)
+// = fp16(x - fp16(x)).  The packed kernels run ONCE over the 2 M rows with an fp32 result; pbl_act_f32_join adds the halves.
+extern "C" int pbl_act_f32_split(const float* x, int M, uint32_t K, size_t ldx, void* x_f16, void* stream) {
+    if (!x || !x_f16 || M < 1 || K < 1 || ldx < K) return PBL_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(x_f16) & 1)) return PBL_ERR_MISALIGNED;
+    uint16_t* xh = static_cast<uint16_t*>(x_f16);
+    size_t MK = size_t(M) * K;
+    int vec = !(K & 3u) && !(ldx & 3) && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(x_f16) & 7) && !(MK & 3);
+    void* argv[] = {&x, &K, &ldx, &MK, &xh, &vec};
+    return hipLaunchKernel(reinterpret_cast<const void*>(act_f32_split_kernel), dim3(uint32_t((MK + 4 * ACT_THREADS - 1) / (4 * ACT_THREADS))),
+                           dim3(ACT_THREADS), argv, 0, static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+// y_out [M, N] (out_dtype) = cast((y_f32[t, r] + y_f32[M + t, r]) + bias[r]) for y_f32 [2 M, N]: the two terms of pbl_act_f32_split
+// added in fp32, the bias once.  One small kernel.
+extern "C" int pbl_act_f32_join(const float* y_f32, const float* bias, int M, uint32_t N, void* y_out, int out_dtype, void* stream) {
+    if (!y_f32 || !y_out || M < 1 || N < 1) return PBL_ERR_INVALID_ARG;
+    size_t MN = size_t(M) * N;
+    if ((reinterpret_cast<uintptr_t>(y_f32) & 15) || (reinterpret_cast<uintptr_t>(y_out) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
+        return PBL_ERR_MISALIGNED;
+    const void* k = out_dtype == PBL_DTYPE_F32 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_F32>)
+                  : out_dtype == PBL_DTYPE_F16 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_F16>)
+                  : out_dtype == PBL_DTYPE_BF16 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_BF16>) : nullptr;
+    if (!k) return PBL_ERR_INVALID_ARG;
+    const float* tok_scale = nullptr;
+    const float* y2 = y_f32 + MN;
+    void* argv[] = {&y_f32, &tok_scale, &bias, &N, &MN, &y_out, &y2};
     return hipLaunchKernel(k, dim3(uint32_t((MN + 4 * ACT_THREADS - 1) / (4 * ACT_THREADS))), dim3(ACT_THREADS), argv, 0,
                            static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
 }

@@ -180,16 +180,19 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
         return y.to(out_dt).reshape(shape);
     };
     // fp32 activations: x = x_hi + x_lo with both terms fp16; the kernels are linear in x, so y = W x_hi + W x_lo accumulated in
-    // fp32 (bias added once)
+    // fp32 (bias added once).  One launch each way (pbl_act_f32_split / _join, csrc/pbl_act.hip) around the packed kernel.
     auto split_f32 = [&]() {
-        const at::Tensor x_hi = x2.to(at::kHalf);
-        const at::Tensor x_lo = x2.sub(x_hi.to(at::kFloat)).to(at::kHalf);
-        return at::cat({x_hi, x_lo}, 0).contiguous();
+        const at::Tensor xs = x2.stride(-1) == 1 && (M == 1 || x2.stride(0) >= K) ? x2 : x2.contiguous();
+        at::Tensor xh = at::empty({2 * M, K}, x2.options().dtype(at::kHalf));
+        check(pbl_act_f32_split(xs.data_ptr<float>(), int(M), uint32_t(K), M == 1 ? size_t(K) : size_t(xs.stride(0)), xh.data_ptr(), stream_of(x2)),
+              "act_f32_split");
+        return xh;
     };
     auto join_f32 = [&](const at::Tensor& yy) {
-        at::Tensor y = yy.narrow(0, 0, M).add(yy.narrow(0, M, M));
-        if (has_bias) y = y.add(*bias);
-        return y.to(out_dt).reshape(shape);
+        at::Tensor y = at::empty({M, N}, yy.options().dtype(out_dt));
+        const int dt = out_dt == at::kFloat ? PBL_DTYPE_F32 : (out_dt == at::kHalf ? PBL_DTYPE_F16 : PBL_DTYPE_BF16);
+        check(pbl_act_f32_join(yy.data_ptr<float>(), L.bias, int(M), uint32_t(N), y.data_ptr(), dt, stream_of(yy)), "act_f32_join");
+        return y.reshape(shape);
     };
     if (mok ? rows > MFMA_MAX : M >= GEMM_THRESHOLD) {
         // GEMM regime.  Round 5: every layer an fp16 checkpoint is exact for runs on the hand-written kernels whatever the

@@ -817,6 +817,52 @@ def test_bf16_small_batch_finish_folded_into_the_k_split_reduce():
     assert rc == _lib.PBL_ERR_UNSUPPORTED and bool((y == 7.0).all())
 
 
+def test_fp32_activations_split_and_join_on_the_device():
+    """round 5: fp32 activations (the reference's fp32-only module classes) are split into two fp16 terms and joined again by one
+    launch each (pbl_act_f32_split / pbl_act_f32_join) -- bit for bit the torch composition the route used before:
+    hi = x.half(), lo = (x - hi.float()).half(); y = (y[:M] + y[M:]) + bias."""
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for M, K, wide in ((1, 4096, 0), (5, 1000, 0), (3, 1001, 0), (7, 4096, 8192), (33, 520, 1040)):
+        xw = torch.from_numpy(synth.activations((M, wide or K), 70 + M, 21)).float().to(DEV) * 1.0009765625
+        x = xw[:, :K] if wide else xw
+        x[0, 3] = 1.0e5                                            # beyond fp16: hi = inf, lo = -inf (what torch gives)
+        x[M - 1, 7] = 3.0e-9                                       # below fp16's subnormals: hi = 0, lo = 0
+        xh = torch.empty(2 * M, K, dtype=torch.float16, device=DEV)
+        _lib.check(L.pbl_act_f32_split(x.data_ptr(), M, K, K if M == 1 else x.stride(0), xh.data_ptr(), st), "split")
+        hi = x.half()
+        lo = (x - hi.float()).half()
+        assert torch.equal(xh[:M].view(torch.int16), hi.view(torch.int16)), (M, K)
+        assert torch.equal(xh[M:].view(torch.int16), lo.contiguous().view(torch.int16)), (M, K)
+    for M, N, with_bias in ((1, 4096, True), (5, 78, True), (3, 1001, False), (40, 512, True)):
+        yy = torch.from_numpy(synth.normal((2 * M, N), 5, M, 3.0)).float().to(DEV)
+        b = torch.from_numpy(synth.normal((N,), 6, M, 0.5)).float().to(DEV) if with_bias else None
+        want = yy[:M] + yy[M:]
+        if b is not None:
+            want = want + b
+        for dt, code in ((torch.float32, _lib.PBL_DTYPE_F32), (torch.float16, _lib.PBL_DTYPE_F16), (torch.bfloat16, _lib.PBL_DTYPE_BF16)):
+            out = torch.empty(M, N, dtype=dt, device=DEV)
+            _lib.check(L.pbl_act_f32_join(yy.data_ptr(), b.data_ptr() if b is not None else None, M, N, out.data_ptr(), code, st), "join")
+            assert torch.equal(out, want.to(dt)), (M, N, dt)
+    # the module route: a layer with bias at GEMV, small-batch and GEMM-regime row counts, both routes, against the float64 oracle
+    Wq = synth.llm_weight(512, 1024, seed=5, heavy_tail=True)
+    mq = O.ptq_low_mask(Wq, 0.9, "magnitude", None, -1)
+    rq = O.ptq_rtn(Wq, mq, 8, -1)
+    bq = synth.normal((512,), 3, 3, 0.1)
+    layer = Q.PBLinear.from_dense(torch.from_numpy(rq["W_fq"]).half(), torch.from_numpy(bq), torch.from_numpy(mq), -1, rq["hscale"], rq["hzero"]).to(DEV)
+    Wd = layer.weight.float().cpu().numpy()
+    for M in (1, 3, 20, 40, 300):
+        xf = T(synth.activations((M, 1024), 9, M)).float() * 1.0009765625
+        ref = O.dense_linear(xf.cpu().numpy().astype(np.float64), Wd, bq)
+        y = layer(xf)
+        assert y.dtype == torch.float32 and y.shape == (M, 512)
+        assert O.parity_errors(y.cpu().numpy(), ref)[0] < 2e-5, M
+        y2 = Q._pb_linear_forward(layer.packed, layer.pbl_bias, xf, False, None)        # the ctypes route: the same launches
+        assert torch.equal(y, y2), M
+        xv = torch.cat([xf, xf], 1)[:, :1024]                                              # a strided view
+        assert torch.equal(layer(xv), y), M
+
+
 def test_bf16_fused_decode_of_a_bf16_model():
     """a bf16 HF LLaMA (how the checkpoints ship; qat/run_qat.py:120 trains under bf16) through fuse_decode_ + GraphedForward: the
     fused q/k/v and gate/up launches take bf16 activations directly (pbl_gemv_bf16_fused_host) -- logits of the fused model, eager and

@@ -21,7 +21,14 @@ def measure():
     for M in (1, 4, 16):
         x = torch.from_numpy(synth.activations((M, K), 5, 21)).to("cuda:0")
         xb = x.bfloat16()
-        for name, fn in (("pb", lambda: layer(x)), ("pb_bf16", lambda: layer(xb)), ("dense", lambda: dense(x))):
+        xf = x.float() * 1.0009765625
+
+        def torch_split():                      # fp32 x the way the route did it before round 5's split / join kernels: torch ops around ONE kernel call
+            hi = xf.half()
+            yy = Q.pb_linear_forward(layer.packed, None, torch.cat([hi, (xf - hi.float()).half()], 0), out_f32=True)
+            return yy[:M] + yy[M:]
+        for name, fn in (("pb", lambda: layer(x)), ("pb_bf16", lambda: layer(xb)), ("pb_f32", lambda: layer(xf)), ("pb_f32_torch_split", torch_split),
+                         ("dense", lambda: dense(x))):
             with torch.no_grad():
                 for _ in range(200): fn()
                 torch.cuda.synchronize()
