@@ -678,6 +678,7 @@ class PBLinear(nn.Module, BinaryInterface):
         return self.pbl_bias
 
     def forward(self, x):
+        x = _autocast_input(x)
         if torch.compiler.is_compiling():
             m = self._meta          # (the tracer cannot read tensor version counters; the header fields are constants of the module)
             if _lib.native_linear() is not None:     # the native operator has a Meta kernel: traced as one node
@@ -745,6 +746,19 @@ def _pack_sign_like(w_sim: torch.Tensor, hi: torch.Tensor, lo: torch.Tensor) -> 
     return pack_dense(w_sim, hi.reshape(N, 1), lo.reshape(N, 1), np.ones(N, np.float32), np.zeros(N, np.float32))
 
 
+def _autocast_input(x: torch.Tensor) -> torch.Tensor:
+    """F.linear is on autocast's lower-precision list: inside `torch.autocast("cuda", dtype)` it casts its floating-point inputs
+    (not float64) to `dtype` and returns `dtype` -- how the reference's modules run under the HF Trainer's bf16=True
+    (qat/run_qat.py:120).  A custom operator is invisible to autocast, so the modules do the cast themselves: the same output dtype
+    as the reference's, and ONE pass of the bf16 / fp16 kernels instead of the two fp16 terms an fp32 input takes (the weights stay
+    exact where the reference rounds them to bf16 too)."""
+    if x.is_cuda and x.is_floating_point() and x.dtype != torch.float64 and torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        if dt in (torch.float16, torch.bfloat16) and x.dtype != dt:
+            return x.to(dt)
+    return x
+
+
 class _DenseBacked(nn.Module, BinaryInterface):
     """Shared plumbing: keeps the reference's `weight`/`bias` Parameters and packs lazily."""
 
@@ -796,6 +810,7 @@ class _DenseBacked(nn.Module, BinaryInterface):
             # QAT step: the weights change every step, so nothing is packed; the dense simulated weight is
             # built on the GPU with the straight-through estimator and a library GEMM runs on it
             return torch.nn.functional.linear(x, self._train_weight(), self.bias)
+        x = _autocast_input(x)
         dd = torch.float16 if self.weight.dtype == torch.float16 else torch.float32
         return pb_linear_forward(self._packed_on(x.device), self._bias_f32(x.device), x, dense_dtype=dd)
 

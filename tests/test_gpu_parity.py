@@ -863,6 +863,40 @@ def test_fp32_activations_split_and_join_on_the_device():
         assert torch.equal(layer(xv), y), M
 
 
+def test_eval_forward_under_autocast_follows_f_linear():
+    """F.linear is on autocast's lower-precision list (the reference's modules under the HF Trainer's bf16=True, qat/run_qat.py:120):
+    fp32 / fp16 inputs are cast to the autocast dtype and the result has that dtype.  The packed modules do the same cast
+    themselves (a custom operator is invisible to autocast): output dtype and numbers against F.linear on the dense weight under
+    the same context, for a packed fp16 checkpoint layer and for a QAT module in eval() (fp32 weights)."""
+    Wq = synth.llm_weight(512, 1024, seed=5, heavy_tail=True)
+    mq = O.ptq_low_mask(Wq, 0.9, "magnitude", None, -1)
+    rq = O.ptq_rtn(Wq, mq, 8, -1)
+    bq = synth.normal((512,), 3, 3, 0.1)
+    layer = Q.PBLinear.from_dense(torch.from_numpy(rq["W_fq"]).half(), torch.from_numpy(bq), torch.from_numpy(mq), -1, rq["hscale"], rq["hzero"]).to(DEV)
+    qat = Q.BinaryXnorExceptOutliersLinear(torch.from_numpy(Wq), torch.from_numpy(bq), 0.1)
+    qat.eval(); qat.gen_outlier_mask(); qat = qat.to(DEV)
+    with torch.no_grad():
+        for mod in (layer, qat):
+            lin = mod.to_regular_linear().to(DEV)
+            for M in (1, 6, 40, 300):
+                xf = T(synth.activations((M, 1024), 11, M)).float()
+                assert mod(xf).dtype == torch.float32                              # no autocast: F.linear's own dtype rule
+                for dt in (torch.bfloat16, torch.float16):
+                    with torch.autocast("cuda", dtype=dt):
+                        y = mod(xf)
+                        ref = torch.nn.functional.linear(xf, lin.weight.float(), lin.bias.float())
+                        yh = mod(xf.half())                                       # an fp16 input is cast as well
+                    assert y.dtype == dt and ref.dtype == dt and yh.dtype == dt, (M, dt)
+                    yo = mod(xf.to(dt))                                           # the module on the cast input, outside the context
+                    if mod is layer:                                              # hand-written kernels at every row count: the same launches
+                        assert torch.equal(y, yo), (M, dt)
+                    else:                                                         # (fp32-grid layer in the GEMM regime: the library GEMM on the unpacked
+                        assert O.parity_errors(y.float().cpu().numpy(), yo.float().cpu().numpy().astype(np.float64))[0] < 2e-2     # weight is itself autocast)
+                    assert O.parity_errors(y.float().cpu().numpy(), ref.float().cpu().numpy().astype(np.float64))[0] < (2e-2 if dt == torch.bfloat16 else 2e-3), (M, dt)
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=False):
+                    assert mod(xf).dtype == torch.float32
+
+
 def test_bf16_fused_decode_of_a_bf16_model():
     """a bf16 HF LLaMA (how the checkpoints ship; qat/run_qat.py:120 trains under bf16) through fuse_decode_ + GraphedForward: the
     fused q/k/v and gate/up launches take bf16 activations directly (pbl_gemv_bf16_fused_host) -- logits of the fused model, eager and
