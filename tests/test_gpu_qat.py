@@ -213,3 +213,36 @@ def test_short_qat_training_run_tracks_reference_arithmetic():
         y = model(x)
         y_ref = ref_forward(x)
     assert relmax(y, y_ref.cpu().numpy().astype(np.float64)) < 2e-3
+
+
+def test_modules_under_gradient_checkpointing():
+    """the forward must work under gradient checkpointing (HF `gradient_checkpointing=True`; the reference's own
+    modules recompute their weights with torch.utils.checkpoint, quant/quantizer.py:108,192).  A checkpointed call -- forward
+    without a graph, forward again inside backward -- gives the gradients of a plain call: the QAT module in train() (dW, db, dx)
+    and a packed PBLinear in eval (dx through the operator's autograd formula)."""
+    from torch.utils.checkpoint import checkpoint
+    g = golden("g8_qat_step")
+    m = Q.BinaryXnorExceptOutliersLinear(T(g["W"]).cpu(), T(g["b"]).cpu(), 0.1)
+    m.train(); m.gen_outlier_mask()
+    m = m.to(DEV)
+    dy = T(g["dy"])
+
+    def grads(fn, params):
+        x = T(g["x"]).requires_grad_(True)
+        for p_ in params:
+            p_.grad = None
+        y = fn(x)
+        y.backward(dy.to(y.dtype))
+        return [y.detach().clone(), x.grad.clone()] + [p_.grad.clone() for p_ in params]
+    plain = grads(lambda x: m(x), [m.weight, m.bias])
+    ckpt = grads(lambda x: checkpoint(m, x, use_reentrant=False), [m.weight, m.bias])
+    for a, b in zip(plain, ckpt):
+        assert torch.equal(a, b)
+    m.eval()
+    packed = Q.PBLinear.from_dense(m.to_regular_linear().weight.detach().half().cpu(), T(g["b"]).cpu(), None, -1).to(DEV)
+    plain = grads(lambda x: packed(x), [])
+    ckpt = grads(lambda x: checkpoint(packed, x, use_reentrant=False), [])
+    ck_re = grads(lambda x: checkpoint(packed, x, use_reentrant=True), [])
+    for a, b, c in zip(plain, ckpt, ck_re):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert relmax(plain[1], (g["dy"].astype(np.float64) @ packed.weight.float().cpu().numpy().astype(np.float64))) < 1e-3
