@@ -944,3 +944,48 @@ def test_bf16_fused_decode_of_a_bf16_model():
         for t in (9, 10, 11):
             tok = ids[:, t:t + 1]
             assert torch.equal(g.replay(tok), plain(tok, use_cache=False).logits), t
+
+
+def test_concurrent_host_threads_on_their_own_streams():
+    """SURVEY 8(b) threading: "reentrant, no global mutable state; safe to call from multiple host threads on different streams".
+    Four host threads, each on its own stream, call ONE shared layer (whose GEMM image is built lazily by whoever gets there first)
+    and a layer of their own at GEMV, small-batch and GEMM-regime row counts with fp16 / bf16 / fp32 activations; every result is
+    bit for bit what a single thread computed before."""
+    import threading
+    Wq = synth.llm_weight(512, 1024, seed=5, heavy_tail=True)
+    mq = O.ptq_low_mask(Wq, 0.9, "magnitude", None, -1)
+    rq = O.ptq_rtn(Wq, mq, 8, -1)
+    bq = synth.normal((512,), 3, 3, 0.1)
+
+    def make():
+        return Q.PBLinear.from_dense(torch.from_numpy(rq["W_fq"]).half(), torch.from_numpy(bq), torch.from_numpy(mq), -1, rq["hscale"], rq["hzero"]).to(DEV)
+    first = make()
+    cases = []
+    for M in (1, 3, 12, 40, 300):
+        x = T(synth.activations((M, 1024), 13, M))
+        for xi in (x, x.bfloat16(), x.float() * 1.0009765625):
+            cases.append((xi, first(xi)))
+    torch.cuda.synchronize()
+    shared = make()                                              # no image yet: the threads race to build it
+    errors = []
+
+    def work(tid):
+        try:
+            own = make()
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st), torch.no_grad():
+                for rep in range(12):
+                    for k, (xi, want) in enumerate(cases):
+                        lay = shared if (k + rep + tid) % 2 else own
+                        xi_s = xi.clone()                        # (allocated and written on this thread's stream)
+                        y = lay(xi_s)
+                        if not torch.equal(y, want):
+                            errors.append((tid, rep, k, float((y.float() - want.float()).abs().max())))
+            st.synchronize()
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((tid, repr(e)))
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors[:5]
