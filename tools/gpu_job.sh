@@ -6,6 +6,7 @@
 #              7B-shaped forward fp16 + bf16                                                                   (calls r5-1, r5-3, r5-4)
 #   profiles   rocprofv3 kernel trace + PMC passes of the driver's command, of cfg4 and a kernel trace of cfg3            (call r5-3)
 #   variants   A/B builds from tools/build_variant.sh (build/libpbl_<name>.so, PBL_LIB): cfg4 per variant                 (call r5-5)
+#   gemvknobs  A/B builds of the headline GEMV's compile-time knobs (-DPBL_TILE_RING, -DPBL_GROUPED_WPB), the driver's command   (call r5k)
 #   sbsplit    A/B builds of the small-batch kernel's K-split rule (-DPBL_SB_MIN_HPS) on llama-7b shapes, tools/bench_small.py   (call r5z)
 #   bf16trace  kernel trace of a small decode batch with bf16 activations (tools/trace_bf16_small.py)                      (call r5x)
 #   plumbing8  eight ranks of `bench.py --gpus 8` time-slicing one device (PBL_BENCH_BACKEND=gloo)                        (call r5-1)
@@ -55,6 +56,11 @@ variants)
   for v in default ${VARIANTS:-sbw5 sbw6 sbw7}; do
     if [ $v = default ]; then unset PBL_LIB; else export PBL_LIB=build/libpbl_$v.so; fi
     timeout 300 python bench.py --workload cfg4 --steps 20 --warmup 5 > $O/cfg4_$v.json 2> $O/cfg4_$v.err; echo cfg4 $v; line $O/cfg4_$v.json
+  done ;;
+gemvknobs)
+  for v in default ${VARIANTS:-ring3 wpb2 wpb8} default; do
+    if [ $v = default ]; then unset PBL_LIB; else export PBL_LIB=build/libpbl_$v.so; fi
+    timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_$v.json 2> $O/bench_$v.err; echo "== $v"; line $O/bench_$v.json
   done ;;
 sbsplit)
   for v in default ${VARIANTS:-hps2 hps3 hps6}; do
