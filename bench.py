@@ -141,47 +141,90 @@ def cpu_baseline(dense_layers, K, M, budget_s=8.0):
     return out
 
 
-def run_side_workload(a):
-    """--workload cfg3 | cfg4: the other single-GPU configurations of BASELINE.json as bench lines of their own (the driver
-    runs the default workload; these feed profiles/).  One step = one pass over the configuration's linears.
+def side_layers(workload, dev, synth_mode):
+    """The linears of a side workload as PBLinear modules on `dev` (own device copy per linear) + M.
+    synth_mode "oracle": the structure comes from the oracle's restatement of the reference's RTN path on the host (what
+    `--workload cfg3 | cfg4` measured in rounds 3 - 5; tens of seconds of numpy per layer); "device": the product's own producer
+    (pb_llm_amd/ptq.py LowHighGPTQ, disable_gptq = RTN values, then to_pb: salient selection, quantizers and packer all on the
+    GPU -- row f2 of SURVEY 8) on random-init fp16 weights N(0, 0.02^2) with a 1 % heavy tail and, for the hessian metric,
+    calibration activations whose hot channels (1 %, 20 x) concentrate the salients in columns: the same kind of layer in a
+    fraction of a second, which is what lets the driver's own command carry these lines."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import pb_llm_amd.quant as Q
+    from pb_llm_amd import synth
+    shapes = ([("q", 4096, 4096)] * 4 + [("gate", 11008, 4096)] * 2 + [("down", 4096, 11008)]) if workload == "cfg3" else \
+             ([("ffn_in", 13824, 5120)] * 6 + [("ffn_out", 5120, 13824)] * 6)       # cfg4: 6 device copies each, beyond the Infinity Cache
+    M = 2048 if workload == "cfg3" else 32
+    low_frac, metric = (0.95, "hessian") if workload == "cfg3" else (0.8, "magnitude")
+    built = {}
+    if synth_mode == "oracle":
+        from cfg_shapes import hessian_layer
+        from oracle import pb_oracle as O
+        for _, N, K in shapes:
+            if (N, K) in built:
+                continue
+            if workload == "cfg3":
+                W, mask, r = hessian_layer(N, K, low_frac, seed=300 + len(built))
+            else:
+                W = synth.llm_weight(N, K, seed=N % 97)
+                mask = O.ptq_low_mask(W, low_frac, "magnitude", None, -1)
+                r = O.ptq_rtn(W, mask, 8, -1)
+            built[(N, K)] = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
+    else:
+        from pb_llm_amd.ptq import LowHighGPTQ
+        gen = torch.Generator(device=dev)
+        for _, N, K in shapes:
+            if (N, K) in built:
+                continue
+            gen.manual_seed(300 + len(built))
+            W = torch.randn(N, K, device=dev, generator=gen) * 0.02
+            tail = torch.rand(N, K, device=dev, generator=gen) < 0.01
+            W = torch.where(tail, W * 4.0, W)
+            lin = torch.nn.Linear(K, N, bias=False, device=dev, dtype=torch.float16)
+            lin.weight.data = W.half()
+            del W, tail
+            g = LowHighGPTQ(lin, metric, -1, 8, disable_gptq=True)
+            X = torch.randn(1024, K, device=dev, generator=gen)
+            if metric == "hessian":
+                hot = torch.randperm(K, device=dev, generator=gen)[:max(1, K // 100)]
+                X[:, hot] *= 20.0
+            g.add_batch(X)
+            g.fasterquant(low_frac)
+            built[(N, K)] = g.to_pb()
+            g.free()
+            del g, lin, X
+        torch.cuda.empty_cache()
+    def own_copy(pk):                                   # every linear multiplies from its own bytes in HBM
+        return type(pk)(pk.blob.to(dev).clone() if pk.blob.device == dev else pk.blob.to(dev), pk.N, pk.K, pk.P, pk.G, pk.NRB, pk.flags,
+                        pk.max_nch, pk.max_nexc, pk.nnz, pk.nexc)
+    layers = [Q.PBLinear(own_copy(built[(N, K)].packed), None) for _, N, K in shapes]
+    return layers, M
+
+
+def measure_side(workload, steps, warmup, preheat_s, gemm_backend="default", small_batch_image="default", synth_mode="oracle"):
+    """--workload cfg3 | cfg4: the other single-GPU configurations of BASELINE.json, as bench lines of their own (`--workload`)
+    and, compact, under "side" in the driver's default line (round 6).  One step = one pass over the
+    configuration's linears through the modules' forward with the LIBRARY'S DEFAULTS, timed with HIP events on torch's current
+    stream (the stream the modules launch on) after its own pre-heat.
       cfg3  configs[2]: the seven linears of a llama-7b decoder layer, low_frac 0.95 HESSIAN salients, M = 2048 (prefill);
             bound: fp16 MFMA (2.5 PFLOP/s dense).  value = tokens/s of the 32-layer stack's linears = M / (32 t_layer).
       cfg4  configs[3]: llama-13b FFN 13824x5120 and 5120x13824, low_frac 0.8, M = 32; bound: HBM."""
-    sys.path.insert(0, os.path.join(REPO, "tests"))
-    from cfg_shapes import LLAMA7B, hessian_layer
-    from oracle import pb_oracle as O
-    from pb_llm_amd import synth
     import pb_llm_amd.quant as Q
+    from pb_llm_amd import synth
     import __graft_entry__ as ge
     ge.build()
     dev = torch.device("cuda:0")
-    layers, flops, alg = [], 0.0, 0
-    if a.workload == "cfg3":
-        M = 2048
-        built = {}
-        for name, (N, K) in LLAMA7B.items():
-            key = (N, K)
-            if key not in built:
-                W, mask, r = hessian_layer(N, K, 0.95, seed=300 + len(built))
-                built[key] = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1,
-                                                   r["hscale"], r["hzero"])
-            layers.append(Q.PBLinear(built[key].packed.to(dev), None))           # own device copy per linear
-            flops += 2.0 * M * N * K
-    else:
-        M = 32
-        for N, K in ((13824, 5120), (5120, 13824)):
-            W = synth.llm_weight(N, K, seed=N % 97)
-            mask = O.ptq_low_mask(W, 0.8, "magnitude", None, -1)
-            r = O.ptq_rtn(W, mask, 8, -1)
-            base = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), None, torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
-            for _ in range(6):                                                    # 6 device copies each: beyond the Infinity Cache
-                layers.append(Q.PBLinear(base.packed.to(dev), None))
-    if a.gemm_backend != "default":
-        Q.GEMM_BACKEND = a.gemm_backend
-    a.gemm_backend = Q.GEMM_BACKEND                      # (what ran: reported in the line)
-    if a.workload == "cfg4" and a.small_batch_image != "default":
-        Q.SMALL_BATCH_IMAGE = a.small_batch_image
-    a.small_batch_image = Q.SMALL_BATCH_IMAGE
+    t_build = time.perf_counter()
+    layers, M = side_layers(workload, dev, synth_mode)
+    t_build = time.perf_counter() - t_build
+    flops = sum(2.0 * M * l.out_features * l.in_features for l in layers)
+    old = (Q.GEMM_BACKEND, Q.SMALL_BATCH_IMAGE)
+    if gemm_backend != "default":
+        Q.GEMM_BACKEND = gemm_backend
+    gemm_backend = Q.GEMM_BACKEND                      # (what ran: reported in the line)
+    if workload == "cfg4" and small_batch_image != "default":
+        Q.SMALL_BATCH_IMAGE = small_batch_image
+    small_batch_image = Q.SMALL_BATCH_IMAGE
     xs = {K: torch.from_numpy(synth.activations((M, K), 3, 21)).to(dev) for K in {l.in_features for l in layers}}
     alg = sum(l.packed.algorithmic_bytes(M) for l in layers)
 
@@ -189,50 +232,90 @@ def run_side_workload(a):
         for l in layers:
             l(xs[l.in_features])
 
-    with torch.no_grad():
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < a.preheat_s:
+    try:
+        with torch.no_grad():
+            t_pre = time.perf_counter()
             run(); torch.cuda.synchronize()
-        for _ in range(a.warmup):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
-        for _ in range(a.steps):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-    dev_s = e0.elapsed_time(e1) * 1e-3 / a.steps
-    n_img = sum(1 for l in layers if getattr(l.packed, "_gemm_image", (None, None))[1] is not None)
-    if a.workload == "cfg3":
+            while time.perf_counter() - t_pre < preheat_s:
+                run(); torch.cuda.synchronize()
+            for _ in range(warmup):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(steps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+    finally:
+        Q.GEMM_BACKEND, Q.SMALL_BATCH_IMAGE = old
+    dev_s = e0.elapsed_time(e1) * 1e-3 / steps
+    imgs = [getattr(l.packed, "_gemm_image", (None, None))[1] for l in layers]
+    n_img = sum(1 for i in imgs if i is not None)
+    if workload == "cfg3":
         roof = {"bound": "mfma", "achieved": flops / dev_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "traffic": None,
-                "kernel": ("pbl_unpack_kernel + library GEMM" if a.gemm_backend == "library" else
+                "kernel": ("pbl_unpack_kernel + library GEMM" if gemm_backend == "library" else
                            f"pbl_gemm_img_kernel ({n_img} of {len(layers)} layers have a GEMM image; the rest: " +
-                           ("pbl_gemm_kernel)" if a.gemm_backend in ("fused", "auto") else "pbl_unpack_kernel + library GEMM)")),
+                           ("pbl_gemm_kernel)" if gemm_backend in ("fused", "auto") else "pbl_unpack_kernel + library GEMM)")),
                 "us_per_step": 1e6 * dev_s}
-        value, unit = M / (32 * wall / a.steps), "tokens/s (linears of a 32-layer stack)"
+        value, unit = M / (32 * wall / steps), "tokens/s (linears of a 32-layer stack)"
         work = "llama-7b decoder-layer linears (q,k,v,o 4096x4096; gate,up 11008x4096; down 4096x11008), low_frac 0.95 hessian, M=2048"
     else:
         roof = {"bound": "hbm", "achieved": alg / dev_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-                "kernel": (f"pbl_sb_img_kernel + sb_reduce_kernel over the layers' GEMM images ({n_img} of {len(layers)} layers)" if n_img
+                "kernel": (f"small-batch kernel over the layers' GEMM images ({n_img} of {len(layers)} layers)" if n_img
                            else "pbl_mfma_kernel + pbl_mfma_reduce over the packed records"),
                 "us_per_step": 1e6 * dev_s, "us_per_layer": 1e6 * dev_s / len(layers),
+                "algorithmic_bytes_per_step": alg,
                 "blob_bytes": sum(l.packed.blob.numel() for l in layers),
-                "image_bytes": sum(l.packed._gemm_image[1].data.numel() for l in layers if getattr(l.packed, "_gemm_image", (None, None))[1] is not None)}
-        value, unit = len(layers) * M / (wall / a.steps), "layer-tokens/s"
+                "image_bytes": sum(i.data.numel() for i in imgs if i is not None)}
+        value, unit = len(layers) * M / (wall / steps), "layer-tokens/s"
         work = "llama-13b FFN 13824x5120 + 5120x13824 (6 device copies each), low_frac 0.8, M=32"
     roof["frac"] = roof["achieved"] / roof["peak"]
-    if a.workload == "cfg4" and roof.get("image_bytes"):
+    if workload == "cfg4" and roof.get("image_bytes"):
         # `achieved` counts the ALGORITHMIC bytes (the packed blob: what the layer needs); the image kernel reads the image instead
         roof["bytes_read_GBps"] = roof["image_bytes"] / dev_s / 1e9
         roof["bytes_read_frac"] = roof["bytes_read_GBps"] / roof["peak"]
-    print(json.dumps({"metric": f"PB-linear side workload {a.workload}", "value": value, "unit": unit, "n_gpus": 1,
-                      "steps": a.steps, "warmup": a.warmup, "preheat_s": a.preheat_s, "ms_per_step": 1e3 * wall / a.steps,
-                      "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 in/out, f32 accumulate",
-                      "data": "synthetic", "config": {"workload": work, "gemm_backend": a.gemm_backend, **({"small_batch_image": a.small_batch_image} if a.workload == "cfg4" else {})},
-                      "roofline": roof}), flush=True)
+    nnz = sum(int(l.packed.nnz) for l in layers)
+    tot = sum(l.out_features * l.in_features for l in layers)
+    line = {"metric": f"PB-linear side workload {workload}", "value": value, "unit": unit, "n_gpus": 1,
+            "steps": steps, "warmup": warmup, "preheat_s": preheat_s, "ms_per_step": 1e3 * wall / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16 in/out, f32 accumulate",
+            "data": "synthetic", "config": {"workload": work, "gemm_backend": gemm_backend, "synth": synth_mode, "salient_frac": nnz / tot,
+                                            "build_s": round(t_build, 2), **({"small_batch_image": small_batch_image} if workload == "cfg4" else {})},
+            "roofline": roof}
+    del layers, xs
+    torch.cuda.empty_cache()
+    return line
+
+
+def run_side_workload(a):
+    print(json.dumps(measure_side(a.workload, a.steps, a.warmup, a.preheat_s, a.gemm_backend, a.small_batch_image, a.synth)), flush=True)
+
+
+def side_summary(budget_note="library defaults, device-synthesised layers (the product's GPU producer), own pre-heat + HIP events"):
+    """configs[2] and configs[3] inside the driver's default line: {"cfg3": {...}, "cfg4": {...}}.  A side line
+    that fails is reported as {"error": ...}: the headline is never lost to it."""
+    out = {"note": budget_note}
+    for wl, steps, warmup, pre in (("cfg3", 10, 3, 1.0), ("cfg4", 20, 5, 1.0)):
+        t0 = time.perf_counter()
+        try:
+            l = measure_side(wl, steps, warmup, pre, synth_mode="device")
+            r = l["roofline"]
+            d = {"us_per_step": r["us_per_step"], "frac": r["frac"], "bound": r["bound"], "achieved": r["achieved"], "unit": r["unit"],
+                 "kernel": r["kernel"], "steps": steps, "warmup": warmup, "preheat_s": pre, "workload": l["config"]["workload"],
+                 "salient_frac": l["config"]["salient_frac"]}
+            if wl == "cfg4":
+                d.update(us_per_layer=r["us_per_layer"], bytes_read_frac=r.get("bytes_read_frac"), image_bytes=r.get("image_bytes"),
+                         blob_bytes=r.get("blob_bytes"), algorithmic_bytes_per_step=r.get("algorithmic_bytes_per_step"))
+            else:
+                d.update(gemm_backend=l["config"]["gemm_backend"])
+            d["wall_s"] = round(time.perf_counter() - t0, 2)
+            out[wl] = d
+        except Exception as e:       # noqa: BLE001 -- reported in the line
+            out[wl] = {"error": f"{type(e).__name__}: {str(e)[:300]}", "wall_s": round(time.perf_counter() - t0, 2)}
+    return out
 
 
 # role of layer i in a llama decoder layer (SURVEY 8(e) "LLaMA layer mapping"): True = K-split (+ all-reduce)
@@ -274,6 +357,9 @@ def main():
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
                     help="cfg2 = BASELINE configs[1], the headline GEMV stream (default, what the driver runs); cfg3 / cfg4: "
                          "configs[2] / configs[3] as side lines (see run_side_workload)")
+    ap.add_argument("--synth", choices=["oracle", "device"], default="oracle",
+                    help="cfg3 / cfg4: where the layers' structure comes from (see side_layers); the driver line's \"side\" entries use device")
+    ap.add_argument("--no-side", action="store_true", help="default workload: skip the cfg3 / cfg4 side entries of the line")
     ap.add_argument("--gemm-backend", choices=["default", "auto", "tuned", "library", "fused"], default="default",
                     help="cfg3: quant.GEMM_BACKEND -- default = the library's own setting (\"auto\": always the hand-written kernel over each "
                          "layer's GEMM image, round 5); tuned = round 4's routing (library GEMM where the 128 x 256 tiles leave a thin last "
@@ -653,6 +739,13 @@ def main():
                 out["rccl_per_layer_baseline"] = rccl_base
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline([b["W"] for b in base], a.K, a.M)
+        if world == 1 and not a.no_side and a.mode == "grouped":
+            # BASELINE configs[2] / configs[3] measured by the SAME process the driver times (after the headline: its numbers are
+            # final above; the stream's blobs are released first)
+            groups.clear()
+            run = None
+            torch.cuda.empty_cache()
+            out["side"] = side_summary()
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -410,13 +410,16 @@ int pbl_act_finish(const float* y_f32, const float* tok_scale, const float* bias
 /* fp32 activations (the reference's fp32-only module classes, quant/quantizer.py:78-80,175-177; QAT's fp32 master weights,
  * utils.py:34-36): F.linear(x_f32, w, b).  The packed kernels are linear in x, so x is split into two fp16 terms, both run through
  * the kernel in ONE call with an fp32 result, and the halves are added:
- *   pbl_act_f32_split  x [M, K] fp32 (rows ldx elements apart) -> x_f16 [2 M, K] fp16 contiguous: rows [0, M) = fp16(x),
- *                      rows [M, 2 M) = fp16(x - fp16(x));
- *   pbl_act_f32_join   y_out [M, N] (out_dtype) = cast((y_f32[t, r] + y_f32[M + t, r]) + bias[r]) for y_f32 [2 M, N] (16-byte
- *                      aligned, like bias and y_out); bias may be NULL.
+ *   pbl_act_f32_split  x [M, K] fp32 (rows ldx elements apart) -> x_f16 [2 M, K] fp16 contiguous + tok_scale [M] fp32: per token
+ *                      s = 2^max(0, exponent(amax) - 14) (pbl_act_bf16_prepare's rule), rows [0, M) = fp16(x / s), rows [M, 2 M) =
+ *                      fp16(x / s - fp16(x / s)), tok_scale[t] = s; a token holding inf / NaN becomes its indicator row (finite -> 0,
+ *                      +-inf -> +-1, NaN -> NaN; low term 0) with tok_scale[t] = +inf, so the result has F.linear's non-finite
+ *                      pattern.  tok_scale == NULL: the unscaled form (s = 1; overflows to a NaN row for |x| >= 65520);
+ *   pbl_act_f32_join   y_out [M, N] (out_dtype) = cast((y_f32[t, r] + y_f32[M + t, r]) * tok_scale[t] + bias[r]) for y_f32 [2 M, N]
+ *                      (16-byte aligned, like bias and y_out); tok_scale and bias may be NULL.
  * One small kernel each, no host synchronisation. */
-int pbl_act_f32_split(const float* x, int M, uint32_t K, size_t ldx, void* x_f16, void* stream);
-int pbl_act_f32_join(const float* y_f32, const float* bias, int M, uint32_t N, void* y_out, int out_dtype, void* stream);
+int pbl_act_f32_split(const float* x, int M, uint32_t K, size_t ldx, void* x_f16, float* tok_scale, void* stream);
+int pbl_act_f32_join(const float* y_f32, const float* tok_scale, const float* bias, int M, uint32_t N, void* y_out, int out_dtype, void* stream);
 
 /* bf16 activations in ONE launch (decode: one GEMV pass, M <= 4 rows of a group-free layer): x [M, K] bf16 -> y [M, N] bf16 (fp32 with
  * y_f32).  The kernel's staging phase does what pbl_act_bf16_prepare does and its epilogue what pbl_act_finish does -- the same bits
@@ -542,7 +545,7 @@ int pbl_linear_push_max_tokens(const pbl_layer* layer);
 int pbl_p2p_reduce_f32_dev(void* const* peer_bufs, int rank, int world, float* y_f32, void* y_f16, size_t n, size_t max_elems,
                            uint32_t expect_records, void* stream);
 
-int pbl_p2p_check(const void* own_buf);                        /* SYNCHRONOUS debugging aid: 1 if a wait ever timed out */
+int pbl_p2p_check(const void* own_buf);                        /* SYNCHRONOUS: 1 if a wait timed out since the last check (the word is then cleared) */
 
 #ifdef __cplusplus
 }

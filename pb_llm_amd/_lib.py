@@ -134,9 +134,9 @@ def lib() -> C.CDLL:
     L.pbl_gemm_small_image_ws.restype = C.c_int
     L.pbl_gemm_small_image_ws.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, sz, vp, vp, sz, vp]
     L.pbl_act_f32_split.restype = C.c_int
-    L.pbl_act_f32_split.argtypes = [vp, C.c_int, u32, sz, vp, vp]
+    L.pbl_act_f32_split.argtypes = [vp, C.c_int, u32, sz, vp, vp, vp]
     L.pbl_act_f32_join.restype = C.c_int
-    L.pbl_act_f32_join.argtypes = [vp, vp, C.c_int, u32, vp, C.c_int, vp]
+    L.pbl_act_f32_join.argtypes = [vp, vp, vp, C.c_int, u32, vp, C.c_int, vp]
     L.pbl_gemm_small_image_act.restype = C.c_int
     L.pbl_gemm_small_image_act.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, vp, sz, vp, vp, sz, vp]
     L.pbl_gemv_f16_fused.restype = C.c_int

@@ -160,32 +160,69 @@ __global__ __launch_bounds__(ACT_THREADS) void act_finish_kernel(const float* __
     }
 }
 
-// fp32 activations as two fp16 terms (the kernels are linear in x: W x = W hi + W lo, accumulated in fp32): hi = fp16(x),
-// lo = fp16(x - hi), written as rows [0, M) and [M, 2 M) of xh.  Four elements per thread.
+// fp32 activations as two fp16 terms (the kernels are linear in x: W x = W hi + W lo, accumulated in fp32), written as rows [0, M)
+// and [M, 2 M) of xh.  One workgroup per token row.  With `scale` (round 6; ADVICE r5: |x| >= 65520 gave hi = inf, lo = -inf and a
+// NaN row where F.linear(x_f32, ..) is finite) the row is first scaled by the power of two pbl_act_bf16_prepare uses,
+// s = 2^max(0, exponent(amax) - 14):  hi = fp16(x / s), lo = fp16(x / s - hi), scale[t] = s -- the same bits as the unscaled form
+// whenever amax < 2^15; a token that holds inf / NaN becomes its indicator row in hi (finite -> 0, +-inf -> +-1, NaN -> NaN), lo = 0,
+// scale[t] = +inf, so that (W . indicator) * inf has F.linear's pattern.  Without `scale`: hi = fp16(x), lo = fp16(x - hi).
 __global__ __launch_bounds__(ACT_THREADS) void act_f32_split_kernel(const float* __restrict__ x, uint32_t K, size_t ldx, size_t MK,
-                                                                    uint16_t* __restrict__ xh, int vec) {
-    const size_t i = (size_t(blockIdx.x) * ACT_THREADS + threadIdx.x) * 4;
-    if (i >= MK) return;
-    auto two = [&](float v, uint32_t& hi, uint32_t& lo) {
-        const _Float16 h = _Float16(v);
-        hi = uint32_t(__builtin_bit_cast(uint16_t, h));
-        lo = uint32_t(__builtin_bit_cast(uint16_t, _Float16(v - float(h))));
-    };
-    if (vec) {                                                  // K % 4 == 0, ldx % 4 == 0, 16-byte bases: four elements of one row
-        const size_t t = i / K;
-        const v4f v = *reinterpret_cast<const v4f*>(x + t * ldx + (i - t * K));
-        uint32_t h[4], l[4];
+                                                                    uint16_t* __restrict__ xh, float* __restrict__ scale) {
+    __shared__ uint32_t s_red[ACT_THREADS / 64];
+    const size_t t = blockIdx.x;
+    const float* src = x + t * ldx;
+    uint16_t* dhi = xh + t * size_t(K);
+    uint16_t* dlo = dhi + MK;
+    const int tid = threadIdx.x;
+    const bool vec = (K & 3u) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dhi) & 7) == 0 && (MK & 3) == 0;
+    bool finite = true;
+    float down = 1.f;
+    if (scale) {
+        uint32_t mx = 0;
+        if (vec) {
+            for (uint32_t i = tid; i < (K >> 2); i += ACT_THREADS) {
+                const u32x4 v = reinterpret_cast<const u32x4*>(src)[i];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) two(v[k], h[k], l[k]);
-        *reinterpret_cast<uint2*>(xh + i) = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-        *reinterpret_cast<uint2*>(xh + MK + i) = uint2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+                for (int j = 0; j < 4; ++j) { const uint32_t a = v[j] & 0x7FFFFFFFu; mx = a > mx ? a : mx; }
+            }
+        } else {
+            for (uint32_t i = tid; i < K; i += ACT_THREADS) { const uint32_t a = __builtin_bit_cast(uint32_t, src[i]) & 0x7FFFFFFFu; mx = a > mx ? a : mx; }
+        }
+        mx = block_max_u32(mx, s_red);
+        finite = mx < 0x7F800000u;
+        const int eb = int(mx >> 23) - 127 - 14;
+        const int e = eb > 0 ? eb : 0;
+        down = __builtin_bit_cast(float, uint32_t(127 - e) << 23);
+        if (tid == 0) scale[t] = finite ? __builtin_bit_cast(float, uint32_t(127 + e) << 23) : __builtin_inff();
+    }
+    auto two = [&](float v, uint32_t& hi, uint32_t& lo) {
+        if (finite) {
+            const float w = v * down;                            // exact (a power of two; fp32 subnormals of a row whose maximum is > 2^15 aside)
+            const _Float16 h = _Float16(w);
+            hi = uint32_t(__builtin_bit_cast(uint16_t, h));
+            lo = uint32_t(__builtin_bit_cast(uint16_t, _Float16(w - float(h))));
+        } else {
+            const uint32_t u = __builtin_bit_cast(uint32_t, v), a = u & 0x7FFFFFFFu;
+            const float r = a > 0x7F800000u ? v : (a == 0x7F800000u ? ((u >> 31) ? -1.f : 1.f) : 0.f);
+            hi = uint32_t(__builtin_bit_cast(uint16_t, _Float16(r)));
+            lo = 0u;
+        }
+    };
+    if (vec) {
+        for (uint32_t i = tid; i < (K >> 2); i += ACT_THREADS) {
+            const v4f v = reinterpret_cast<const v4f*>(src)[i];
+            uint32_t h[4], l[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) two(v[k], h[k], l[k]);
+            reinterpret_cast<uint2*>(dhi)[i] = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+            reinterpret_cast<uint2*>(dlo)[i] = uint2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+        }
         return;
     }
-    for (size_t j = i; j < MK && j < i + 4; ++j) {
-        const size_t t = j / K;
+    for (uint32_t i = tid; i < K; i += ACT_THREADS) {
         uint32_t h, l;
-        two(x[t * ldx + (j - t * K)], h, l);
-        xh[j] = uint16_t(h); xh[MK + j] = uint16_t(l);
+        two(src[i], h, l);
+        dhi[i] = uint16_t(h); dlo[i] = uint16_t(l);
     }
 }
 
@@ -223,31 +260,32 @@ extern "C" int pbl_act_finish(const float* y_f32, const float* tok_scale, const 
 }
 
 // fp32 activations (the reference's fp32-only module classes, quant/quantizer.py:78-80,175-177, and QAT's fp32 master weights,
-// utils.py:34-36): x [M, K] fp32 (rows ldx elements apart) -> x_f16 [2 M, K] fp16 contiguous, rows [0, M) = fp16(x), rows [M, 2 M)
-// = fp16(x - fp16(x)).  The packed kernels run ONCE over the 2 M rows with an fp32 result; pbl_act_f32_join adds the halves.
-extern "C" int pbl_act_f32_split(const float* x, int M, uint32_t K, size_t ldx, void* x_f16, void* stream) {
+// utils.py:34-36): x [M, K] fp32 (rows ldx elements apart) -> x_f16 [2 M, K] fp16 contiguous, rows [0, M) = the high term, rows
+// [M, 2 M) the low term (see act_f32_split_kernel).  tok_scale [M] (device fp32; NULL: the unscaled round-5 form, which overflows
+// for |x| >= 65520): the per-token power of two the row was divided by (+inf: a token with inf / NaN).  The packed kernels run ONCE
+// over the 2 M rows with an fp32 result; pbl_act_f32_join adds the halves and multiplies the scale back.
+extern "C" int pbl_act_f32_split(const float* x, int M, uint32_t K, size_t ldx, void* x_f16, float* tok_scale, void* stream) {
     if (!x || !x_f16 || M < 1 || K < 1 || ldx < K) return PBL_ERR_INVALID_ARG;
-    if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(x_f16) & 1)) return PBL_ERR_MISALIGNED;
+    if ((reinterpret_cast<uintptr_t>(x) & 3) || (reinterpret_cast<uintptr_t>(x_f16) & 1) || (reinterpret_cast<uintptr_t>(tok_scale) & 3)) return PBL_ERR_MISALIGNED;
     uint16_t* xh = static_cast<uint16_t*>(x_f16);
     size_t MK = size_t(M) * K;
-    int vec = !(K & 3u) && !(ldx & 3) && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(x_f16) & 7) && !(MK & 3);
-    void* argv[] = {&x, &K, &ldx, &MK, &xh, &vec};
-    return hipLaunchKernel(reinterpret_cast<const void*>(act_f32_split_kernel), dim3(uint32_t((MK + 4 * ACT_THREADS - 1) / (4 * ACT_THREADS))),
-                           dim3(ACT_THREADS), argv, 0, static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+    void* argv[] = {&x, &K, &ldx, &MK, &xh, &tok_scale};
+    return hipLaunchKernel(reinterpret_cast<const void*>(act_f32_split_kernel), dim3(uint32_t(M)), dim3(ACT_THREADS), argv, 0,
+                           static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
 }
 
-// y_out [M, N] (out_dtype) = cast((y_f32[t, r] + y_f32[M + t, r]) + bias[r]) for y_f32 [2 M, N]: the two terms of pbl_act_f32_split
-// added in fp32, the bias once.  One small kernel.
-extern "C" int pbl_act_f32_join(const float* y_f32, const float* bias, int M, uint32_t N, void* y_out, int out_dtype, void* stream) {
+// y_out [M, N] (out_dtype) = cast((y_f32[t, r] + y_f32[M + t, r]) * tok_scale[t] + bias[r]) for y_f32 [2 M, N]: the two terms of
+// pbl_act_f32_split added in fp32, the token's scale (NULL: 1) multiplied back, the bias once.  One small kernel.
+extern "C" int pbl_act_f32_join(const float* y_f32, const float* tok_scale, const float* bias, int M, uint32_t N, void* y_out, int out_dtype, void* stream) {
     if (!y_f32 || !y_out || M < 1 || N < 1) return PBL_ERR_INVALID_ARG;
     size_t MN = size_t(M) * N;
-    if ((reinterpret_cast<uintptr_t>(y_f32) & 15) || (reinterpret_cast<uintptr_t>(y_out) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)))
+    if ((reinterpret_cast<uintptr_t>(y_f32) & 15) || (reinterpret_cast<uintptr_t>(y_out) & 15) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) ||
+        (reinterpret_cast<uintptr_t>(tok_scale) & 3))
         return PBL_ERR_MISALIGNED;
     const void* k = out_dtype == PBL_DTYPE_F32 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_F32>)
                   : out_dtype == PBL_DTYPE_F16 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_F16>)
                   : out_dtype == PBL_DTYPE_BF16 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_BF16>) : nullptr;
     if (!k) return PBL_ERR_INVALID_ARG;
-    const float* tok_scale = nullptr;
     const float* y2 = y_f32 + MN;
     void* argv[] = {&y_f32, &tok_scale, &bias, &N, &MN, &y_out, &y2};
     return hipLaunchKernel(k, dim3(uint32_t((MN + 4 * ACT_THREADS - 1) / (4 * ACT_THREADS))), dim3(ACT_THREADS), argv, 0,

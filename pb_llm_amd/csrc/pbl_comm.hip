@@ -263,8 +263,13 @@ int pbl_p2p_reduce_f32_dev(void* const* peer_bufs, int rank, int world, float* y
 int pbl_p2p_check(const void* own_buf) {
     // debugging aid, SYNCHRONOUS: reads the status word behind the flags (1 = a wait timed out since the buffer was created)
     if (!own_buf) return PBL_ERR_INVALID_ARG;
+    // The word is cleared once it has been reported (it used to stay set for the buffer's life, so ONE transient stall --
+    // a first-use kernel load, a host hiccup on one rank -- left every later wait at the 1 ms limit and ordinary launch skew then
+    // poisoned results until the process ended): the caller raises for the call that timed out, later calls wait 3 s again.
     uint32_t w = 0;
-    if (hipMemcpy(&w, static_cast<const uint8_t*>(own_buf) + flags_bytes(), 4, hipMemcpyDeviceToHost) != hipSuccess) return PBL_ERR_LAUNCH;
+    uint8_t* sp = const_cast<uint8_t*>(static_cast<const uint8_t*>(own_buf)) + flags_bytes();
+    if (hipMemcpy(&w, sp, 4, hipMemcpyDeviceToHost) != hipSuccess) return PBL_ERR_LAUNCH;
+    if (w) { const uint32_t z = 0; if (hipMemcpy(sp, &z, 4, hipMemcpyHostToDevice) != hipSuccess) return PBL_ERR_LAUNCH; }
     return int(w);
 }
 

@@ -1330,8 +1330,9 @@ extern "C" int pbl_gemm_f16_image_ws(const pbl_layer* layer, const void* x, void
     const bool kt = (layer->K & (GI_XC - 1)) != 0;
     ImgPlan p = img_plan(layer, M);
     const size_t need = p.mode ? size_t(p.KS) * p.region_tok * p.region_col * sizeof(float) : 0;
+    // (the reduce reads the bias as 16-byte vectors: a bias that is not 16-byte aligned keeps the one-launch form -- ADVICE r5)
     if (p.mode && (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) || (p.region_col & 3) ||
-                   (layer->N & (om == 1 ? 3u : 7u)))) p.mode = 0;
+                   (layer->N & (om == 1 ? 3u : 7u)) || (reinterpret_cast<uintptr_t>(layer->bias) & 15))) p.mode = 0;
     // the full part (everything when the plan is one launch): whole K, straight to y
     a.rt0 = 0; a.tt0 = 0; a.nrt = p.mode == 2 ? p.cut : p.RT; a.ntt = p.mode == 1 ? p.cut : p.TT;
     a.h0 = 0; a.nh = NH; a.hps = NH; a.KSn = 1; a.part_stride = 0; a.ldy = layer->N; a.ycol0 = 0; a.ytok0 = 0;

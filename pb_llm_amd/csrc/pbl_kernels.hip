@@ -725,11 +725,15 @@ size_t lds_bytes(uint32_t P, uint32_t max_nch, int mb, int wpb, int split = 1) {
 template <int MB, int WPB, bool SF, int SPLIT = 1>
 int launch(const GemvArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     auto k = a.x_bf16 ? pbl_gemv_kernel<MB, WPB, SF, SPLIT, true> : pbl_gemv_kernel<MB, WPB, SF, SPLIT, false>;
-    if (lds > 64 * 1024) {
-        if (lds > 160 * 1024) return PBL_ERR_UNSUPPORTED;
+    // the bf16 instantiation holds s_amax / s_tscale in STATIC LDS on top of the dynamic size (4 MB (WPB + 1) bytes, rounded up):
+    // both limits are on the sum (a layer just under a limit failed the launch instead of answering UNSUPPORTED, which
+    // pbl_linear_bf16's callers turn into the three-launch form)
+    const size_t stat = a.x_bf16 ? ((size_t(4) * MB * (WPB + 1) + 15) & ~size_t(15)) + 16 : 16;
+    if (lds + stat > 64 * 1024) {
+        if (lds + stat > 160 * 1024) return PBL_ERR_UNSUPPORTED;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds)) != hipSuccess)
-            return PBL_ERR_LAUNCH;
+            return a.x_bf16 ? PBL_ERR_UNSUPPORTED : PBL_ERR_LAUNCH;
     }
     GemvArgs args = a;
     void* argv[] = {&args};

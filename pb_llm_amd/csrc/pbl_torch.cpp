@@ -180,18 +180,21 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
         return y.to(out_dt).reshape(shape);
     };
     // fp32 activations: x = x_hi + x_lo with both terms fp16; the kernels are linear in x, so y = W x_hi + W x_lo accumulated in
-    // fp32 (bias added once).  One launch each way (pbl_act_f32_split / _join, csrc/pbl_act.hip) around the packed kernel.
+    // fp32 (bias added once), each token scaled by a power of two so that no term leaves fp16's range.  One launch each way
+    // (pbl_act_f32_split / _join, csrc/pbl_act.hip) around the packed kernel.
+    at::Tensor f32_scale;                                  // tok_scale of split_f32(): a power of two per token (+inf: inf / NaN inside)
     auto split_f32 = [&]() {
         const at::Tensor xs = x2.stride(-1) == 1 && (M == 1 || x2.stride(0) >= K) ? x2 : x2.contiguous();
         at::Tensor xh = at::empty({2 * M, K}, x2.options().dtype(at::kHalf));
-        check(pbl_act_f32_split(xs.data_ptr<float>(), int(M), uint32_t(K), M == 1 ? size_t(K) : size_t(xs.stride(0)), xh.data_ptr(), stream_of(x2)),
-              "act_f32_split");
+        f32_scale = at::empty({M}, x2.options().dtype(at::kFloat));
+        check(pbl_act_f32_split(xs.data_ptr<float>(), int(M), uint32_t(K), M == 1 ? size_t(K) : size_t(xs.stride(0)), xh.data_ptr(),
+                                f32_scale.data_ptr<float>(), stream_of(x2)), "act_f32_split");
         return xh;
     };
     auto join_f32 = [&](const at::Tensor& yy) {
         at::Tensor y = at::empty({M, N}, yy.options().dtype(out_dt));
         const int dt = out_dt == at::kFloat ? PBL_DTYPE_F32 : (out_dt == at::kHalf ? PBL_DTYPE_F16 : PBL_DTYPE_BF16);
-        check(pbl_act_f32_join(yy.data_ptr<float>(), L.bias, int(M), uint32_t(N), y.data_ptr(), dt, stream_of(yy)), "act_f32_join");
+        check(pbl_act_f32_join(yy.data_ptr<float>(), f32_scale.data_ptr<float>(), L.bias, int(M), uint32_t(N), y.data_ptr(), dt, stream_of(yy)), "act_f32_join");
         return y.reshape(shape);
     };
     if (mok ? rows > MFMA_MAX : M >= GEMM_THRESHOLD) {

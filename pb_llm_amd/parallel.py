@@ -224,8 +224,9 @@ class P2PAllReduce:
         return True
 
     def check(self) -> None:
-        """synchronous: raises if any wait timed out since construction (a peer died or never launched; the affected
-        outputs were overwritten with NaN by the kernel)"""
+        """synchronous: raises if any wait timed out since the last check() (a peer died or never launched; the affected outputs
+        were overwritten with NaN by the kernel).  The status word is cleared when it is reported (round 6): one transient stall
+        poisons the calls up to this check, not every later one."""
         if self._own is not None and _lib.lib().pbl_p2p_check(self._own) != 0:
             raise _lib.PblError("P2PAllReduce: a peer's flag did not arrive within the bounded wait")
 

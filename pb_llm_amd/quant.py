@@ -473,19 +473,25 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype):
         run(layer_s, xin, y, nrows, True)
         return y
 
+    f32_scale = []                                      # tok_scale of the last split_f32() (one call per forward)
+
     def split_f32():
-        # fp32 activations: x = x_hi + x_lo with both terms fp16; the kernels are linear in x, so y = W x_hi + W x_lo accumulated
-        # in fp32 (bias added once).  One launch each way (pbl_act_f32_split / _join) around the packed kernel.
+        # fp32 activations: x = s (x_hi + x_lo) with both terms fp16 and s a per-token power of two (1 below 2^15: ADVICE r5 -- an
+        # unscaled split overflows fp16 at |x| >= 65520); the kernels are linear in x, so y = s (W x_hi + W x_lo) accumulated in fp32
+        # (bias added once).  One launch each way (pbl_act_f32_split / _join) around the packed kernel.
         xs = x2 if x2.dtype == torch.float32 else x2.float()
         xs = xs if xs.stride(-1) == 1 and (M == 1 or xs.stride(0) >= packed.K) else xs.contiguous()
         xh = torch.empty(2 * M, packed.K, dtype=torch.float16, device=x.device)
-        _lib.check(L.pbl_act_f32_split(xs.data_ptr(), M, packed.K, packed.K if M == 1 else xs.stride(0), xh.data_ptr(), stream), "act_f32_split")
+        tsc = torch.empty(M, dtype=torch.float32, device=x.device)
+        _lib.check(L.pbl_act_f32_split(xs.data_ptr(), M, packed.K, packed.K if M == 1 else xs.stride(0), xh.data_ptr(), tsc.data_ptr(), stream),
+                   "act_f32_split")
+        f32_scale[:] = [tsc]
         return xh
 
     def join_f32(yy):
         out = torch.empty(M, packed.N, dtype=torch.float32, device=x.device)
-        _lib.check(L.pbl_act_f32_join(yy.data_ptr(), bias_f32.data_ptr() if bias_f32 is not None else None, M, packed.N, out.data_ptr(),
-                                      _lib.PBL_DTYPE_F32, stream), "act_f32_join")
+        _lib.check(L.pbl_act_f32_join(yy.data_ptr(), f32_scale[0].data_ptr(), bias_f32.data_ptr() if bias_f32 is not None else None, M, packed.N,
+                                      out.data_ptr(), _lib.PBL_DTYPE_F32, stream), "act_f32_join")
         return (out if out_f32 or x.dtype == torch.float32 else out.to(x.dtype)).reshape(*lead, packed.N)
 
     if gemm_regime:

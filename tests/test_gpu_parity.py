@@ -829,11 +829,26 @@ def test_fp32_activations_split_and_join_on_the_device():
         x[0, 3] = 1.0e5                                            # beyond fp16: hi = inf, lo = -inf (what torch gives)
         x[M - 1, 7] = 3.0e-9                                       # below fp16's subnormals: hi = 0, lo = 0
         xh = torch.empty(2 * M, K, dtype=torch.float16, device=DEV)
-        _lib.check(L.pbl_act_f32_split(x.data_ptr(), M, K, K if M == 1 else x.stride(0), xh.data_ptr(), st), "split")
+        _lib.check(L.pbl_act_f32_split(x.data_ptr(), M, K, K if M == 1 else x.stride(0), xh.data_ptr(), None, st), "split")
         hi = x.half()
         lo = (x - hi.float()).half()
         assert torch.equal(xh[:M].view(torch.int16), hi.view(torch.int16)), (M, K)
         assert torch.equal(xh[M:].view(torch.int16), lo.contiguous().view(torch.int16)), (M, K)
+        # round 6: with tok_scale every row is first divided by s = 2^max(0, exponent(amax) - 14): rows below 2^15 keep
+        # the unscaled bits with s = 1, the row holding 1e5 (exponent 16) is divided by 4 and stays finite
+        tsc = torch.empty(M, dtype=torch.float32, device=DEV)
+        xs2 = torch.empty_like(xh)
+        _lib.check(L.pbl_act_f32_split(x.data_ptr(), M, K, K if M == 1 else x.stride(0), xs2.data_ptr(), tsc.data_ptr(), st), "split scaled")
+        want_s = torch.ones(M, device=DEV)
+        want_s[0] = 4.0
+        assert torch.equal(tsc, want_s), (M, K, tsc)
+        xd = x / want_s[:, None]
+        hi2 = xd.half()
+        lo2 = (xd - hi2.float()).half()
+        assert torch.isfinite(xs2.float()).all()
+        assert torch.equal(xs2[:M].view(torch.int16), hi2.view(torch.int16)) and torch.equal(xs2[M:].view(torch.int16), lo2.contiguous().view(torch.int16)), (M, K)
+        if M > 1:
+            assert torch.equal(xs2[1:M].view(torch.int16), xh[1:M].view(torch.int16)) and torch.equal(xs2[M + 1:].view(torch.int16), xh[M + 1:].view(torch.int16))
     for M, N, with_bias in ((1, 4096, True), (5, 78, True), (3, 1001, False), (40, 512, True)):
         yy = torch.from_numpy(synth.normal((2 * M, N), 5, M, 3.0)).float().to(DEV)
         b = torch.from_numpy(synth.normal((N,), 6, M, 0.5)).float().to(DEV) if with_bias else None
@@ -842,8 +857,13 @@ def test_fp32_activations_split_and_join_on_the_device():
             want = want + b
         for dt, code in ((torch.float32, _lib.PBL_DTYPE_F32), (torch.float16, _lib.PBL_DTYPE_F16), (torch.bfloat16, _lib.PBL_DTYPE_BF16)):
             out = torch.empty(M, N, dtype=dt, device=DEV)
-            _lib.check(L.pbl_act_f32_join(yy.data_ptr(), b.data_ptr() if b is not None else None, M, N, out.data_ptr(), code, st), "join")
+            _lib.check(L.pbl_act_f32_join(yy.data_ptr(), None, b.data_ptr() if b is not None else None, M, N, out.data_ptr(), code, st), "join")
             assert torch.equal(out, want.to(dt)), (M, N, dt)
+            sc = torch.ones(M, device=DEV)
+            sc[M - 1] = 8.0
+            _lib.check(L.pbl_act_f32_join(yy.data_ptr(), sc.data_ptr(), b.data_ptr() if b is not None else None, M, N, out.data_ptr(), code, st), "join scaled")
+            want_sc = (yy[:M] + yy[M:]).double() * sc[:, None].double() + (b.double() if b is not None else 0.0)      # one rounding (fma)
+            assert torch.equal(out, want_sc.float().to(dt)), (M, N, dt, "scaled")
     # the module route: a layer with bias at GEMV, small-batch and GEMM-regime row counts, both routes, against the float64 oracle
     Wq = synth.llm_weight(512, 1024, seed=5, heavy_tail=True)
     mq = O.ptq_low_mask(Wq, 0.9, "magnitude", None, -1)
@@ -861,6 +881,42 @@ def test_fp32_activations_split_and_join_on_the_device():
         assert torch.equal(y, y2), M
         xv = torch.cat([xf, xf], 1)[:, :1024]                                              # a strided view
         assert torch.equal(layer(xv), y), M
+
+
+@pytest.mark.parametrize("M", [2, 40, 300])
+def test_fp32_activations_beyond_fp16_range_and_non_finite(M):
+    """the fp32 route's fp16 terms had no range handling -- |x| >= 65520 gave hi = inf, lo = -inf and a NaN row,
+    an inf input gave NaN instead of +-inf, where the reference's F.linear(x_f32, w, b) (quant/quantizer.py:86,193) is finite / +-inf.
+    Round 6: per-token power-of-two scaling (pbl_act_f32_split emits tok_scale, pbl_act_f32_join multiplies it back).  GEMV (2 rows),
+    small-batch (40) and GEMM-regime (300) row counts, native operator and ctypes route, against the float64 oracle at 2e-5."""
+    Wq = synth.llm_weight(512, 1024, seed=15, heavy_tail=True)
+    mq = O.ptq_low_mask(Wq, 0.9, "magnitude", None, -1)
+    rq = O.ptq_rtn(Wq, mq, 8, -1)
+    bq = synth.normal((512,), 3, 13, 0.1)
+    layer = Q.PBLinear.from_dense(torch.from_numpy(rq["W_fq"]).half(), torch.from_numpy(bq), torch.from_numpy(mq), -1, rq["hscale"], rq["hzero"]).to(DEV)
+    Wd = layer.weight.float().cpu().numpy()
+    xf = T(synth.activations((M, 1024), 19, M)).float() * 1.0009765625
+    xf[0, 5] = 7.0e4                                               # one outlier beyond fp16 in an ordinary row
+    xf[M - 1] *= 3.0e6                                             # a whole row far outside
+    xf[M // 2, 9] = -1.5e30
+    ref = O.dense_linear(xf.cpu().numpy().astype(np.float64), Wd, bq)
+    for route in ("native", "ctypes"):
+        y = layer(xf) if route == "native" else Q._pb_linear_forward(layer.packed, layer.pbl_bias, xf, False, None)
+        assert y.dtype == torch.float32 and bool(torch.isfinite(y).all()), (route, M)
+        assert O.parity_errors(y.cpu().numpy(), ref)[0] < 2e-5, (route, M)
+    # an infinity: the row's outputs are +-inf by the sign of the weight it meets (NaN where that weight is 0), the other rows finite
+    xi = xf.clone()
+    xi[0, 11] = float("inf")
+    want = torch.nn.functional.linear(xi.cpu(), torch.from_numpy(Wd), torch.from_numpy(bq))
+    y = layer(xi)
+    got0, want0 = y[0].cpu(), want[0]
+    assert bool(torch.isinf(want0).any())
+    assert torch.equal(torch.isnan(got0), torch.isnan(want0)) and torch.equal(got0[torch.isinf(want0)], want0[torch.isinf(want0)]), M
+    assert bool(torch.isfinite(y[1:]).all()) and O.parity_errors(y[1:].cpu().numpy(), ref[1:])[0] < 2e-5
+    xn = xf.clone()
+    xn[M - 1, 0] = float("nan")
+    yn = layer(xn)
+    assert bool(torch.isnan(yn[M - 1]).all()) and bool(torch.isfinite(yn[:M - 1]).all())
 
 
 def test_eval_forward_under_autocast_follows_f_linear():

@@ -122,12 +122,14 @@ def test_activation_entry_points_check_their_arguments():
     # pbl_gemm_f16_image_ex: bf16 output needs the per-token scales, the other types must not get them
     assert L.pbl_gemm_f16_image_ex(C.byref(lay), 16, 16, 4, _lib.PBL_DTYPE_BF16, None, 16, 64, 16, None) == _lib.PBL_ERR_INVALID_ARG
     assert L.pbl_gemm_f16_image_ex(C.byref(lay), 16, 16, 4, 9, None, 16, 64, 16, None) == _lib.PBL_ERR_INVALID_ARG
-    assert L.pbl_act_f32_split(None, 1, 8, 8, 16, None) == _lib.PBL_ERR_INVALID_ARG
-    assert L.pbl_act_f32_split(16, 2, 8, 4, 16, None) == _lib.PBL_ERR_INVALID_ARG                 # ldx < K
-    assert L.pbl_act_f32_split(18, 1, 8, 8, 16, None) == _lib.PBL_ERR_MISALIGNED
-    assert L.pbl_act_f32_join(None, None, 1, 8, 16, 0, None) == _lib.PBL_ERR_INVALID_ARG
-    assert L.pbl_act_f32_join(16, None, 1, 8, 16, 7, None) == _lib.PBL_ERR_INVALID_ARG            # unknown dtype
-    assert L.pbl_act_f32_join(16, 20, 1, 8, 16, 0, None) == _lib.PBL_ERR_MISALIGNED               # bias
+    assert L.pbl_act_f32_split(None, 1, 8, 8, 16, 16, None) == _lib.PBL_ERR_INVALID_ARG
+    assert L.pbl_act_f32_split(16, 2, 8, 4, 16, 16, None) == _lib.PBL_ERR_INVALID_ARG             # ldx < K
+    assert L.pbl_act_f32_split(18, 1, 8, 8, 16, 16, None) == _lib.PBL_ERR_MISALIGNED
+    assert L.pbl_act_f32_split(16, 1, 8, 8, 16, 18, None) == _lib.PBL_ERR_MISALIGNED              # tok_scale (round 6)
+    assert L.pbl_act_f32_join(None, None, None, 1, 8, 16, 0, None) == _lib.PBL_ERR_INVALID_ARG
+    assert L.pbl_act_f32_join(16, None, None, 1, 8, 16, 7, None) == _lib.PBL_ERR_INVALID_ARG      # unknown dtype
+    assert L.pbl_act_f32_join(16, None, 20, 1, 8, 16, 0, None) == _lib.PBL_ERR_MISALIGNED         # bias
+    assert L.pbl_act_f32_join(16, 18, None, 1, 8, 16, 0, None) == _lib.PBL_ERR_MISALIGNED         # tok_scale
     # the small-batch kernel for scaled activations: a token scale and a bf16 / fp32 result, 1 - 64 rows
     assert L.pbl_gemm_small_image_act(C.byref(lay), 16, 16, 8, _lib.PBL_DTYPE_BF16, None, 16, 64, 16, None, 0, None) == _lib.PBL_ERR_INVALID_ARG
     assert L.pbl_gemm_small_image_act(C.byref(lay), 16, 16, 8, _lib.PBL_DTYPE_F16, 16, 16, 64, 16, None, 0, None) == _lib.PBL_ERR_INVALID_ARG
