@@ -748,14 +748,19 @@ struct SbArgs {
     const uint32_t* rtab;
     const uint32_t* levels;
 };
-#ifndef SB_WAVES
-#define SB_WAVES 4                   // working waves of a workgroup (+ 1 that stages x)
-#endif
+#define SB_WAVES 4                   // working waves of a round-4 workgroup (+ 1 that stages x): RP = 4 row pairs, KQ = 1
 #ifndef PBL_SB_WGS_PER_CU
-#define PBL_SB_WGS_PER_CU 2          // workgroups per CU the K split aims at
+#define PBL_SB_WGS_PER_CU 2          // workgroups per CU the K split of the round-4 geometry aims at
 #endif
-#define SB_X_OFF (SB_WAVES * 8192)
-#define SB_LDS(NTB_) (SB_X_OFF + 2 * 8192 * (NTB_))      // + the x tile's double buffer: 32 NTB tokens x 128 columns each
+// Round 6 ("remove the K split instead of tuning it"): the workgroup's geometry is a template parameter pair --
+// RP row pairs x KQ K PHASES.  Working wave w owns row pair w % RP and phase w / RP: of the workgroup's range of half slabs it takes
+// h0 + KQ j + phase (j = 0, 1, ...: the phases interleave, so the workgroup as a whole streams each record's slots front to back and
+// the staging wave's x tiles of a step are one contiguous range of columns).  The KQ phases' accumulators of a row pair are added
+// through LDS in phase order at the end (deterministic), so a layer with enough rows needs NO split across workgroups: no partial
+// tiles in HBM, no workspace, no second launch (13824 x 5120: 216 workgroups of 2 x 4 waves instead of 432 of 4 + a reduce launch
+// over 4 x 1.77 MB of partials).  Layers with few rows keep the round-4 geometry and its split across gridDim.y.
+#define SB_X_OFF(RP_, KQ_) ((RP_) * (KQ_) * 8192)
+#define SB_LDS(NTB_, RP_, KQ_) (SB_X_OFF(RP_, KQ_) + 2 * (KQ_) * 8192 * (NTB_))   // + the x tiles' double buffer: KQ x (32 NTB tokens x 128 columns)
 
 typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;        // constant address space: scalar loads
 // Half slabs of slot requests in flight per wave (2 sets each).  Measured on 13824 x 5120, 20 % salients, 32 rows (calls r4-30 .. 32):
@@ -769,16 +774,24 @@ typedef const __attribute__((address_space(4))) uint32_t* const_u32_ptr;        
 #ifndef PBL_SB_WPE
 #define PBL_SB_WPE(NVK_, NTB_) ((NTB_) == 1 && (NVK_) <= 3 ? 4 : 3)   // (what the register allocator reaches: 33 - 64 rows hold two accumulator blocks)
 #endif
+#ifndef PBL_SB_WPE_KQ
+// the K-phase geometries are limited by their LDS, not their registers: 2 x 4 is ONE workgroup of 9 waves per CU (three waves on one
+// SIMD: <= 168 VGPRs), 1 x 3 two workgroups of 4 waves (two per SIMD)
+#define PBL_SB_WPE_KQ(RP_, KQ_) ((RP_) * (KQ_) + 1 > 8 ? 3 : 2)
+#endif
 #ifndef PBL_SB_NT
 #define PBL_SB_NT 0                  // slot loads with the non-temporal hint (the image is read once)
 #endif
 // NTB: blocks of 32 rows of x (1: up to 32 rows, 2: up to 64 -- the image is still read once; twice the x tile, accumulators, MFMAs)
-template <int NVK, bool KT, int NTB>
-__global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_per_eu(PBL_SB_WPE(NVK, NTB), PBL_SB_WPE(NVK, NTB)))) void pbl_sb_img_kernel(SbArgs a) {
+template <int NVK, bool KT, int NTB, int RP, int KQ>
+__global__ __launch_bounds__((RP * KQ + 1) * GW) __attribute__((amdgpu_waves_per_eu(KQ > 1 ? PBL_SB_WPE_KQ(RP, KQ) : PBL_SB_WPE(NVK, NTB), KQ > 1 ? PBL_SB_WPE_KQ(RP, KQ) : PBL_SB_WPE(NVK, NTB))))
+void pbl_sb_img_kernel(SbArgs a) {
     constexpr int D = PBL_SB_DEPTH;
     static_assert(D >= 2 && D % 2 == 0, "the x double buffer's parity is static in the unrolled loop");
-    __shared__ __attribute__((aligned(16))) char smem_s[SB_LDS(NTB)];
+    constexpr int NWORK = RP * KQ;
+    __shared__ __attribute__((aligned(16))) char smem_s[SB_LDS(NTB, RP, KQ)];
     constexpr uint32_t XBUF = 8192u * NTB;                    // one x tile
+    constexpr uint32_t XOFF = SB_X_OFF(RP, KQ);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const pbl_layer& L = a.L;
@@ -786,7 +799,9 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
     const int NH = (K + GI_HS - 1) / GI_HS;
     const int ks = int(blockIdx.y);
     const int h0 = ks * a.hps, h1 = min(h0 + a.hps, NH);
-    if (wave == SB_WAVES) {
+    const int nsteps = (h1 - h0 + KQ - 1) / KQ;               // steps of the workgroup: every phase takes (at most) one half slab per step
+    const int nstepsp = (nsteps + D - 1) / D * D;             // (the working waves run whole rounds of their slot ring: one barrier per step of those)
+    if (wave == NWORK) {
         // ---- the staging wave.  x tile of a half slab in LDS: [32 tokens][16 units of 8 columns], unit u of token t at
         // 256 t + 16 (u ^ (t & 15)).  A DMA piece is 1 KiB = 4 token rows: lane l lands on unit (l & 15) of token 4 piece + (l >> 4),
         // which holds the LOGICAL unit (l & 15) ^ (token & 15).  Through a buffer descriptor over the M rows of x: tokens >= M read zeros.
@@ -801,25 +816,35 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
             // the units of the LAST half slab beyond K would hold the next token row: pushed out of the descriptor's range, they read zeros
             if constexpr (KT) xvlast[q] = xvoff[q] + ((ktail_units && lu >= ktail_units) ? 0x40000000u : 0u);
         }
-        const int h1p = h0 + (h1 - h0 + D - 1) / D * D;       // (the working waves run whole rounds of their slot ring: one barrier per half slab of those)
-        for (int h = h0; h <= h1p; ++h) {                    // x of half slab h into buffer (h - h0) & 1, then the barrier the others open half slab h behind
-            if (h < h1) {
-                const uint32_t buf = uint32_t(h - h0) & 1u;
+        for (int st = 0; st <= nstepsp; ++st) {              // x of step st (KQ half slabs) into buffer st & 1, then the barrier the others open step st behind
+            if (st < nsteps) {
+                const uint32_t buf = uint32_t(st) & 1u;
 #pragma unroll
-                for (int q = 0; q < 8 * NTB; ++q) {
-                    uint32_t vo = xvoff[q];
-                    if constexpr (KT) vo = (h == NH - 1) ? xvlast[q] : vo;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_s + SB_X_OFF + buf * XBUF + uint32_t(q) * 1024u), 16, int(vo), h * (GI_HS * 2), 0, 0);
+                for (int ph = 0; ph < KQ; ++ph) {
+                    const int h = h0 + st * KQ + ph;
+                    if (h >= h1) break;                      // (the last step of a range that is not a multiple of KQ: those phases idle)
+#pragma unroll
+                    for (int q = 0; q < 8 * NTB; ++q) {
+                        uint32_t vo = xvoff[q];
+                        if constexpr (KT) vo = (h == NH - 1) ? xvlast[q] : vo;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_s + XOFF + (buf * KQ + uint32_t(ph)) * XBUF + uint32_t(q) * 1024u), 16, int(vo),
+                                                                 h * (GI_HS * 2), 0, 0);
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                    // barrier h - h0: x(h) is complete; everyone has left the buffer x(h + 1) goes to
+            __builtin_amdgcn_s_barrier();                    // barrier st: x(st) is complete; everyone has left the buffer x(st + 1) goes to
             asm volatile("" ::: "memory");
+        }
+        if constexpr (KQ > 1) {                              // the two barriers of the phases' reduction (every wave of the workgroup takes them)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
         }
         return;
     }
+    const int rp = KQ > 1 ? wave % RP : wave, kq = KQ > 1 ? wave / RP : 0;      // this wave's row pair of the workgroup, its K phase
     const uint32_t npairs = (L.NRB + 1) / 2;
-    const uint32_t pair_raw = blockIdx.x * SB_WAVES + uint32_t(wave);
+    const uint32_t pair_raw = blockIdx.x * RP + uint32_t(rp);
     const uint32_t pair = min(pair_raw, npairs - 1);         // (a surplus wave mirrors the last pair: it keeps the barriers and stores nothing)
     char* const As = smem_s + wave * 8192;
     const uint32_t* levels = a.levels;
@@ -887,7 +912,7 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
 #pragma unroll
     for (int k8 = 0; k8 < 8; ++k8) {
         aq[k8] = uint32_t(i32) * 256u + ((uint32_t(2 * k8 + g) ^ uint32_t(i32 & 15)) << 4);
-        bq[k8] = SB_X_OFF + aq[k8];                           // (the x tile has the A tile's geometry: 32 rows of 256 bytes, the same swizzle)
+        bq[k8] = XOFF + uint32_t(kq) * XBUF + aq[k8];        // (the x tile has the A tile's geometry: 32 rows of 256 bytes, the same swizzle; this phase's tile of a buffer)
     }
     v16f acc[NTB];
 #pragma unroll
@@ -895,49 +920,112 @@ __global__ __launch_bounds__((SB_WAVES + 1) * GW) __attribute__((amdgpu_waves_pe
 #pragma unroll
         for (int e_ = 0; e_ < 16; ++e_) acc[b][e_] = 0.f;
 
-    {
-        const uint32_t g0 = (uint32_t(h0) * GI_HS) / gs;
-        load_levels(0, g0); load_levels(1, g0);
-    }
+    // this wave's half slabs: hs(j) = h0 + KQ j + kq, j = 0 .. nsteps - 1 (live while < h1; the last step of a range that is not a
+    // multiple of KQ idles the higher phases)
+    const int hfirst = min(h0 + kq, h1 - 1);
+    uint32_t gcur = (uint32_t(hfirst) * GI_HS) / gs;          // the column group whose levels the SGPRs hold
+    load_levels(0, gcur); load_levels(1, gcur);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         // (in THIS order: the compiler counts vmcnt for the loop's first use of a set from the loads issued behind it on every path
         // into the loop; left free, the scheduler puts set 0's loads last in the prologue and the loop then waits for all but five)
-        request(0, h0 + j, e[2 * j], nvs[2 * j]);
+        request(0, h0 + KQ * j + kq, e[2 * j], nvs[2 * j]);
         asm volatile("" ::: "memory");
-        request(1, h0 + j, e[2 * j + 1], nvs[2 * j + 1]);
+        request(1, h0 + KQ * j + kq, e[2 * j + 1], nvs[2 * j + 1]);
         asm volatile("" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();                            // barrier 0: x of the first half slab is in LDS
+    __builtin_amdgcn_s_barrier();                            // barrier 0: x of the first step is in LDS
     asm volatile("" ::: "memory");
-    // `live`: false for the half slabs that pad the split's last round of the ring (wave uniform).  They keep the round's shape --
-    // the same loads, the same barrier -- and skip the work: with the SAME number of loads on every path through the loop the
-    // compiler's vmcnt counts stay at "all younger sets in flight" (an early exit from the round, or a remainder behind the loop,
-    // made it size the round's first wait for the shortest path: vmcnt(5) instead of vmcnt(21)).
-    auto half_slab = [&](int h, uint32_t buf, u32x4 (&sa)[NVK], u32x4 (&sb)[NVK], uint32_t& nva, uint32_t& nvb, bool live) {
-        if (live && L.G > 1 && h > h0 && (uint32_t(h) * GI_HS) % gs == 0) { const uint32_t gg = (uint32_t(h) * GI_HS) / gs; load_levels(0, gg); load_levels(1, gg); }
+    // `live`: false for the steps that pad the last round of the ring, and for a phase beyond the range's end (wave uniform).  They
+    // keep the round's shape -- the same loads, the same barrier -- and skip the work: with the SAME number of loads on every path
+    // through the loop the compiler's vmcnt counts stay at "all younger sets in flight" (an early exit from the round, or a
+    // remainder behind the loop, made it size the round's first wait for the shortest path: vmcnt(5) instead of vmcnt(21)).
+    // The fragment reads are issued from inline asm one k-step ahead of the MFMA that consumes them and waited for with a counted
+    // lgkmcnt (LDS returns in order; the reads come after this wave's tile stores in program order, and a wave's LDS operations
+    // execute in order): round 4 left them to the compiler, which kept the pipelined form (`lgkmcnt(2)`) in some builds and fell back
+    // to read - wait(0) - multiply per k-step in others (round 6: any change to the loop around it) -- a full LDS latency in front of
+    // each of the eight MFMAs of a half slab, on the critical path of a wave that has few neighbours to hide behind.
+    struct SbFrag { v8h a, b[NTB]; };
+    const uint32_t a_off = uint32_t(wave) * 8192u;
+    auto half_slab = [&](int h, auto buf_tag, u32x4 (&sa)[NVK], u32x4 (&sb)[NVK], uint32_t& nva, uint32_t& nvb, bool live) {
+        constexpr uint32_t XB0 = uint32_t(decltype(buf_tag)::value) * (KQ * XBUF);     // this step's x buffer (immediate offset)
+        if (live && L.G > 1) {
+            const uint32_t gg = (uint32_t(h) * GI_HS) / gs;
+            if (gg != gcur) { gcur = gg; load_levels(0, gg); load_levels(1, gg); }
+        }
         if (live) expand(0, sa, nva);
-        request(0, h + D, sa, nva);
+        request(0, h + KQ * D, sa, nva);
         if (live) expand(1, sb, nvb);
-        request(1, h + D, sb, nvb);
+        request(1, h + KQ * D, sb, nvb);
         if (live) {
+            SbFrag f[2];
+            auto load_frag = [&](SbFrag& d, int k8) {
+                asm volatile("ds_read_b128 %0, %1" : "=&v"(d.a) : "v"(a_off + aq[k8]) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d.b[0]) : "v"(bq[k8]), "n"(XB0) : "memory");
+                if constexpr (NTB == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(d.b[1]) : "v"(bq[k8]), "n"(XB0 + 8192u) : "memory");
+            };
+            auto wait_frag = [&](SbFrag& d, auto n_tag) {                  // d has landed; n younger reads stay in flight
+                constexpr int NOUT = decltype(n_tag)::value;
+                if constexpr (NTB == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(d.a), "+v"(d.b[0]), "+v"(d.b[1]) : "n"(NOUT) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(d.a), "+v"(d.b[0]) : "n"(NOUT) : "memory");
+            };
+            load_frag(f[0], 0);
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8) {
-                const v8h af = *reinterpret_cast<const v8h*>(As + aq[k8]);
-#pragma unroll
-                for (int b = 0; b < NTB; ++b) {
-                    const v8h bf = *reinterpret_cast<const v8h*>(smem_s + bq[k8] + buf * XBUF + uint32_t(b) * 8192u);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[b], 0, 0, 0);
+                if (k8 < 7) {
+                    load_frag(f[(k8 + 1) & 1], k8 + 1);
+                    wait_frag(f[k8 & 1], std::integral_constant<int, 1 + NTB>{});
+                } else {
+                    wait_frag(f[k8 & 1], std::integral_constant<int, 0>{});
                 }
+#pragma unroll
+                for (int b = 0; b < NTB; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k8 & 1].a, f[k8 & 1].b[b], acc[b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);                         // (nothing moves across: the MFMAs stay between their wait and the next one)
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's fragment reads of the x tile are done; then everyone's, and the next tile is in
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
-    for (int h = h0; h < h1; h += D) {
+    // (the induction variable is the round's first half slab of PHASE 0 -- the same trip count, i.e. the same barriers, for every phase;
+    // written over the step index instead, the compiler kept 24 more VGPRs live and the 128-register variants spilled)
+    static_assert(D == 2 || D == 4, "the ring's steps are spelled out (their x buffer is an immediate offset)");
+    for (int hb = h0; hb < h1; hb += KQ * D) {
+        half_slab(hb + kq, std::integral_constant<int, 0>{}, e[0], e[1], nvs[0], nvs[1], hb + kq < h1);
+        half_slab(hb + KQ + kq, std::integral_constant<int, 1>{}, e[2], e[3], nvs[2], nvs[3], hb + KQ + kq < h1);
+        if constexpr (D == 4) {
+            half_slab(hb + 2 * KQ + kq, std::integral_constant<int, 0>{}, e[4], e[5], nvs[4], nvs[5], hb + 2 * KQ + kq < h1);
+            half_slab(hb + 3 * KQ + kq, std::integral_constant<int, 1>{}, e[6], e[7], nvs[6], nvs[7], hb + 3 * KQ + kq < h1);
+        }
+    }
+
+    if constexpr (KQ > 1) {
+        // ---- the phases of a row pair added in phase order (deterministic): phases 1 .. KQ - 1 park their accumulators in their own
+        // (now idle) A tile, 4 KiB per token block, element e of lane l at 256 e + 4 l; phase 0 adds them and stores
+        float* mine = reinterpret_cast<float*>(As);
+        if (kq > 0) {
 #pragma unroll
-        for (int j = 0; j < D; ++j) half_slab(h + j, uint32_t(j & 1), e[2 * j], e[2 * j + 1], nvs[2 * j], nvs[2 * j + 1], h + j < h1);
+            for (int b = 0; b < NTB; ++b)
+#pragma unroll
+                for (int e_ = 0; e_ < 16; ++e_) mine[(b * 16 + e_) * 64 + lane] = acc[b][e_];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kq == 0) {
+#pragma unroll
+            for (int ph = 1; ph < KQ; ++ph) {
+                const float* other = reinterpret_cast<const float*>(smem_s + (ph * RP + rp) * 8192);
+#pragma unroll
+                for (int b = 0; b < NTB; ++b)
+#pragma unroll
+                    for (int e_ = 0; e_ < 16; ++e_) acc[b][e_] += other[(b * 16 + e_) * 64 + lane];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // (the second barrier the staging wave takes: every wave leaves together)
+        asm volatile("" ::: "memory");
+        if (kq > 0) return;
     }
 
     // ---- the 32 x 32 tiles: rows (reg & 3) + 8 (reg >> 2) + 4 g of the pair, token 32 b + i32
@@ -1059,15 +1147,38 @@ int sb_cu_count() {
     }
     return cus[dev];
 }
-void sb_split(const pbl_layer* L, int& KS, int& hps) {
-    const int waves = g_sb_waves;
-    const int NH = int((L->K + GI_HS - 1) / GI_HS), npairs = int((L->NRB + 1) / 2);
-    const int cols = (npairs + SB_WAVES - 1) / SB_WAVES;
-    int ks = waves > 0 ? (waves + npairs / 2) / npairs : int((PBL_SB_WGS_PER_CU * sb_cu_count() * 51LL / 50) / cols);
-    if (ks > NH / 4) ks = NH / 4;
+// The launch geometry of the small-batch kernel for M rows: (RP row pairs x KQ K phases) per workgroup, KS splits across gridDim.y.
+//   geometry 0  RP 4, KQ 1 (round 4): four row pairs share one x tile; K is split ACROSS workgroups (rule above) and sb_reduce_kernel
+//               adds the partial tiles.  What 33 - 64 rows and layers with few rows run.
+//   geometry 1  RP 2, KQ 4 (round 6): layers with enough rows to fill the chip with whole-K workgroups -- no split, no workspace, ONE
+//               launch (13824 x 5120: 216 workgroups of 8 working waves, 128 KiB of LDS each; 19.5 us where geometry 0 + reduce take
+//               22.0, profiles/r06_small_batch.md).
+// Measured and not kept (same file): RP 1 x KQ 3 with a third of geometry 0's split for layers with few rows and a long K
+// (5120 x 13824: 22.9 us against 21.1 for geometry 0) -- the kernel is bound by its LDS traffic per (record, half slab), not by the
+// partial tiles; ring depth 4 and non-temporal slot loads (36 us / +0.4 us).
+struct SbPlan { int geo, rp, kq, KS, hps; };
+int g_sb_force_geo = -1, g_sb_force_ks = 0;      // tools / tests only (pbl_debug_set_small_image_plan)
+SbPlan sb_plan(const pbl_layer* L, int M) {
+    const int NH = int((L->K + GI_HS - 1) / GI_HS), npairs = int((L->NRB + 1) / 2), cus = sb_cu_count();
+    SbPlan p = {0, SB_WAVES, 1, 1, NH};
+    int geo = (M <= 32 && npairs * 4 >= cus * 5) ? 1 : 0;          // >= 160 whole-K workgroups of two pairs on 256 CUs
+    if (g_sb_force_geo >= 0 && (g_sb_force_geo == 0 || M <= 32)) geo = g_sb_force_geo > 1 ? 1 : g_sb_force_geo;
+    int ks = 1;
+    if (geo == 0 || g_sb_waves > 0) {
+        const int cols = (npairs + SB_WAVES - 1) / SB_WAVES;
+        geo = 0;
+        ks = g_sb_waves > 0 ? (g_sb_waves + npairs / 2) / npairs : int((PBL_SB_WGS_PER_CU * cus * 51LL / 50) / cols);
+        if (ks > NH / 4) ks = NH / 4;
+    } else {
+        p.rp = 2; p.kq = 4;
+    }
+    if (g_sb_force_ks > 0 && g_sb_force_geo >= 0) ks = g_sb_force_ks;
+    if (ks > NH) ks = NH;
     if (ks < 1) ks = 1;
-    hps = (NH + ks - 1) / ks;
-    KS = (NH + hps - 1) / hps;
+    p.geo = geo;
+    p.hps = (NH + ks - 1) / ks;
+    p.KS = (NH + p.hps - 1) / p.hps;
+    return p;
 }
 
 size_t align16(size_t v) { return (v + 15) & ~size_t(15); }
@@ -1371,13 +1482,15 @@ extern "C" int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y
 
 // tuning hook (tools/): the number of waves the small-batch kernel's K split aims at
 extern "C" void pbl_debug_set_small_image_waves(int n) { g_sb_waves = n > 0 ? n : 0; }
+// tools / tests: force the small-batch kernel's geometry (0: RP 4 x KQ 1, 1: RP 2 x KQ 4 -- up to 32 rows) and, with ks > 0, its
+// split across workgroups; geo < 0: back to the rule (sb_plan)
+extern "C" void pbl_debug_set_small_image_plan(int geo, int ks) { g_sb_force_geo = geo; g_sb_force_ks = ks; }
 
 // Transient workspace of pbl_gemm_small_image_ws for M <= 64 rows: the K splits' fp32 partial outputs (0: one split).
 extern "C" size_t pbl_gemm_small_image_workspace_bytes(const pbl_layer* layer, int M) {
     if (!layer_ok(layer) || M < 1 || M > 64) return 0;
-    int KS, hps;
-    sb_split(layer, KS, hps);
-    return KS > 1 ? size_t(KS) * M * layer->N * sizeof(float) : 0;
+    const SbPlan p = sb_plan(layer, M);
+    return p.KS > 1 ? size_t(p.KS) * M * layer->N * sizeof(float) : 0;
 }
 
 // the small-batch kernel's launches behind pbl_gemm_small_image_ws / _act (tok_scale: the _act form)
@@ -1395,9 +1508,12 @@ static int sb_launch(const pbl_layer* layer, const void* x, void* y, int M, int 
     a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = out_dtype == PBL_DTYPE_F32;
     a.slots = ib + g.slots_off; a.rbase = reinterpret_cast<const uint32_t*>(ib + sizeof(ImgHeader));
     a.rtab = reinterpret_cast<const uint32_t*>(ib + g.rtab_off); a.levels = reinterpret_cast<const uint32_t*>(ib + g.levels_off);
-    sb_split(layer, a.KS, a.hps);
+    SbPlan pl = sb_plan(layer, M);
     const uint32_t NH = (layer->K + GI_HS - 1) / GI_HS;
-    if (a.KS > 1 && (!workspace || workspace_bytes < size_t(a.KS) * M * layer->N * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15))) { a.KS = 1; a.hps = int(NH); }
+    // (no workspace: geometry 0 falls back to ONE split per layer -- slow for layers with few rows; the K-phase geometries then cover
+    // the whole K inside their workgroups)
+    if (pl.KS > 1 && (!workspace || workspace_bytes < size_t(pl.KS) * M * layer->N * sizeof(float) || (reinterpret_cast<uintptr_t>(workspace) & 15))) { pl.KS = 1; pl.hps = int(NH); }
+    a.KS = pl.KS; a.hps = pl.hps;
     if (tok_scale) {                                         // scaled activations: scale and bias belong to the reduce
         if (a.KS == 1) return PBL_ERR_UNSUPPORTED;
         a.L.bias = nullptr;
@@ -1405,14 +1521,18 @@ static int sb_launch(const pbl_layer* layer, const void* x, void* y, int M, int 
     a.part = a.KS > 1 ? static_cast<float*>(workspace) : nullptr;
     const uint32_t nvk = geom[1];
     const bool kt = (layer->K & (GI_HS - 1)) != 0;
-#define SB_PICK2(NV_, KT_) (M > 32 ? reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, KT_, 2>) : reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, KT_, 1>))
+    const int ntb = M > 32 ? 2 : 1;
+#define SB_PICK3(NV_, KT_, NTB_) (pl.geo == 1 ? reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, KT_, 1, 2, 4>) \
+                                              : reinterpret_cast<const void*>(pbl_sb_img_kernel<NV_, KT_, NTB_, SB_WAVES, 1>))
+#define SB_PICK2(NV_, KT_) (ntb == 2 ? SB_PICK3(NV_, KT_, 2) : SB_PICK3(NV_, KT_, 1))
 #define SB_PICK(NV_) (kt ? SB_PICK2(NV_, true) : SB_PICK2(NV_, false))
     const void* k = nvk == 1 ? SB_PICK(1) : nvk == 2 ? SB_PICK(2) : nvk == 3 ? SB_PICK(3) : nvk == 4 ? SB_PICK(4) : SB_PICK(5);
 #undef SB_PICK
 #undef SB_PICK2
+#undef SB_PICK3
     void* argv[] = {&a};
     const uint32_t npairs = (layer->NRB + 1) / 2;
-    if (hipLaunchKernel(k, dim3((npairs + SB_WAVES - 1) / SB_WAVES, uint32_t(a.KS)), dim3((SB_WAVES + 1) * GW), argv, 0, st) != hipSuccess) return PBL_ERR_LAUNCH;
+    if (hipLaunchKernel(k, dim3((npairs + pl.rp - 1) / pl.rp, uint32_t(a.KS)), dim3((pl.rp * pl.kq + 1) * GW), argv, 0, st) != hipSuccess) return PBL_ERR_LAUNCH;
     if (a.KS > 1) {
         const float* part = a.part;
         size_t MN = size_t(M) * layer->N;

@@ -479,3 +479,74 @@ def test_full_tensor_against_the_float64_oracle_per_kernel_family(family):
     bar = 1e-3 * np.abs(ref).max()
     tiles = err.reshape(-1, min(M, 256), 32, 128).max(axis=(1, 3)) if M >= 256 else err.reshape(1, M, 32, 128).max(axis=(1, 3))
     assert (tiles < bar).all(), np.argwhere(tiles >= bar)[:8]
+
+
+def _force_small_plan(geo, ks=0):
+    f = _lib.lib().pbl_debug_set_small_image_plan
+    f.restype, f.argtypes = None, [C.c_int, C.c_int]
+    f(geo, ks)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_small_batch_geometries_with_k_phases_on_random_layers(seed):
+    """round 6: the small-batch kernel's workgroup is (RP row pairs) x (KQ K phases) -- geometry 1 = 2 x 4 (whole-K workgroups: no
+    split across workgroups, no workspace, one launch) -- the phases' accumulators added through LDS in phase order.  The geometry forced (pbl_debug_set_small_image_plan) on random layers: ragged N / odd record counts, K from one half slab
+    (fewer half slabs than phases) to many with and without a tail, column groups, exceptions; with and without an additional split
+    across workgroups; 1 - 32 rows; against the float64 oracle, repeatable, and the same numbers as geometry 0 within fp32 summation
+    order."""
+    rng = np.random.default_rng(2000 + seed)
+    gs = int(rng.choice([-1, -1, 128, 256]))
+    K = int(rng.choice([16, 128, 200, 384, 1288, 2048, 3200])) if gs == -1 else gs * int(rng.integers(1, 12))
+    N = int(rng.choice([8, 24, 40, 100, 130, 257, 512]))
+    lf = float(rng.choice([0.5, 0.8, 0.9, 0.97]))
+    p, Wd = rtn_layer(N, K, gs, seed=177 + seed, low_frac=lf, fp16=True, exceptions=int(rng.integers(0, 4)))
+    pd = p.to(DEV)
+    img = Q.gemm_image(pd)
+    assert img is not None
+    W16 = Wd.astype(np.float16).astype(np.float32)
+    b = synth.normal((N,), 5, seed, 0.1)
+    NH = (K + 127) // 128
+    try:
+        for M in (1, int(rng.integers(2, 32)), 32):
+            x = synth.activations((M, K), seed + M, 21)
+            xt = T(x)
+            ref, ref_nb = O.dense_linear(x, W16, b), O.dense_linear(x, W16)
+            _force_small_plan(0)
+            y0 = Q.small_image_forward(pd, None, xt, img, out_f32=True)
+            for geo, ks in ((1, 1), (1, 2), (1, 3), (1, NH)):
+                _force_small_plan(geo, ks)
+                y = Q.small_image_forward(pd, T(b), xt, img)
+                assert y.shape == (M, N)
+                assert_parity(y, ref)
+                y32 = Q.small_image_forward(pd, None, xt, img, out_f32=True)
+                assert_parity(y32, ref_nb, 3e-4)
+                assert torch.equal(y32, Q.small_image_forward(pd, None, xt, img, out_f32=True)), (geo, ks, M)
+                assert_parity(y32, y0.cpu().numpy().astype(np.float64), 1e-4)
+    finally:
+        _force_small_plan(-1)
+
+
+@pytest.mark.parametrize("N,K,geo", [(13824, 5120, 1), (5120, 13824, 0)])
+def test_small_batch_default_geometry_on_the_config4_shapes(N, K, geo):
+    """BASELINE configs[3] out of the box (round 6): 13824 x 5120 at 32 rows runs as ONE launch -- whole-K workgroups, no workspace
+    (pbl_gemm_small_image_workspace_bytes == 0) -- and 5120 x 13824 (160 row pairs) keeps the split across workgroups; ALL rows
+    against the float64 oracle, 50 launches bit-equal (the x double buffer / phase reduction hand-overs), 1 and 17 rows as well."""
+    p, Wd = rtn_layer(N, K, -1, seed=5 + geo, low_frac=0.8, fp16=True)
+    pd = p.to(DEV)
+    img = Q.gemm_image(pd)
+    assert img is not None
+    W16 = Wd.astype(np.float16).astype(np.float32)
+    lay = pd.layer_struct(None)
+    wsb = _lib.lib().pbl_gemm_small_image_workspace_bytes
+    wsb.restype = C.c_size_t
+    if geo == 1:
+        assert wsb(C.byref(lay), 32) == 0                                   # one launch, nothing to add up afterwards
+    else:
+        assert wsb(C.byref(lay), 32) > 0
+    for M in (32, 17, 1):
+        x = synth.activations((M, K), 9 + M, 21)
+        xt = T(x)
+        y = Q.small_image_forward(pd, None, xt, img)
+        assert_parity(y, O.dense_linear(x, W16))
+        for _ in range(50 if M == 32 else 3):
+            assert torch.equal(y, Q.small_image_forward(pd, None, xt, img))

@@ -57,7 +57,9 @@ def test_the_audit_finds_a_one_too_lax_wait_in_the_small_batch_kernel(audit):
     reads, the staging wave's vmcnt(0) in front of the barrier that publishes the x tile, the working waves' lgkmcnt(0) in front of
     the barrier that frees it -- made ONE laxer is reported; likewise the image kernel's counted lgkmcnt(6) over its fragment reads"""
     asm = audit.compile_asm(audit.IMG_SRC)
-    for pat in ("pbl_sb_img_kernelILi2ELb0ELi1E", "pbl_sb_img_kernelILi3ELb1ELi2E"):
+    # (round 6: the workgroup geometry RP x KQ is a template parameter pair -- the round-4 geometry 4 x 1 at both token-block counts,
+    # and the K-phase geometry 2 x 4, whose reduction adds two barriers and LDS traffic of its own)
+    for pat in ("pbl_sb_img_kernelILi2ELb0ELi1ELi4ELi1E", "pbl_sb_img_kernelILi3ELb1ELi2ELi4ELi1E", "pbl_sb_img_kernelILi2ELb0ELi1ELi2ELi4E"):
         (name, lines), = audit.kernel_bodies_named(asm, pat).items()
         assert audit.audit_waits(lines)[0] == []
         for counter in ("vmcnt", "lgkmcnt"):

@@ -15,6 +15,34 @@ quick)   # the round's new tests, smoke, the driver's command (with the side ent
   T0=$(date +%s.%N); timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; echo "bench wall $(echo "$(date +%s.%N) - $T0" | bc) s"; tail -2 $O/bench_driver.err | cut -c1-300
   python tools/show_line.py $O/bench_driver.json
   ;;
+small)   # the small-batch kernel's geometries: parity tests, then a sweep of forced plans per shape (tools/bench_small.py)
+  timeout 1500 python -m pytest tests/test_gpu_gemm.py -q -m gpu -p no:cacheprovider --timeout 900 -k "small" > $O/pytest_small.txt 2>&1; tail -3 $O/pytest_small.txt | cut -c1-300; grep -E "^(FAILED|ERROR)" $O/pytest_small.txt | cut -c1-300
+  PBL_BENCH_SHAPES=${SHAPES:-13824x5120:0.8,5120x13824:0.8} PBL_BENCH_MS=${MS:-32} PBL_SB_PLANS=${PLANS:-default,0:0,1:1,1:2,2:1,2:2,2:3,2:4,2:6} timeout 900 python tools/bench_small.py > $O/small.jsonl 2> $O/small.err
+  python - $O/small.jsonl <<'P'
+import json,sys
+for l in open(sys.argv[1]):
+    d=json.loads(l); print(d['shape'], d['low_frac'], 'M', d['M'], 'img_MB', d['image_MB'], 'blob_MB', d['blob_MB'], {k[5:-3]: v for k, v in d.items() if k.startswith('plan_') and k.endswith('_us')}, 'records', d['records_us'], 'dense', d['dense_us'], 'maxerr', max(v for k, v in d.items() if k.endswith('_err')))
+P
+  tail -3 $O/small.err | cut -c1-300
+  ;;
+smallvar)   # A/B builds of the small-batch kernel (tools/build_variant.sh -> build/libpbl_<name>.so) on the cfg4 shapes + the per-CU bandwidth probe
+  [ -x build/ubench_cu_bw ] && timeout 120 build/ubench_cu_bw > $O/cu_bw.json 2>&1; python - $O/cu_bw.json <<'P'
+import json,sys
+try:
+    for r in json.load(open(sys.argv[1]))["rows"]:
+        if r: print(r)
+except Exception as e: print("cu_bw", e)
+P
+  for v in default ${VARIANTS:-d4 nt d4nt}; do
+    if [ $v = default ]; then unset PBL_LIB; else export PBL_LIB=build/libpbl_$v.so; fi
+    PBL_BENCH_SHAPES=${SHAPES:-13824x5120:0.8,5120x13824:0.8} PBL_BENCH_MS=${MS:-32} PBL_SB_PLANS=${PLANS:-default,0:0,1:1} timeout 600 python tools/bench_small.py > $O/small_$v.jsonl 2> $O/small_$v.err
+    echo "== $v"; python - $O/small_$v.jsonl <<'P'
+import json,sys
+for l in open(sys.argv[1]):
+    d=json.loads(l); print(d['shape'], 'M', d['M'], {k[5:-3]: v for k, v in d.items() if k.startswith('plan_') and k.endswith('_us')}, 'maxerr', max(v for k, v in d.items() if k.endswith('_err')))
+P
+  done
+  ;;
 full)
   for i in $(seq 1 ${REPS:-1}); do timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 900 > $O/pytest$i.txt 2>&1; tail -3 $O/pytest$i.txt | cut -c1-300; grep -E "^(FAILED|ERROR)" $O/pytest$i.txt | cut -c1-300; done
   ;;
