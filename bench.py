@@ -666,6 +666,50 @@ def main():
             tp_notes.append(f"{main_path} reported a timed-out peer wait: the line carries the RCCL per-layer measurement")
             wall, dev_s, kern_s, tp_path, tp_graphed = bw, bd, bk, "rccl-per-layer", False
 
+    tp_phases = None
+    if tp:
+        # where a step's time goes, per phase, from a few EAGER steps of the path that was timed (outside the K steps above; round 6,
+        # VERDICT r5 item 9): the N-split launch, and per K-split layer the push GEMV + reduce kernel (fused), or the GEMV launch + the
+        # all-reduce calls (per-layer / stacked paths); HIP events on the launch stream, max over ranks
+        ph = {}
+        try:
+            if comm is not None:
+                comm.phase_events = []
+            n_ev = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                step_tp(tp_path)
+                e1.record()
+                n_ev.append((e0, e1))
+            torch.cuda.synchronize()
+            ph["eager_step_us"] = 1e3 * sum(s_.elapsed_time(e_) for s_, e_ in n_ev) / len(n_ev)
+            if comm is not None and comm.phase_events:
+                for kind in sorted({k for k, _, _ in comm.phase_events}):
+                    v = [s_.elapsed_time(e_) for k, s_, e_ in comm.phase_events if k == kind]
+                    ph[f"{kind}_us_per_call"] = 1e3 * sum(v) / len(v)
+                    ph[f"{kind}_calls_per_step"] = len(v) // 3
+            g0e, g1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0e.record(); gn.launch(); g1e.record()
+            torch.cuda.synchronize()
+            ph["nsplit_gemv_us"] = 1e3 * g0e.elapsed_time(g1e)
+            if use_dist:
+                keys = sorted(ph)
+                tt = torch.tensor([ph[k] for k in keys], device=ctl, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ph = dict(zip(keys, tt.tolist()))
+        except Exception as e:      # noqa: BLE001 -- diagnostics never cost the line
+            ph["error"] = f"{type(e).__name__}: {str(e)[:160]}"
+        finally:
+            if comm is not None:
+                comm.phase_events = None
+        if comm is not None and os.environ.get("PBL_BENCH_P2P_SELFTEST", "1") == "1":
+            try:
+                ph["p2p_pair_allreduce_16KB_us"] = P2PAllReduce.selftest_pairs(dev)
+            except Exception as e:  # noqa: BLE001
+                ph["p2p_pair_allreduce_16KB_us"] = f"{type(e).__name__}: {str(e)[:160]}"
+        tp_phases = ph
+
     traffic, traffic_source = None, None
     key = f"N{a.N}_K{a.K}_L{a.layers}_M{a.M}_lf{a.low_frac}_{a.mode}"
     try:  # HBM bytes per launch: PMC passes cannot run inside this process; the value is read from the committed
@@ -737,6 +781,8 @@ def main():
                 out["config"]["tp_notes"] = tp_notes
             if rccl_base is not None:
                 out["rccl_per_layer_baseline"] = rccl_base
+            if tp_phases is not None:
+                out["tp_phases"] = tp_phases
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline([b["W"] for b in base], a.K, a.M)
         if world == 1 and not a.no_side and a.mode == "grouped":

@@ -176,7 +176,7 @@ class _FusedGroup:
     SOLO_WARN_AFTER = 32
     MERGE_MAX_ROWS = 64            # the small-batch kernel's range: beyond it a merged layer has nothing on its members (same tiles, same rounds)
 
-    def __init__(self, mods: list[PBLinear], merge_batched: bool = True):
+    def __init__(self, mods: list[PBLinear], merge_batched: bool = False):
         self.mods = mods
         self.x_ref, self.x_version, self.outs, self.pending = None, -1, None, set()
         self.launches = self.served = self.solo_launches = self.merged_launches = 0
@@ -206,6 +206,9 @@ class _FusedGroup:
                 dev = self.mods[0].pbl_blob.device
                 bias = torch.cat([b if b is not None else torch.zeros(m.out_features, device=dev) for b, m in zip(biases, self.mods)])
             self.merged = PBLinear(concat_rows([m.packed for m in self.mods]), bias, self.mods[0].weight_dtype)
+            import logging
+            logging.getLogger("pb_llm_amd").info("fuse_decode_(merge_batched=True): merged layer of %d projections holds %d more packed bytes "
+                                                 "(+ its GEMM image on the first batched call)", len(self.mods), self.merged.packed.nbytes)
             self.offs = [0]
             for m in self.mods:
                 self.offs.append(self.offs[-1] + m.out_features)
@@ -235,14 +238,16 @@ class _FusedGroup:
 FUSE_SETS = (("q_proj", "k_proj", "v_proj"), ("gate_proj", "up_proj"))     # LLaMA naming (HF)
 
 
-def fuse_decode_(model: nn.Module, sets=FUSE_SETS, merge_batched: bool = True) -> int:
+def fuse_decode_(model: nn.Module, sets=FUSE_SETS, merge_batched: bool = False) -> int:
     """Decode-time fusion: in every module that holds all the projections of a set as PBLinears with one
     in_features (HF LlamaAttention: q/k/v_proj; LlamaMLP: gate/up_proj), replace them by members of one fused launch.
     7 launches per decoder layer become 4.  Returns the number of groups created.  The caller this serves is the token
     loop of gptq_pb/eval_ppl_utils.py:55-64 / qat/eval_after_qat.py:11-33 at batch 1.
-    merge_batched (round 5): a decode BATCH (5 - 64 rows) runs each group as ONE call of the members' row-wise concatenation
-    (packing.concat_rows; built on the first such call, costs the members' packed bytes once more plus its GEMM image) instead of
-    one small-batch launch + reduce per projection."""
+    merge_batched (round 5; OPT-IN since round 6, ADVICE r5: the default silently held blob + image + merged blob + merged image): a
+    decode BATCH (5 - 64 rows) runs each group as ONE call of the members' row-wise concatenation (packing.concat_rows; built on the
+    first such call; costs the members' packed bytes once more plus its GEMM image -- logged once per group at INFO level on the
+    "pb_llm_amd" logger) instead of one small-batch launch + reduce per projection (llama-7b decoder layer at 16 rows: 94.0 -> 78.5
+    us).  A decode-only phase at batch <= 4 never reads a GEMM image: `drop_gemm_images_` releases them."""
     n = 0
     for mod in list(model.modules()):
         for names in sets:
@@ -258,20 +263,56 @@ def fuse_decode_(model: nn.Module, sets=FUSE_SETS, merge_batched: bool = True) -
     return n
 
 
-def build_gemm_images_(model: nn.Module) -> tuple[int, int]:
+def build_gemm_images_(model: nn.Module, release_blobs: bool = False) -> tuple[int, int]:
     """Build and keep the GEMM image of every packed fp16-checkpoint linear of `model` NOW (quant._kept_image), instead of on its
     first prefill call: afterwards calls with 5 - 64 rows run the small-batch kernel over the image under the default
     quant.SMALL_BATCH_IMAGE = "auto" -- also inside a hipGraph capture, where an image cannot be built (the build reads two words
-    back).  Costs the images' memory on top of the blobs (1.7 - 2.4 x the blob's bytes).  Returns (layers with an image, bytes)."""
+    back).  Costs the images' memory on top of the blobs (1.7 - 2.4 x the blob's bytes) -- unless release_blobs (round 6): then the
+    image becomes each layer's ONLY device copy (PBLinear.release_blob_: the blob moves to host memory, state_dict() still holds it;
+    every row count multiplies from the image) -- what an evaluation run wants (qat/eval_after_qat.py:11-33, gptq_pb/eval_ppl_utils.py:
+    55-64 call the layers with whole 2048-token windows only): a llama-7b-shaped model at 5 % hessian salients holds 4.2 GB instead
+    of 6.3.  Returns (layers with an image, image bytes); `release_blobs_` / `restore_blobs_` do the second step on their own."""
     from . import quant as Q
     n = nbytes = 0
     for m in model.modules():
-        if isinstance(m, Q.PBLinear) and m.weight_dtype == torch.float16 and m.pbl_blob.is_cuda and Q.fused_gemm_ok(m.packed):
+        if isinstance(m, Q.PBLinear) and m._image_only is not None:
+            n += 1
+            nbytes += m._image_only[0].data.numel()
+        elif isinstance(m, Q.PBLinear) and m.weight_dtype == torch.float16 and m.pbl_blob.is_cuda and Q.fused_gemm_ok(m.packed):
             img = Q._kept_image(m.packed)
             if img is not None:
                 n += 1
                 nbytes += img.data.numel()
+    if release_blobs:
+        release_blobs_(model)
     return n, nbytes
+
+
+def release_blobs_(model: nn.Module, pin: bool = False) -> int:
+    """PBLinear.release_blob_ on every packed linear of `model` that has a GEMM image (fp16-checkpoint layers; others keep their
+    blob); returns the device bytes released.  Not on a model whose projections were fused for decode (fuse_decode_: the fused
+    launches read the blobs) -- un-fused layers released here are simply skipped by a later fuse_decode_."""
+    from . import quant as Q
+    if any(isinstance(m, _FusedMember) for m in model.modules()):
+        raise RuntimeError("release_blobs_: the model's projections are fused for decode (fuse_decode_), whose launches read the blobs")
+    n = 0
+    for m in model.modules():
+        if isinstance(m, Q.PBLinear) and m._image_only is None and m.pbl_blob.is_cuda and m.weight_dtype == torch.float16 \
+                and Q.fused_gemm_ok(m.packed) and Q._kept_image(m.packed) is not None:
+            n += m.release_blob_(pin)
+    torch.cuda.empty_cache()
+    return n
+
+
+def restore_blobs_(model: nn.Module) -> int:
+    """the blobs of every image-only linear back on the device (decode through the GEMV again); returns the layers restored"""
+    from . import quant as Q
+    n = 0
+    for m in model.modules():
+        if isinstance(m, Q.PBLinear) and m._image_only is not None:
+            m.restore_blob_()
+            n += 1
+    return n
 
 
 def drop_gemm_images_(model: nn.Module) -> int:

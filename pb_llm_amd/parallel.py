@@ -107,6 +107,10 @@ class P2PAllReduce:
             raise ValueError("at most 16 ranks")
         self.max_numel = int(max_numel)
         self._own, self._opened, self._ptrs = None, [], None
+        # diagnostics (round 6; bench.py --gpus N "tp_phases"): a list here makes fused_linear_ / all_reduce_ record HIP events around
+        # their launches -- (kind, start, end) with kind in {"push_gemv", "reduce", "p2p_allreduce"} -- so that the first run on real
+        # xGMI says WHERE a step's time went.  None (default): nothing is recorded.
+        self.phase_events = None
         if not lazy:
             self._allocate()
 
@@ -193,10 +197,64 @@ class P2PAllReduce:
         if t.numel() > self.max_numel:
             raise _lib.PblError(f"P2PAllReduce sized for {self.max_numel} elements, got {t.numel()}")
         st = torch.cuda.current_stream(self.device).cuda_stream
+        ev = self._phase_start()
         _lib.check(_lib.lib().pbl_p2p_allreduce_f32_dev(self._ptrs, self.rank, self.world, t.data_ptr(),
                                                         out_f16.data_ptr() if out_f16 is not None else None, t.numel(),
                                                         self.max_numel, st), "p2p_allreduce")
+        self._phase_end("p2p_allreduce", ev)
         return t
+
+    def _phase_start(self):
+        if self.phase_events is None or torch.cuda.is_current_stream_capturing():
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(self.device))
+        return e
+
+    def _phase_end(self, kind, e0):
+        if e0 is None:
+            return None
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record(torch.cuda.current_stream(self.device))
+        self.phase_events.append((kind, e0, e1))
+        return e1
+
+    @staticmethod
+    def selftest_pairs(device, numel: int = 4096, iters: int = 20, group=None) -> dict:
+        """One-shot all-reduce latency of `numel` fp32 (16 KB by default: one decode token of a 4096-wide layer) for every PAIR of
+        ranks, over a two-rank communicator of its own: {"i-j": microseconds} on every rank (max over the two members).  Collective
+        over `group` (every rank takes part in creating every pair's group).  What to read it for: on a node each pair is one xGMI
+        link, and a slow or absent link shows here before it shows as a slow step."""
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ranks = list(range(world)) if group is None else dist.get_process_group_ranks(group)
+        out = {}
+        for i in range(world):
+            for j in range(i + 1, world):
+                pg = dist.new_group([ranks[i], ranks[j]])               # (collective over the default group: every rank calls it)
+                us = -1.0
+                if rank in (i, j):
+                    try:
+                        c = P2PAllReduce(numel, device, pg)
+                        t = torch.ones(numel, dtype=torch.float32, device=device)
+                        for _ in range(3):
+                            c.all_reduce_(t)
+                        torch.cuda.synchronize(device)
+                        dist.barrier(group=pg)
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(iters):
+                            c.all_reduce_(t)
+                        e1.record()
+                        torch.cuda.synchronize(device)
+                        c.check()
+                        us = e0.elapsed_time(e1) * 1e3 / iters
+                        c.close()
+                    except _lib.PblError:
+                        us = -1.0
+                res = [None] * world
+                dist.all_gather_object(res, us, group=group)
+                out[f"{i}-{j}"] = round(max(res[i], res[j]), 2) if min(res[i], res[j]) >= 0 else None
+        return out
 
     def fused_linear_(self, packed, bias_f32, x2: torch.Tensor, out: torch.Tensor) -> bool:
         """K-split layer with the push fused into the GEMV's epilogue (pbl_linear_f16_push) + the reduce (pbl_p2p_reduce_f32_dev):
@@ -214,13 +272,16 @@ class P2PAllReduce:
         L = _lib.lib()
         layer = packed.layer_struct(bias_f32)
         st = torch.cuda.current_stream(self.device).cuda_stream
+        ev = self._phase_start()
         rc = L.pbl_linear_f16_push(C.byref(layer), x2.data_ptr(), M, self._ptrs, self.rank, self.world, self.max_numel, st)
         if rc == _lib.PBL_ERR_UNSUPPORTED:
             return False
         _lib.check(rc, "linear_f16_push")
+        ev = self._phase_end("push_gemv", ev)
         f32 = out.dtype == torch.float32
         _lib.check(L.pbl_p2p_reduce_f32_dev(self._ptrs, self.rank, self.world, out.data_ptr() if f32 else None,
                                             None if f32 else out.data_ptr(), M * packed.N, self.max_numel, packed.NRB, st), "p2p_reduce")
+        self._phase_end("reduce", ev)
         return True
 
     def check(self) -> None:

@@ -690,7 +690,7 @@ def test_batched_decode_runs_the_projections_as_one_merged_layer():
     side = H.quantize_dense_(model, producer)
     plain = H.to_pb_(model, side).to(DEV)
     fused = copy.deepcopy(plain)
-    assert H.fuse_decode_(fused) == 4
+    assert H.fuse_decode_(fused, merge_batched=True) == 4            # (opt-in since round 6)
     ids = torch.from_numpy((synth.uniform01(320, 7, 1) * 1000).astype(np.int64)).view(1, -1).to(DEV)
     g0 = fused.model.layers[0].self_attn.q_proj._group[0]
     with torch.no_grad():
@@ -705,7 +705,7 @@ def test_batched_decode_runs_the_projections_as_one_merged_layer():
         ab = fused(ids[:, :16], use_cache=False).logits                     # (bf16 hidden states would take the same path; fp16 here)
         assert torch.equal(ab, fused(ids[:, :16], use_cache=False).logits)
     nofuse = copy.deepcopy(plain)
-    assert H.fuse_decode_(nofuse, merge_batched=False) == 4
+    assert H.fuse_decode_(nofuse) == 4                                  # the default: no merged copies
     with torch.no_grad():
         assert torch.equal(nofuse(ids[:, :16], use_cache=False).logits, plain(ids[:, :16], use_cache=False).logits)   # off: the members' own launches
 
@@ -913,3 +913,94 @@ def test_fused_launch_inline_and_table_descriptors_agree():
         assert torch.equal(a, b)
     for p, o in zip(ps, o5):
         assert_parity(o, O.dense_linear(xs, p.unpack().numpy()), 2e-4)
+
+
+def test_image_only_residency_one_copy_of_the_weights():
+    """VERDICT r5 item 5 / missing #6: the fast paths multiplied from a GEMM image that sat ON TOP of the blob.  Round 6:
+    PBLinear.release_blob_ makes the image the layer's only device copy -- the blob moves to host memory (still the module's buffer:
+    state_dict / load_state_dict work), every row count and activation dtype multiplies from the image (<= 64 rows: small-batch kernel,
+    beyond: GEMM kernel) -- and restore_blob_ brings the GEMV back with the same image.  Reference consumers: the perplexity loops
+    (gptq_pb/eval_ppl_utils.py:55-64, qat/eval_after_qat.py:11-33), which only call the layers with whole windows."""
+    from pb_llm_amd import harness as H
+
+    def make(seed):
+        W = synth.llm_weight(512, 1024, seed=seed, heavy_tail=True)
+        mask = O.ptq_low_mask(W, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(W, mask, 8, -1)
+        b = synth.normal((512,), 3, seed, 0.1)
+        lay = Q.PBLinear.from_dense(torch.from_numpy(r["W_fq"]).half(), torch.from_numpy(b), torch.from_numpy(mask), -1, r["hscale"], r["hzero"])
+        return lay, r["W_fq"].astype(np.float16).astype(np.float32), b
+
+    layer, Wd, b = make(21)
+    layer = layer.to(DEV)
+    xs = {M: T(synth.activations((M, 1024), 5, M)) for M in (1, 3, 20, 64, 65, 300)}
+    before = {M: layer(x) for M, x in xs.items()}
+    torch.cuda.synchronize()
+    m0 = torch.cuda.memory_allocated()
+    blob_bytes = layer.packed.nbytes
+    assert layer.release_blob_() == blob_bytes and layer.release_blob_() == 0
+    torch.cuda.synchronize()
+    assert not layer.pbl_blob.is_cuda and m0 - torch.cuda.memory_allocated() >= 0.95 * blob_bytes       # the blob's device bytes are gone
+    assert set(layer.state_dict()) == {"pbl_blob", "pbl_bias"} and layer.state_dict()["pbl_blob"].numel() == blob_bytes
+    for M, x in xs.items():
+        y = layer(x)
+        assert y.dtype == torch.float16 and y.shape == (M, 512)
+        assert_parity(y, O.dense_linear(x.cpu().numpy(), Wd, b))
+        if M >= 5:
+            assert torch.equal(y, before[M]), M                      # the same kernels over the same image as before the release
+        assert not (called_ops(lambda: layer(x)) & LIBRARY_GEMM_OPS)
+    for M in (1, 40, 300):                                           # bf16 and fp32 activations from the image alone
+        xb = xs[300][:M].bfloat16()
+        yb = layer(xb)
+        assert yb.dtype == torch.bfloat16
+        assert O.parity_errors(yb.float().cpu().numpy(), O.dense_linear(xb.float().cpu().numpy(), Wd, b))[0] < 1e-2
+        xf = xs[300][:M].float() * 1.0009765625
+        yf = layer(xf)
+        assert yf.dtype == torch.float32 and O.parity_errors(yf.cpu().numpy(), O.dense_linear(xf.cpu().numpy().astype(np.float64), Wd, b))[0] < 3e-4
+    with pytest.raises(_lib.PblError):
+        layer(xs[3].clone().requires_grad_(True))                    # the input gradient needs the blob
+    # new weights through load_state_dict: the host buffer is rewritten, the image follows on the next call
+    other, Wd2, b2 = make(22)
+    layer.load_state_dict(other.state_dict())
+    assert_parity(layer(xs[300]), O.dense_linear(xs[300].cpu().numpy(), Wd2, b2))
+    assert_parity(layer(xs[1]), O.dense_linear(xs[1].cpu().numpy(), Wd2, b2))
+    layer.restore_blob_()
+    assert layer.pbl_blob.is_cuda and layer._image_only is None
+    ref1 = other.to(DEV)
+    assert torch.equal(layer(xs[1]), ref1(xs[1])) and torch.equal(layer(xs[300]), ref1(xs[300]))       # the GEMV again; prefill bit for bit
+    # model level: build_gemm_images_(release_blobs=True) on a small HF llama; a fused model refuses
+    from transformers import LlamaConfig, LlamaForCausalLM
+    import copy
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=8,
+                      num_key_value_heads=8, vocab_size=1000, max_position_embeddings=512)
+    model = LlamaForCausalLM(cfg).half().eval()
+
+    def producer(name, W):
+        Wn = W.float().numpy()
+        mask = O.ptq_low_mask(Wn, 0.9, "magnitude", None, -1)
+        r = O.ptq_rtn(Wn, mask, 8, -1)
+        return dict(W_fq=torch.from_numpy(r["W_fq"]), low_mask=torch.from_numpy(mask), hscale=r["hscale"], hzero=r["hzero"])
+
+    side = H.quantize_dense_(model, producer)
+    plain = H.to_pb_(model, side).to(DEV)
+    lean = copy.deepcopy(plain)
+    packed_bytes = sum(m.packed.nbytes for m in lean.modules() if isinstance(m, Q.PBLinear))
+    torch.cuda.synchronize()
+    m1 = torch.cuda.memory_allocated()
+    n, img_bytes = H.build_gemm_images_(lean, release_blobs=True)
+    torch.cuda.synchronize()
+    assert n == 14 and torch.cuda.memory_allocated() - m1 <= img_bytes - 0.95 * packed_bytes + (1 << 20)      # images in, blobs out
+    ids = torch.from_numpy((synth.uniform01(320, 7, 1) * 1000).astype(np.int64)).view(1, -1).to(DEV)
+    with torch.no_grad():
+        for T_ in (300, 16, 1):
+            a, c = lean(ids[:, :T_], use_cache=False).logits.float(), plain(ids[:, :T_], use_cache=False).logits.float()
+            assert float((a - c).abs().max() / c.abs().max()) < 5e-3, T_
+    assert H.fuse_decode_(lean) == 0                                    # image-only projections are not fused (the fused launches read blobs)
+    fused = copy.deepcopy(plain)
+    H.fuse_decode_(fused)
+    with pytest.raises(RuntimeError):
+        H.release_blobs_(fused)
+    assert H.restore_blobs_(lean) == 14
+    with torch.no_grad():
+        assert torch.equal(lean(ids[:, :1], use_cache=False).logits, plain(ids[:, :1], use_cache=False).logits)

@@ -91,9 +91,13 @@ def _pb_factory(lin: nn.Linear):
 def test_replace_save_load_roundtrip(tmp_path):
     torch.manual_seed(0)
     model = Tiny()
-    Q.replace_linear_with_pb(model, _pb_factory)           # skips lm_head like gptq_pb/modelutils.find_layers
+    Q.replace_linear_with_pb(model, _pb_factory, skip=("lm_head",))      # the GPTQ-PB pipeline's call: gptq_pb/modelutils.find_layers never sees lm_head
     assert isinstance(model.q_proj, Q.PBLinear) and isinstance(model.mlp[0], Q.PBLinear)
     assert isinstance(model.mlp[2], Q.BinaryLinear) and isinstance(model.lm_head, nn.Linear)
+    # the default is the QAT pipeline's: qat/run_qat.py:45-66 swaps EVERY nn.Linear, lm_head included
+    m2 = Tiny()
+    Q.replace_linear_with_pb(m2, lambda lin: Q.BinaryLinear(lin.weight.data, lin.bias.data if lin.bias is not None else None))
+    assert not any(type(m) is nn.Linear for m in m2.modules()) and isinstance(m2.lm_head, Q.BinaryLinear) and m2.lm_head.global_name == "lm_head"
     assert model.mlp[0].global_name == "mlp.0"
     model.mlp[2]._packed_on(torch.device("cpu"))
     meta = pbio.save_pb(model, str(tmp_path / "ckpt"))

@@ -43,6 +43,16 @@ for l in open(sys.argv[1]):
 P
   done
   ;;
+mix1)   # image-only residency test + new small-batch tests, GEMM-image kernel ablations (A/B builds), hessian-vs-magnitude GEMV
+  timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 900 -k "image_only or small_batch or fused_decode or merged or fp32_act" > $O/pytest_mix.txt 2>&1; tail -3 $O/pytest_mix.txt | cut -c1-300; grep -E "^(FAILED|ERROR)" $O/pytest_mix.txt | cut -c1-300
+  for v in default abl1 abl2 abl3 abl4 abl6 abl7 default; do
+    if [ $v = default ]; then unset PBL_LIB; else export PBL_LIB=build/libpbl_$v.so; fi
+    [ $v = default ] || [ -f build/libpbl_$v.so ] || continue
+    timeout 200 python tools/bench_gemm_ablate.py 2>> $O/ablate.err | tee -a $O/ablate.jsonl
+  done
+  unset PBL_LIB
+  timeout 300 python tools/bench_hessian_gemv.py 2> $O/hess.err | tee $O/hessian_gemv.jsonl | cut -c1-400
+  ;;
 full)
   for i in $(seq 1 ${REPS:-1}); do timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 900 > $O/pytest$i.txt 2>&1; tail -3 $O/pytest$i.txt | cut -c1-300; grep -E "^(FAILED|ERROR)" $O/pytest$i.txt | cut -c1-300; done
   ;;
