@@ -351,6 +351,14 @@ size_t pbl_gemm_image_stats_bytes(const pbl_layer* layer);
 int pbl_gemm_image_stats(const pbl_layer* layer, void* stats_dev, void* stream);
 size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* geom);
 int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, void* stream);
+/* The RESIDUAL image of an fp32-grid layer (round 6): same buffer size, geometry words and statistics buffer as pbl_gemm_image_build,
+ * but every value v of the layer (row levels, salient values fl32(sscale (q - szero)), exceptions) is stored as fp16(4096 (v - fp16(v)))
+ * where the ordinary image stores fp16(v).  The reference's fp32-only module classes (quant/quantizer.py:75-86,172-193: weights forced
+ * to fp32) and QAT's fp32 master weights (utils.py:34-36) multiply with fp32 values an fp16 tile cannot hold; with both images
+ *     W = W_hi + 2^-12 W_lo   (up to 2^-22 |W|),    y = x W_hi^T + 2^-12 x W_lo^T
+ * so the GEMM regime of those layers runs on pbl_gemm_f16_image_ws / pbl_gemm_small_image_ws twice (fp32 results) + pbl_act_f32_join3
+ * instead of pbl_unpack_dev + an fp32 library GEMM.  PBL_ERR_UNSUPPORTED for PBL_FLAG_SAL_F16 layers (their values are fp16). */
+int pbl_gemm_image_build_residual(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, void* stream);
 int pbl_gemm_f16_image(const pbl_layer* layer, const void* x, void* y, int M, int y_f32, const void* image, size_t image_bytes,
                        const uint32_t* geom, void* stream);
 /* Shapes whose tiles are not a whole number of rounds of the chip (5120 x 5120 at 2048 rows: 320 tiles of 128 x 256 on 256 CUs; a
@@ -420,6 +428,12 @@ int pbl_act_finish(const float* y_f32, const float* tok_scale, const float* bias
  * One small kernel each, no host synchronisation. */
 int pbl_act_f32_split(const float* x, int M, uint32_t K, size_t ldx, void* x_f16, float* tok_scale, void* stream);
 int pbl_act_f32_join(const float* y_f32, const float* tok_scale, const float* bias, int M, uint32_t N, void* y_out, int out_dtype, void* stream);
+/* y_out [M, N] (out_dtype) = cast((y_f32[t, r] (+ y_f32[M + t, r] if two_terms) + lo_scale * y_lo[t, r]) * tok_scale[t] + bias[r]): the terms
+ * of an fp32-grid layer multiplied from its two images (above; lo_scale = 2^-12).  y_f32 is [2 M, N] for fp32 activations (the two fp16
+ * terms of pbl_act_f32_split through the ordinary image) or [M, N] (two_terms = 0: fp16 / scaled bf16 activations); y_lo [M, N] is the HIGH
+ * activation term through the residual image.  tok_scale / bias may be NULL; pointers 16-byte aligned.  One small kernel. */
+int pbl_act_f32_join3(const float* y_f32, int two_terms, const float* y_lo, float lo_scale, const float* tok_scale, const float* bias, int M,
+                      uint32_t N, void* y_out, int out_dtype, void* stream);
 
 /* bf16 activations in ONE launch (decode: one GEMV pass, M <= 4 rows of a group-free layer): x [M, K] bf16 -> y [M, N] bf16 (fp32 with
  * y_f32).  The kernel's staging phase does what pbl_act_bf16_prepare does and its epilogue what pbl_act_finish does -- the same bits

@@ -119,7 +119,8 @@ __global__ __launch_bounds__(ACT_THREADS) void act_bf16_prepare_kernel(const uin
 template <int OUT>       // PBL_DTYPE_F32 / _F16 / _BF16
 __global__ __launch_bounds__(ACT_THREADS) void act_finish_kernel(const float* __restrict__ y, const float* __restrict__ scale,
                                                                  const float* __restrict__ bias, uint32_t N, size_t MN, void* __restrict__ out,
-                                                                 const float* __restrict__ y2) {      // y2: a second term added to y first (pbl_act_f32_join)
+                                                                 const float* __restrict__ y2,        // y2: a second term added to y first (pbl_act_f32_join)
+                                                                 const float* __restrict__ y3, float c3) {   // y3: a third term, times c3 (pbl_act_f32_join3)
     const size_t i = (size_t(blockIdx.x) * ACT_THREADS + threadIdx.x) * 4;
     if (i >= MN) return;
     auto put = [&](size_t j, float v) {
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(ACT_THREADS) void act_finish_kernel(const float* __
         const float s = scale ? scale[t] : 1.f;
         v4f v = *reinterpret_cast<const v4f*>(y + i);
         if (y2) v += *reinterpret_cast<const v4f*>(y2 + i);
+        if (y3) { const v4f w = *reinterpret_cast<const v4f*>(y3 + i); for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(w[k], c3, v[k]); }
         v4f b = {0.f, 0.f, 0.f, 0.f};
         if (bias) b = *reinterpret_cast<const v4f*>(bias + r);
         float o[4];
@@ -155,7 +157,8 @@ __global__ __launch_bounds__(ACT_THREADS) void act_finish_kernel(const float* __
     for (size_t j = i; j < MN && j < i + 4; ++j) {
         const size_t t = j / N;
         const float b = bias ? bias[j - t * N] : 0.f;
-        const float v = y2 ? y[j] + y2[j] : y[j];
+        float v = y2 ? y[j] + y2[j] : y[j];
+        if (y3) v = __builtin_fmaf(y3[j], c3, v);
         put(j, scale ? __builtin_fmaf(v, scale[t], b) : v + b);
     }
 }
@@ -254,7 +257,9 @@ extern "C" int pbl_act_finish(const float* y_f32, const float* tok_scale, const 
     if (!k) return PBL_ERR_INVALID_ARG;
     size_t MN = size_t(M) * N;
     const float* y2 = nullptr;
-    void* argv[] = {&y_f32, &tok_scale, &bias, &N, &MN, &y_out, &y2};
+    const float* y3 = nullptr;
+    float c3 = 0.f;
+    void* argv[] = {&y_f32, &tok_scale, &bias, &N, &MN, &y_out, &y2, &y3, &c3};
     return hipLaunchKernel(k, dim3(uint32_t((MN + 4 * ACT_THREADS - 1) / (4 * ACT_THREADS))), dim3(ACT_THREADS), argv, 0,
                            static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
 }
@@ -287,7 +292,30 @@ extern "C" int pbl_act_f32_join(const float* y_f32, const float* tok_scale, cons
                   : out_dtype == PBL_DTYPE_BF16 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_BF16>) : nullptr;
     if (!k) return PBL_ERR_INVALID_ARG;
     const float* y2 = y_f32 + MN;
-    void* argv[] = {&y_f32, &tok_scale, &bias, &N, &MN, &y_out, &y2};
+    const float* y3 = nullptr;
+    float c3 = 0.f;
+    void* argv[] = {&y_f32, &tok_scale, &bias, &N, &MN, &y_out, &y2, &y3, &c3};
+    return hipLaunchKernel(k, dim3(uint32_t((MN + 4 * ACT_THREADS - 1) / (4 * ACT_THREADS))), dim3(ACT_THREADS), argv, 0,
+                           static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+// y_out [M, N] (out_dtype) = cast((y_f32[t, r] (+ y_f32[M + t, r] with two_terms) + lo_scale * y_lo[t, r]) * tok_scale[t] + bias[r]):
+// the terms of an fp32-grid layer multiplied from its two images (pbl_gemm_image_build / _build_residual; lo_scale = 2^-12) -- y_f32
+// [2 M, N] for fp32 activations (pbl_act_f32_split's two fp16 terms through the ordinary image) or [M, N] for fp16 / scaled bf16
+// activations, y_lo [M, N] the HIGH activation term through the residual image.  tok_scale and bias may be NULL.  One small kernel.
+extern "C" int pbl_act_f32_join3(const float* y_f32, int two_terms, const float* y_lo, float lo_scale, const float* tok_scale, const float* bias, int M,
+                                 uint32_t N, void* y_out, int out_dtype, void* stream) {
+    if (!y_f32 || !y_lo || !y_out || M < 1 || N < 1) return PBL_ERR_INVALID_ARG;
+    size_t MN = size_t(M) * N;
+    if ((reinterpret_cast<uintptr_t>(y_f32) & 15) || (reinterpret_cast<uintptr_t>(y_lo) & 15) || (reinterpret_cast<uintptr_t>(y_out) & 15) ||
+        (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) || (reinterpret_cast<uintptr_t>(tok_scale) & 3) || (two_terms && (MN & 3)))
+        return PBL_ERR_MISALIGNED;
+    const void* k = out_dtype == PBL_DTYPE_F32 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_F32>)
+                  : out_dtype == PBL_DTYPE_F16 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_F16>)
+                  : out_dtype == PBL_DTYPE_BF16 ? reinterpret_cast<const void*>(act_finish_kernel<PBL_DTYPE_BF16>) : nullptr;
+    if (!k) return PBL_ERR_INVALID_ARG;
+    const float* y2 = two_terms ? y_f32 + MN : nullptr;
+    void* argv[] = {&y_f32, &tok_scale, &bias, &N, &MN, &y_out, &y2, &y_lo, &lo_scale};
     return hipLaunchKernel(k, dim3(uint32_t((MN + 4 * ACT_THREADS - 1) / (4 * ACT_THREADS))), dim3(ACT_THREADS), argv, 0,
                            static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
 }

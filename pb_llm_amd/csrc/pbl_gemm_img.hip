@@ -106,7 +106,16 @@ struct PrepArgs {
     uint32_t* rlen;                // stats: out, slots of the record in 256-byte units; build: in, rbase (the exclusive prefix sum)
     uint32_t* rtab;                // stats: out; build: in
     uint64_t rtab_off, slots_off, levels_off, total;
+    int resid;                     // build: the RESIDUAL image of an fp32-grid layer (see pbl_gemm_image_build_residual)
 };
+// the fp16 number an image holds for the fp32 value v: fp16(v), or -- residual image -- fp16(4096 (v - fp16(v))): what fp16 lost of
+// v, scaled by 2^12 into fp16's normal range (exact up to ~2^-22 |v|)
+__device__ __forceinline__ uint32_t img_h16(float v, int resid) {
+    asm volatile("" : "+v"(v));      // keep the fp32 value: an fp16-checkpoint value is double rounded
+    const _Float16 h = _Float16(v);
+    if (!resid) return uint32_t(__builtin_bit_cast(uint16_t, h));
+    return uint32_t(__builtin_bit_cast(uint16_t, _Float16(4096.f * (v - float(h)))));
+}
 template <bool STATS>
 __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, PrepArgs pa) {
     extern __shared__ __attribute__((aligned(16))) char smem_p[];
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
             const uint32_t pos = atomicAdd(&s_cnt[h], 1u);
             if (!STATS) {
                 const float qf = float((q >> (8 * e)) & 0xFFu);
-                const uint32_t v = uint32_t(__builtin_bit_cast(uint16_t, round_f16_twice(ss * (qf - sz))));
+                const uint32_t v = img_h16(ss * (qf - sz), pa.resid);
                 put(h, pos, ((row * 256u + ((off[e] & 0xFFu) ^ (row << 4))) << 16) | v);
             }
         }
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
         const uint32_t col = ex.x & 0xFFFFu, row = ex.x >> 16, h = col >> 7, o = (2u * col) & 0xFFu;
         const uint32_t pos = atomicAdd(&s_cnt[h], 1u);
         if (!STATS) {
-            const uint32_t v = uint32_t(__builtin_bit_cast(uint16_t, _Float16(__builtin_bit_cast(float, ex.y))));
+            const uint32_t v = img_h16(__builtin_bit_cast(float, ex.y), pa.resid);
             put(h, pos, ((row * 256u + (o ^ (row << 4))) << 16) | v);
         }
     }
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
             float hi, lo;
             if (L.G > 1) { const float2 v = ghl[(uint32_t(h) * GI_HS) / (L.K / L.G)]; hi = v.x; lo = v.y; }   // row 0's levels of that group
             else { hi = params[0].hi; lo = params[0].lo; }
-            padw = ((d0 >> 8) & 1u) ? h16(hi) : h16(lo);                                                    // row 0 <-> bit 8 (pbl.h), offset 0
+            padw = ((d0 >> 8) & 1u) ? img_h16(hi, pa.resid) : img_h16(lo, pa.resid);                         // row 0 <-> bit 8 (pbl.h), offset 0
         }
         for (uint32_t k = 1; k < EW; ++k)
             if ((k - 1u) * 64u + uint32_t(l) >= n) sl[(k >> 2) * 256u + (k & 3u)] = padw;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(GI_PREP_THREADS) void img_prep_kernel(pbl_layer L, 
         float hi, lo;
         if (L.G > 1) { const float2 v = ghl[size_t(r) * L.G + g]; hi = v.x; lo = v.y; }
         else { hi = params[r].hi; lo = params[r].lo; }
-        const uint32_t hh = h16(hi), ll = h16(lo);
+        const uint32_t hh = img_h16(hi, pa.resid), ll = img_h16(lo, pa.resid);
         lev[it] = (((hh - ll) & 0xFFFFu) << 16) | ll;
     }
     // the record's table row and start, into the image
@@ -1251,7 +1260,23 @@ extern "C" size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* g
 // Build the image into `image` (>= pbl_gemm_image_bytes(layer, geom), 16-byte aligned) from the layer and the statistics buffer
 // pbl_gemm_image_stats filled for it: one small kernel.  It depends on the blob only and stays valid as long as the blob is
 // unchanged; the statistics buffer may be released once this call's kernel has run.
+static int image_build(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, int resid, void* stream);
 extern "C" int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, void* stream) {
+    return image_build(layer, geom, stats_dev, image, image_bytes, 0, stream);
+}
+
+// The RESIDUAL image of an fp32-grid layer (round 6; the reference's fp32-only module classes, quant/quantizer.py:78,175, and QAT's
+// fp32 master weights, utils.py:34-36): the same slots, tables and geometry as pbl_gemm_image_build, but every value v (levels,
+// salient values fl32(sscale (q - szero)), exceptions) is replaced by fp16(4096 (v - fp16(v))).  With the ordinary image (which holds
+// fp16(v)) the layer's fp32 weights are  W = W_hi + 2^-12 W_lo  up to 2^-22 |W|, so  y = x W_hi^T + 2^-12 x W_lo^T  runs on the
+// hand-written fp16-tile kernels and meets the fp32 classes' 2e-5 bar -- no dense fp32 copy, no library GEMM (pbl_act_f32_join3 adds
+// the terms).  Not for PBL_FLAG_SAL_F16 layers (their values ARE fp16: the residual is zero).
+extern "C" int pbl_gemm_image_build_residual(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, void* stream) {
+    if (layer && (layer->flags & PBL_FLAG_SAL_F16)) return PBL_ERR_UNSUPPORTED;
+    return image_build(layer, geom, stats_dev, image, image_bytes, 1, stream);
+}
+
+static int image_build(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, int resid, void* stream) {
     if (!layer || !layer->blob || !image || !geom || !stats_dev) return PBL_ERR_INVALID_ARG;
     if (!layer_ok(layer)) return PBL_ERR_UNSUPPORTED;
     ImgGeom g;
@@ -1265,6 +1290,7 @@ extern "C" int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom
     pa.rlen = reinterpret_cast<uint32_t*>(sb + stats_rlen_off());
     pa.rtab = reinterpret_cast<uint32_t*>(sb + stats_rtab_off(layer));
     pa.rtab_off = g.rtab_off; pa.slots_off = g.slots_off; pa.levels_off = g.levels_off; pa.total = g.total;
+    pa.resid = resid;
     void* argv[] = {&lcopy, &pa};
     return hipLaunchKernel(reinterpret_cast<const void*>(img_prep_kernel<false>), dim3(layer->NRB), dim3(GI_PREP_THREADS), argv, prep_lds(layer),
                            static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;

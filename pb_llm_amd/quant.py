@@ -245,7 +245,7 @@ class GemmImage:
         return int(self.geom[1])
 
 
-def gemm_image(packed: PackedWeight) -> GemmImage | None:
+def gemm_image(packed: PackedWeight, residual: bool = False) -> GemmImage | None:
     """Build the layer's GEMM image: pbl_gemm_image_stats (two small kernels + ONE read-back of two words, the only host sync),
     then pbl_gemm_image_build.  None: the layer has no image (K % 8, more than 127 half slabs, odd group size, a slot with more
     than 1216 entries -- PBL_ERR_UNSUPPORTED / a zero size) -- pbl_gemm_f16_ws serves it.  Any OTHER status (a failed launch, a
@@ -269,7 +269,9 @@ def gemm_image(packed: PackedWeight) -> GemmImage | None:
     if not nb:
         return None                                  # (geom[1] == 0xFFFFFFFF: some slot holds more than 1216 entries)
     data = torch.empty(nb, dtype=torch.uint8, device=dev)
-    _lib.check(L.pbl_gemm_image_build(C.byref(layer), geom, stats.data_ptr(), data.data_ptr(), nb, st), "gemm_image_build")
+    # residual (round 6): the image of what fp16 loses of an fp32-grid layer's values, scaled by 2^12 (pbl_gemm_image_build_residual)
+    build = L.pbl_gemm_image_build_residual if residual else L.pbl_gemm_image_build
+    _lib.check(build(C.byref(layer), geom, stats.data_ptr(), data.data_ptr(), nb, st), "gemm_image_build")
     ev = torch.cuda.Event()
     ev.record(cur)
     return GemmImage(data, geom, ev, st)      # (stats is released behind the build kernel: the caching allocator is stream ordered)
@@ -302,6 +304,67 @@ def _kept_image(packed: PackedWeight) -> GemmImage | None:
         kept = (key, gemm_image(packed))
         packed._gemm_image = kept
     return kept[1]
+
+
+F32_GRID_IMAGES = True     # fp32-grid layers (BinaryLinear / XnorBinaryLinear / fp32 QAT eval) beyond 32 kernel rows: two fp16 images instead of
+                           # pbl_unpack_dev + an fp32 library GEMM (round 6; False restores round 5's library path)
+F32_GRID_LO_SCALE = 2.0 ** -12
+
+
+def _kept_images_f32grid(packed: PackedWeight) -> "tuple[GemmImage, GemmImage] | None":
+    """(ordinary image = fp16(W), residual image = fp16(4096 (W - fp16(W)))) of an fp32-grid layer, built on first use and kept with
+    the PackedWeight until its blob changes; None: the layer has no image (or the build runs under stream capture)"""
+    if packed.flags & _lib.PBL_FLAG_SAL_F16 or not fused_gemm_ok(packed):
+        return None
+    key = (packed.blob.data_ptr(), packed.blob._version)
+    kept = getattr(packed, "_gemm_images_f32", None)
+    if kept is None or kept[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        hi = gemm_image(packed)
+        lo = gemm_image(packed, residual=True) if hi is not None else None
+        kept = (key, (hi, lo) if lo is not None else None)
+        packed._gemm_images_f32 = kept
+    return kept[1]
+
+
+def _f32_grid_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool, images) -> torch.Tensor:
+    """GEMM regime of an fp32-grid layer on the hand-written kernels (round 6): W = W_hi + 2^-12 W_lo with both
+    parts fp16 images, x = s (x_hi + x_lo) for fp32 activations (pbl_act_f32_split), so
+        y = s (x_hi W_hi^T + x_lo W_hi^T + 2^-12 x_hi W_lo^T) + b        (x_lo W_lo^T is 2^-22 of the result: dropped)
+    -- one kernel call over [x_hi; x_lo] and the ordinary image, one over x_hi and the residual image, pbl_act_f32_join3.  fp16 / bf16
+    activations have no x_lo.  x2 [M, K]; returns [M, N] fp32 for fp32 x (or out_f32), else x's dtype."""
+    hi, lo = images
+    L = _lib.lib()
+    M, dev = x2.shape[0], x2.device
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    tsc = None
+    if x2.dtype == torch.float32:
+        xs = x2 if x2.stride(-1) == 1 and (M == 1 or x2.stride(0) >= packed.K) else x2.contiguous()
+        xin = torch.empty(2 * M, packed.K, dtype=torch.float16, device=dev)
+        tsc = torch.empty(M, dtype=torch.float32, device=dev)
+        _lib.check(L.pbl_act_f32_split(xs.data_ptr(), M, packed.K, packed.K if M == 1 else xs.stride(0), xin.data_ptr(), tsc.data_ptr(), stream), "act_f32_split")
+    elif x2.dtype == torch.bfloat16:
+        xin, tsc = act_bf16_prepare(x2)
+    else:
+        xin = x2.contiguous()
+        if xin.data_ptr() % 16:
+            xin = xin.clone()
+
+    def mm(xa, img):
+        if xa.shape[0] <= SMALL_IMAGE_MAX:
+            return small_image_forward(packed, None, xa, img, True)
+        return fused_gemm_forward(packed, None, xa, True, image=img, split_k=GEMM_SPLIT_K)
+
+    y1 = mm(xin, hi)
+    y2 = mm(xin[:M], lo)
+    odt = torch.float32 if (out_f32 or x2.dtype == torch.float32) else x2.dtype
+    out = torch.empty(M, packed.N, dtype=odt, device=dev)
+    code = {torch.float32: _lib.PBL_DTYPE_F32, torch.float16: _lib.PBL_DTYPE_F16, torch.bfloat16: _lib.PBL_DTYPE_BF16}[odt]
+    _lib.check(L.pbl_act_f32_join3(y1.data_ptr(), int(x2.dtype == torch.float32), y2.data_ptr(), F32_GRID_LO_SCALE,
+                                   tsc.data_ptr() if tsc is not None else None, bias_f32.data_ptr() if bias_f32 is not None else None, M, packed.N,
+                                   out.data_ptr(), code, stream), "act_f32_join3")
+    return out
 
 
 def _small_batch_image(packed: PackedWeight) -> GemmImage | None:
@@ -415,6 +478,10 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
     out_f32: return the fp32 accumulator unrounded (tensor-parallel partial sums).
     Differentiable in x (see _PackedLinearFn); the kernels themselves never run under autograd."""
     nat = _lib.native_linear()
+    if nat is not None and dense_dtype == torch.float32 and F32_GRID_IMAGES and GEMM_BACKEND != "library" and x.is_cuda \
+            and x.shape[-1] == packed.K and not packed.flags & _lib.PBL_FLAG_SAL_F16 and fused_gemm_ok(packed) \
+            and (x.numel() // packed.K) * (2 if x.dtype == torch.float32 else 1) > MFMA_MAX and _mfma_ok(packed):
+        nat = None            # fp32-grid layer in the GEMM regime: the two-image path lives in the ctypes route (_f32_grid_forward)
     if nat is not None and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16, torch.float32) and x.shape[-1] == packed.K \
             and packed.blob.device == x.device:
         # ONE native call (csrc/pbl_torch.cpp) for every row count and activation dtype: routing, output / workspace allocation,
@@ -506,6 +573,12 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype, image_only: "G
                                       out.data_ptr(), _lib.PBL_DTYPE_F32, stream), "act_f32_join")
         return (out if out_f32 or x.dtype == torch.float32 else out.to(x.dtype)).reshape(*lead, packed.N)
 
+    if gemm_regime and not io and not dense_f16 and F32_GRID_IMAGES and GEMM_BACKEND != "library" and x.dtype in (torch.float16, torch.bfloat16, torch.float32):
+        imgs = _kept_images_f32grid(packed)
+        if imgs is not None:
+            for im in imgs:
+                _wait_image(torch.cuda.current_stream(x.device), im)
+            return _f32_grid_forward(packed, bias_f32, x2, out_f32, imgs).reshape(*lead, packed.N)
     if gemm_regime:
         # GEMM regime (same routing as csrc/pbl_torch.cpp).  Every fp16-exact layer runs on the hand-written kernels whatever
         # the activation dtype (backends "auto" / "fused"; "tuned": where an image was granted); fp32-grid layers, "library" and

@@ -17,6 +17,7 @@ from pb_llm_amd import quant as Q
 from pb_llm_amd.packing import pack_dense
 from pb_llm_amd.runtime import GroupedGemv
 from conftest import golden
+from op_trace import LIBRARY_GEMM_OPS, called_ops
 from test_oracle_golden import g5_inputs, g5_name
 
 pytestmark = pytest.mark.gpu
@@ -1045,3 +1046,62 @@ def test_concurrent_host_threads_on_their_own_streams():
     for t in threads: t.join()
     torch.cuda.synchronize()
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("cls", ["binary", "xnor", "qat_f32"])
+def test_fp32_grid_layers_in_the_gemm_regime_never_reach_a_library_gemm(cls):
+    """VERDICT r5 item 8 / the residue of row a17: the reference's fp32-only module classes (quant/quantizer.py:75-86,172-193: weights
+    forced to fp32) and the QAT layer with fp32 master weights (utils.py:34-36) ran `pbl_unpack_dev + at::linear` (fp32 library GEMM)
+    above 32 kernel rows -- fp16 tiles cannot hold their values.  Round 6: two fp16 images (W = fp16(W) + 2^-12 residual) on the
+    hand-written kernels + pbl_act_f32_join3.  64 and 2048 rows (small-batch and GEMM kernels), fp32 / fp16 / bf16 activations: no
+    ATen GEMM operator runs (operator trace), 2e-5 against the float64 oracle for fp32 activations."""
+    N, K = 768, 1024
+    W = synth.llm_weight(N, K, seed=41, heavy_tail=True)
+    W[3, 5] = 0.0
+    b = synth.normal((N,), 41, 3, 0.1)
+    if cls == "binary":
+        m = Q.BinaryLinear(torch.from_numpy(W), torch.from_numpy(b)).to(DEV).eval()
+        ref_fn = lambda x: O.binary_linear_forward(x, W, b)                       # noqa: E731
+    elif cls == "xnor":
+        m = Q.XnorBinaryLinear(torch.from_numpy(W), torch.from_numpy(b)).to(DEV).eval()
+        ref_fn = lambda x: O.xnor_binary_linear_forward(x, W, b)                  # noqa: E731
+    else:
+        m = Q.BinaryXnorExceptOutliersLinear(torch.from_numpy(W), torch.from_numpy(b), 0.1)
+        m.eval()
+        m.gen_outlier_mask()
+        m = m.to(DEV)
+        w_hat, mask, scale = m.weight.data.float().cpu().numpy(), m.outlier_mask.cpu().numpy(), m.binary_scale.cpu().numpy()
+        ref_fn = lambda x: O.pb_qat_forward(x, w_hat, mask, scale, b)             # noqa: E731
+    assert Q.F32_GRID_IMAGES and Q.GEMM_BACKEND == "auto"
+    for M in (64, 2048):
+        x = synth.normal((M, K), 41, 5 + M, 1.0)
+        xt = T(x)
+        with torch.no_grad():
+            ops = called_ops(lambda: m(xt))
+            assert not (ops & LIBRARY_GEMM_OPS), (cls, M, ops & LIBRARY_GEMM_OPS)
+            y = m(xt)
+            assert y.dtype == torch.float32 and y.shape == (M, N)
+            assert_parity(y, ref_fn(x), 2e-5)
+            assert torch.equal(y, m(xt))
+            if cls != "qat_f32":
+                continue                      # (the fp32-only classes raise on half inputs in the reference; ours follow the input dtype -- below for the QAT layer)
+            for dt in (torch.float16, torch.bfloat16):
+                xd = xt.to(dt)
+                assert not (called_ops(lambda: m(xd)) & LIBRARY_GEMM_OPS), (cls, M, dt)
+                yd = m(xd)
+                assert yd.dtype == dt
+                assert O.parity_errors(yd.float().cpu().numpy(), ref_fn(xd.float().cpu().numpy()))[0] < (1e-3 if dt == torch.float16 else 1e-2)
+    # a value beyond fp16's range in the activations (ADVICE r5) on this route as well
+    xo = T(synth.normal((64, K), 41, 99, 1.0))
+    xo[5, 7] = 2.0e5
+    with torch.no_grad():
+        yo = m(xo)
+    assert bool(torch.isfinite(yo).all()) and O.parity_errors(yo.cpu().numpy(), ref_fn(xo.cpu().numpy()))[0] < 2e-5
+    old = Q.F32_GRID_IMAGES
+    try:
+        Q.F32_GRID_IMAGES = False              # round 5's route: the fp32 library GEMM on the unpacked weight
+        with torch.no_grad():
+            assert called_ops(lambda: m(xt)) & LIBRARY_GEMM_OPS
+            assert_parity(m(xt), y.cpu().numpy().astype(np.float64), 2e-5)
+    finally:
+        Q.F32_GRID_IMAGES = old

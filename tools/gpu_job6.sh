@@ -53,6 +53,16 @@ mix1)   # image-only residency test + new small-batch tests, GEMM-image kernel a
   unset PBL_LIB
   timeout 300 python tools/bench_hessian_gemv.py 2> $O/hess.err | tee $O/hessian_gemv.jsonl | cut -c1-400
   ;;
+profiles)   # rocprofv3 of the driver's command (kernel trace + PMC passes), of cfg4 (trace + PMC) and a kernel trace of cfg3 -- the side entries' layers
+  [ -x build/calib_fetch ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/calib_fetch.hip -o build/calib_fetch > /dev/null 2>&1
+  PROF_STEPS=20 PROF_WARMUP=5 timeout 1200 bash tools/profile.sh r06_final > $O/profile_final.txt 2>&1; tail -30 $O/profile_final.txt | cut -c1-400
+  timeout 900 bash tools/profile_cfg4.sh r06_cfg4 --synth device > $O/profile_cfg4.txt 2>&1; tail -14 $O/profile_cfg4.txt | cut -c1-400
+  mkdir -p gpurun_out/prof_r06_cfg3
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r06_cfg3/gemmimg_trace -o trace -- python bench.py --workload cfg3 --synth device --steps 10 --warmup 3 > gpurun_out/prof_r06_cfg3/trace.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace -d gpurun_out/prof_r06_cfg3/gemmimg_pmc -o pmc -- python bench.py --workload cfg3 --synth device --steps 10 --warmup 3 > gpurun_out/prof_r06_cfg3/pmc.log 2>&1
+  python tools/summarize_prof.py gpurun_out/prof_r06_cfg3 > gpurun_out/prof_r06_cfg3/summary.txt 2>&1; cut -c1-300 gpurun_out/prof_r06_cfg3/summary.txt | head -24
+  grep '"metric"' gpurun_out/prof_r06_cfg3/trace.log | cut -c1-600
+  find gpurun_out/prof_r06_final gpurun_out/prof_r06_cfg4 gpurun_out/prof_r06_cfg3 -name "*.db" -size +6M -delete ;;
 full)
   for i in $(seq 1 ${REPS:-1}); do timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 900 > $O/pytest$i.txt 2>&1; tail -3 $O/pytest$i.txt | cut -c1-300; grep -E "^(FAILED|ERROR)" $O/pytest$i.txt | cut -c1-300; done
   ;;

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 # into the pre-heat loop and the last W + K dispatches (the timed region) with them
 STEPS=${PROF_STEPS:-300}; WARM=${PROF_WARMUP:-100}
 export PBL_PROF_WINDOW=$((STEPS + WARM))
-ARGS="--steps $STEPS --warmup $WARM --no-cpu-baseline $*"
+ARGS="--steps $STEPS --warmup $WARM --no-cpu-baseline --no-side $*"      # (the side entries are profiled on their own: gpu_job6.sh profiles)
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python bench.py $ARGS > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE \
   --kernel-trace -d $OUT/pmc1 -o pmc -- python bench.py $ARGS > $OUT/pmc1.log 2>&1
