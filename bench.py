@@ -47,7 +47,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_PROFILE = os.path.join("profiles", "traffic_r05.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "traffic_r06.json")
 
 
 def build_base_layers(n_distinct, N, K, low_frac, seed0):

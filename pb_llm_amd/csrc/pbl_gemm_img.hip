@@ -51,7 +51,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define PBL_GEMM_PPRIO 1
 #endif
 // performance-analysis hook (tools/build_variant.sh): bit 0 no expansion in the loop, bit 1 no x staging in the loop, bit 2 no
-// MFMA.  0 in every shipped build (results are wrong otherwise).
+// MFMA, bits 3 / 4 x staging that re-reads half / an eighth of its bytes (round 6).  0 in every shipped build (results are wrong otherwise).
 #ifndef PBL_IMG_ABLATE
 #define PBL_IMG_ABLATE 0
 #endif
@@ -469,7 +469,9 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const uint32_t dst = GI_X_OFF + slot_off + uint32_t(8 * p + q) * 1024u;
-                uint32_t vo = xvoff[q];
+                // (analysis builds: bit 3 -- pieces 4 .. 7 re-read the bytes of pieces 0 .. 3, bit 4 -- every piece re-reads piece 0's: the
+                // same instructions and LDS writes with half / an eighth of the distinct bytes from L2)
+                uint32_t vo = xvoff[(PBL_IMG_ABLATE & 16) ? 0 : ((PBL_IMG_ABLATE & 8) ? (q & 3) : q)];
                 if constexpr (KT) vo = (ub + u == NUt - 1) ? xvlast[q] : vo;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(smem_i + dst), 16, int(vo), int(so), 0, 0);
             }

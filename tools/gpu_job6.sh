@@ -63,6 +63,24 @@ profiles)   # rocprofv3 of the driver's command (kernel trace + PMC passes), of 
   python tools/summarize_prof.py gpurun_out/prof_r06_cfg3 > gpurun_out/prof_r06_cfg3/summary.txt 2>&1; cut -c1-300 gpurun_out/prof_r06_cfg3/summary.txt | head -24
   grep '"metric"' gpurun_out/prof_r06_cfg3/trace.log | cut -c1-600
   find gpurun_out/prof_r06_final gpurun_out/prof_r06_cfg4 gpurun_out/prof_r06_cfg3 -name "*.db" -size +6M -delete ;;
+mix2)   # x-staging byte-reduction ablations of the GEMM-image kernel; tensor-parallel plumbing lines with the phase timings (ranks share ONE GPU)
+  for v in default abl4 abl12 abl20 abl8 abl16 default; do
+    if [ $v = default ]; then unset PBL_LIB; else export PBL_LIB=build/libpbl_$v.so; fi
+    [ $v = default ] || [ -f build/libpbl_$v.so ] || continue
+    timeout 200 python tools/bench_gemm_ablate.py 2>> $O/ablate.err | tee -a $O/ablate2.jsonl
+  done
+  unset PBL_LIB
+  for n in 2 4; do
+    PBL_BENCH_BACKEND=gloo PBL_BENCH_BASELINE=1 MASTER_PORT=296$n timeout 500 python bench.py --gpus $n --steps 5 --warmup 2 --preheat-s 0.3 --no-cpu-baseline > $O/tp${n}_plumbing.json 2> $O/tp${n}_plumbing.err
+    echo tp$n rc=$?; python - $O/tp${n}_plumbing.json <<'P'
+import json,sys
+for l in open(sys.argv[1]):
+    if l.startswith('{"metric"'):
+        d=json.loads(l); print(round(d["value"]), d["config"].get("tp_path"), d["config"].get("tp_notes"), json.dumps(d.get("tp_phases"))[:900])
+P
+    tail -2 $O/tp${n}_plumbing.err | cut -c1-300
+  done
+  ;;
 full)
   for i in $(seq 1 ${REPS:-1}); do timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 900 > $O/pytest$i.txt 2>&1; tail -3 $O/pytest$i.txt | cut -c1-300; grep -E "^(FAILED|ERROR)" $O/pytest$i.txt | cut -c1-300; done
   ;;
