@@ -351,6 +351,19 @@ size_t pbl_gemm_image_stats_bytes(const pbl_layer* layer);
 int pbl_gemm_image_stats(const pbl_layer* layer, void* stats_dev, void* stream);
 size_t pbl_gemm_image_bytes(const pbl_layer* layer, const uint32_t* geom);
 int pbl_gemm_image_build(const pbl_layer* layer, const uint32_t* geom, const void* stats_dev, void* image, size_t image_bytes, void* stream);
+/* x as a FRAGMENT-MAJOR copy (round 6).  Taking pbl_gemm_f16_image's loop apart showed a quarter of a round going into staging x through
+ * LDS (2 MB per CU and 128 x 256 tile by LDS-DMA, ~50 B/clk/CU whatever the source; profiles/r06_gemm.md).  With this copy a matrix-core B
+ * fragment is 1 KiB of contiguous memory and the kernel's MFMA waves load it straight into registers: no x tile passes through LDS.
+ *   pbl_x_fragment_bytes   size of the copy of x [M, K] fp16: tokens up to a whole 256-token tile x (K up to a 64-column step, + 64) x 2
+ *   pbl_x_to_fragments     x [M, K] fp16 (device, rows ldx elements apart) -> the copy (16-byte aligned): for every block of 32 tokens and
+ *                          every 16-column k-step 1 KiB -- lane l of 64: token l & 31, columns 16 ks + 8 (l >> 5) .. + 7; zeros beyond M / K.
+ *                          ONE small streaming kernel per DISTINCT x: q / k / v of a decoder layer share a copy, gate / up another.
+ *   pbl_gemm_f16_image_xf  pbl_gemm_f16_image_ws with x given as that copy (same M, K, plans, workspace): bit-identical results. */
+size_t pbl_x_fragment_bytes(int M, uint32_t K);
+int pbl_x_to_fragments(const void* x_f16, int M, uint32_t K, size_t ldx, void* x_fragments, void* stream);
+int pbl_gemm_f16_image_xf(const pbl_layer* layer, const void* x_fragments, void* y, int M, int out_dtype, const float* tok_scale,
+                          const void* image, size_t image_bytes, const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream);
+
 /* The RESIDUAL image of an fp32-grid layer (round 6): same buffer size, geometry words and statistics buffer as pbl_gemm_image_build,
  * but every value v of the layer (row levels, salient values fl32(sscale (q - szero)), exceptions) is stored as fp16(4096 (v - fp16(v)))
  * where the ordinary image stores fp16(v).  The reference's fp32-only module classes (quant/quantizer.py:75-86,172-193: weights forced

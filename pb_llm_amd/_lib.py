@@ -50,7 +50,7 @@ _lib = None
 EXPORTS = ["pbl_status_string", "pbl_version", "pbl_pack_dense_f32", "pbl_pack_dev_count", "pbl_pack_dev_write", "pbl_blob_describe",
            "pbl_unpack_dense_f32", "pbl_unpack_dev", "pbl_gemv_lds_bytes", "pbl_linear_f16", "pbl_linear_f16_ws", "pbl_gemm_mfma_f16",
            "pbl_gemm_mfma_f16_ws", "pbl_mfma_workspace_bytes", "pbl_linear_workspace_bytes", "pbl_gemv_f16_grouped", "pbl_gemv_f16_fused", "pbl_gemv_f16_fused_host", "pbl_gemm_f16", "pbl_gemm_f16_ex", "pbl_gemm_f16_ws", "pbl_gemm_workspace_bytes", "pbl_gemm_list_bytes", "pbl_gemm_prepare", "pbl_gemm_f16_prepared",
-           "pbl_gemm_image_stats_bytes", "pbl_gemm_image_stats", "pbl_gemm_image_bytes", "pbl_gemm_image_build", "pbl_gemm_image_build_residual", "pbl_act_f32_join3", "pbl_gemm_f16_image",
+           "pbl_gemm_image_stats_bytes", "pbl_gemm_image_stats", "pbl_gemm_image_bytes", "pbl_gemm_image_build", "pbl_gemm_image_build_residual", "pbl_act_f32_join3", "pbl_x_fragment_bytes", "pbl_x_to_fragments", "pbl_gemm_f16_image_xf", "pbl_gemm_f16_image",
            "pbl_gemm_small_image_workspace_bytes", "pbl_gemm_small_image_ws", "pbl_gemm_small_image_act", "pbl_act_f32_split", "pbl_act_f32_join",
            "pbl_qat_workspace_bytes", "pbl_qat_scale", "pbl_qat_wsim", "pbl_qat_wgrad",
            "pbl_prep_workspace_bytes", "pbl_kth_pair", "pbl_outlier_mask", "pbl_quant8_rows", "pbl_high_calibrate", "pbl_gptq_block",
@@ -129,6 +129,12 @@ def lib() -> C.CDLL:
     L.pbl_gemm_image_build.argtypes = [C.POINTER(PblLayer), vp, vp, vp, sz, vp]
     L.pbl_gemm_image_build_residual.restype = C.c_int
     L.pbl_gemm_image_build_residual.argtypes = [C.POINTER(PblLayer), vp, vp, vp, sz, vp]
+    L.pbl_x_fragment_bytes.restype = sz
+    L.pbl_x_fragment_bytes.argtypes = [C.c_int, u32]
+    L.pbl_x_to_fragments.restype = C.c_int
+    L.pbl_x_to_fragments.argtypes = [vp, C.c_int, u32, sz, vp, vp]
+    L.pbl_gemm_f16_image_xf.restype = C.c_int
+    L.pbl_gemm_f16_image_xf.argtypes = [C.POINTER(PblLayer), vp, vp, C.c_int, C.c_int, vp, vp, sz, vp, vp, sz, vp]
     L.pbl_act_f32_join3.restype = C.c_int
     L.pbl_act_f32_join3.argtypes = [vp, C.c_int, vp, C.c_float, vp, vp, C.c_int, u32, vp, C.c_int, vp]
     L.pbl_gemm_f16_image.restype = C.c_int

@@ -55,6 +55,12 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef PBL_IMG_ABLATE
 #define PBL_IMG_ABLATE 0
 #endif
+#ifndef PBL_XF_BMOD
+#define PBL_XF_BMOD ""                // XF: cache-policy bits of the B-fragment loads (A/B builds: " nt", " sc0", " sc1", " sc0 sc1")
+#endif
+#ifndef PBL_XF_DEPTH
+#define PBL_XF_DEPTH 4                // XF: k-steps the MFMA waves request their B fragments ahead (4: one 64-column step, 8: two)
+#endif
 
 // timeline probe, as in pbl_gemm_big.hip (tools/trace_gemm.py)
 #ifndef PBL_TRACE
@@ -298,6 +304,11 @@ struct ImgArgs {
     const uint32_t* rtab;
     const uint32_t* levels;
     const float* tok_scale; // OM == 2: [M] fp32, the power of two (or +inf) every token's row of y is multiplied with (pbl_act_bf16_prepare)
+    // XF (round 6): x as FRAGMENT-MAJOR copy (pbl_x_to_fragments): [token block of 32][8-column group][32 tokens][8 halves], rows of
+    // xf_kp columns (K rounded up to 64, + 64 columns of zeros), token blocks up to a whole 256-token tile.  The MFMA waves then load
+    // their B fragments straight from it (1 KiB contiguous per fragment) and no x tile goes through LDS at all.
+    const _Float16* xf;
+    uint32_t xf_kp;
     // the work of THIS launch (round 5, pbl_gemm_f16_image_ws: a thin last round is cut off and split along K): row tiles
     // [rt0, rt0 + nrt) x token tiles [tt0, tt0 + ntt), each in KSn work items of hps half slabs out of [h0, h0 + nh).  Work item
     // (tile, ks) writes y element (tok, row) to  ybase[(tok - ytok0) * ldy + (row - ycol0)],  ybase = y + ks * part_stride floats
@@ -324,7 +335,13 @@ __device__ __forceinline__ uint32_t bf16_bits(float f) {
 // OM: the result's type -- 0 fp16, 1 fp32 (both exactly round 4's kernel), 2 bf16 with the per-token scale of bf16 activations:
 // y[t, r] = bf16(acc * tok_scale[t] + bias[r]) (round 5: bf16 activations of the reference's perplexity / QAT loops,
 // qat/run_qat.py:120, no longer leave the hand-written kernel for an unpack + library GEMM)
-template <int OM, bool KT>
+// XF (round 6): the x tile does not go through LDS.  Taking the loop apart (profiles/r06_gemm.md) showed the producer side alone at
+// 53 us per round, 19 of them the LDS-DMA staging of x (2 MB per CU and tile at ~50 B/clk into the LDS, whatever the source) -- more
+// than the dense library's whole kernel leaves.  With a fragment-major copy of x (one small kernel per DISTINCT x: q / k / v and
+// gate / up share theirs) a B fragment is 1 KiB of contiguous memory: the MFMA waves load it into registers four k-steps ahead
+// (asm loads, ONE counted `vmcnt(6)`: three k-steps of two loads stay in flight), the expanding waves only expand, and the LDS
+// carries A alone.
+template <int OM, bool KT, bool XF>
 __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kernel(ImgArgs a) {
     constexpr bool Y32 = OM == 1;
     extern __shared__ __attribute__((aligned(16))) char smem_i[];
@@ -447,6 +464,29 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
                          : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]) : "v"(lo), "s"(sp), "s"(nv) : "memory", "scc");
             nv_out = int(nv);
         };
+        // XF: ALWAYS five loads per request (a vector the slot does not have re-reads its first one: an L1 hit into registers nobody
+        // stores) -- without the eight x pieces per step between two requests the in-order count that proves "the set requested four
+        // requests ago has landed" must come from the requests themselves: three requests x five loads = `vmcnt(15)`
+        auto request_xf = [&](int i, int hh, u32x4 (&dst)[GI_NVMAX], int& nv_out) {
+            const uint32_t t = slot_word(i, min(hh, NH - 1));
+            const uint32_t nv = t >> 16;
+            const uint8_t* sp = sbase[i] + size_t(t & 0xFFFFu) * 256;
+            const uint32_t o1 = lane16 + (nv > 1u ? 1024u : 0u), o2 = lane16 + (nv > 2u ? 2048u : 0u), o3 = lane16 + (nv > 3u ? 3072u : 0u);
+            const uint32_t o4 = lane16 + (nv > 4u ? 4096u : 0u);
+            static_assert(GI_NVMAX == 5, "the request block spells five loads out");
+            asm volatile("global_load_dwordx4 %0, %5, %10\n\t"
+                         "global_load_dwordx4 %1, %6, %10\n\t"
+                         "global_load_dwordx4 %2, %7, %10\n\t"
+                         "global_load_dwordx4 %3, %8, %10\n\t"
+                         "global_load_dwordx4 %4, %9, %10"
+                         : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4])
+                         : "v"(lane16), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "s"(sp) : "memory");
+            nv_out = int(nv);
+        };
+        auto req = [&](int i, int hh, u32x4 (&dst)[GI_NVMAX], int& nv_out) {
+            if constexpr (XF) request_xf(i, hh, dst, nv_out);
+            else request(i, hh, dst, nv_out);
+        };
         // x through a buffer descriptor that starts at this workgroup's first token: tokens >= M read zeros
         const char* xbase = reinterpret_cast<const char*>(a.x) + size_t(tok0) * size_t(K) * 2;
         const size_t xrem = size_t(min(M - tok0, GI_TOK)) * size_t(K) * 2;          // <= 256 * 32767 * 2 < 2^24
@@ -515,7 +555,8 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
 #define GI_EREGS GI_ESET(0, 0), GI_ESET(0, 1), GI_ESET(1, 0), GI_ESET(1, 1)
         auto wait_all = [&]() {
             TR_T0();
-            asm volatile("s_waitcnt vmcnt(10)" : GI_EREGS :: "memory");
+            if constexpr (XF) asm volatile("s_waitcnt vmcnt(15)" : GI_EREGS :: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" : GI_EREGS :: "memory");
             TR_ADD(tr_vm);
         };
         auto barrier = [&]() {
@@ -530,14 +571,16 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
 #pragma unroll
         for (int i = 0; i < 2; ++i) load_levels(i, (uint32_t(hb) * GI_HS) / gs);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) request(i, hb, e[0][i], nvs[0][i]);
+        for (int i = 0; i < 2; ++i) req(i, hb, e[0][i], nvs[0][i]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) request(i, hb + 1, e[1][i], nvs[1][i]);
-        stage_x(0, 0);
-        stage_x(1, GI_XSLOT);
+        for (int i = 0; i < 2; ++i) req(i, hb + 1, e[1][i], nvs[1][i]);
+        if constexpr (!XF) {
+            stage_x(0, 0);
+            stage_x(1, GI_XSLOT);
+        }
         asm volatile("s_waitcnt vmcnt(0)" : GI_EREGS :: "memory");
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { expand(i, e[0][i], nvs[0][i], 0); request(i, hb + 2, e[0][i], nvs[0][i]); }
+        for (int i = 0; i < 2; ++i) { expand(i, e[0][i], nvs[0][i], 0); req(i, hb + 2, e[0][i], nvs[0][i]); }
         TR_STAMP(1);
         barrier();                                               // barrier 0: stage 0 of A, steps 0 and 1 of x are in LDS
 
@@ -548,11 +591,13 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
             constexpr int QM = decltype(qm_tag)::value;           // q & 3
             constexpr int i = QM & 1, st = ((QM >> 1) + 1) & 1;   // record; stage == register set == parity of the target half slab
             const int hh = hb + (q >> 1) + 1;                   // (absolute half slab; q counts this item's steps)
-            if (!(PBL_IMG_ABLATE & 2)) stage_x(q + 2, xs_free);
-            { const uint32_t t = xs_free; xs_free = xs_a; xs_a = xs_b; xs_b = t; }
+            if constexpr (!XF) {
+                if (!(PBL_IMG_ABLATE & 2)) stage_x(q + 2, xs_free);
+                { const uint32_t t = xs_free; xs_free = xs_a; xs_a = xs_b; xs_b = t; }
+            }
             if (L.G > 1 && (uint32_t(hh) * GI_HS) % gs == 0 && hh < NH) load_levels(i, (uint32_t(hh) * GI_HS) / gs);
             if (!(PBL_IMG_ABLATE & 1)) expand(i, e[st][i], nvs[st][i], uint32_t(st));
-            request(i, hh + 2, e[st][i], nvs[st][i]);
+            req(i, hh + 2, e[st][i], nvs[st][i]);
             wait_all();
             barrier();
         };
@@ -642,6 +687,113 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
         asm volatile("" ::: "memory");
     }
     TR_STAMP(1);
+    if constexpr (XF) {
+        // ---- XF: B fragments from the fragment-major copy of x, straight into registers.  k-step j (16 columns) of token block tb:
+        // 1 KiB at  xf + tb * xf_kp * 64 + j * 1024,  lane l its 16 bytes at + 16 l.  bx[k][tt]: the fragment of the CURRENT step's
+        // k-step k; the load for the same k of the NEXT step is issued right behind the MFMAs that consumed it (four k-steps ahead),
+        // so in front of k-step j + 1 exactly the loads of j + 2, j + 3, j + 4 are younger: ONE constant `vmcnt(6)`.  The MFMA waves
+        // issue no other vector-memory instruction.  Past the item's end the loads read the next split's columns or the copy's 64
+        // columns of zero padding; nothing is used, `vmcnt(0)` behind the loop keeps them out of the epilogue's registers.
+        struct FragA { v8h a[4]; };
+        constexpr int XD = PBL_XF_DEPTH;                             // k-steps a B fragment is requested ahead: 4 (one step) or 8 (two steps)
+        static_assert(XD == 4 || XD == 8, "B fragments are requested one or two 64-column steps ahead");
+        v8h bx[XD][2];
+        const uint64_t tb0 = uint64_t(tok0 / 32 + 2 * c);
+        const char* bbase = reinterpret_cast<const char*>(a.xf) + tb0 * uint64_t(a.xf_kp) * 64u + uint64_t(ub) * 4096u;   // this item's first step
+        const uint32_t off0 = uint32_t(lane) * 16u, off1 = off0 + a.xf_kp * 64u;
+        auto load_b_ = [](v8h (&d)[2], const char* base, uint32_t o0, uint32_t o1, auto k_tag) {     // (offsets as arguments: clang does not
+            constexpr int KO = decltype(k_tag)::value * 1024;                                          // capture locals named only by asm operands)
+            asm volatile("global_load_dwordx4 %0, %2, %4 offset:%5" PBL_XF_BMOD "\n\t"
+                         "global_load_dwordx4 %1, %3, %4 offset:%5" PBL_XF_BMOD
+                         : "=&v"(d[0]), "=&v"(d[1]) : "v"(o0), "v"(o1), "s"(base), "n"(KO) : "memory");
+        };
+        auto load_b = [&](v8h (&d)[2], const char* base, auto k_tag) { load_b_(d, base, off0, off1, k_tag); };
+        auto wait_b = [&](v8h (&d)[2]) {                            // d has landed; the 2 (XD - 1) younger loads stay in flight
+            if constexpr (XD == 4) asm volatile("s_waitcnt vmcnt(6)" : "+v"(d[0]), "+v"(d[1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(14)" : "+v"(d[0]), "+v"(d[1]) :: "memory");
+        };
+        auto load_a = [&](FragA& f, uint32_t aaddr, auto aoff_tag) {
+            constexpr int AO = decltype(aoff_tag)::value;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a[0]) : "v"(aaddr), "n"(AO) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a[1]) : "v"(aaddr), "n"(AO + 8192) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a[2]) : "v"(aaddr), "n"(AO + 16384) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(f.a[3]) : "v"(aaddr), "n"(AO + 24576) : "memory");
+        };
+        auto wait_a = [&](FragA& f, auto n_tag) {
+            constexpr int NOUT = decltype(n_tag)::value;
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]) : "n"(NOUT) : "memory");
+        };
+        auto mma_x = [&](const FragA& f, const v8h (&b)[2]) {
+            if (!(PBL_IMG_ABLATE & 4)) {
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt)
+                        acc[rt][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[rt], b[tt], acc[rt][tt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        load_b(bx[0], bbase, std::integral_constant<int, 0>{});
+        load_b(bx[1], bbase, std::integral_constant<int, 1>{});
+        load_b(bx[2], bbase, std::integral_constant<int, 2>{});
+        load_b(bx[3], bbase, std::integral_constant<int, 3>{});
+        if constexpr (XD == 8) {
+            load_b(bx[XD - 4], bbase + 4096, std::integral_constant<int, 0>{});
+            load_b(bx[XD - 3], bbase + 4096, std::integral_constant<int, 1>{});
+            load_b(bx[XD - 2], bbase + 4096, std::integral_constant<int, 2>{});
+            load_b(bx[XD - 1], bbase + 4096, std::integral_constant<int, 3>{});
+        }
+        const char* bnext = bbase + (XD / 4) * 4096;
+        FragA g0, g1;
+        load_a(g0, aq[0], std::integral_constant<int, 0>{});
+        auto substep_x = [&](auto um_tag) {
+            constexpr int UM = decltype(um_tag)::value;               // u & 3
+            constexpr int abuf = ((UM >> 1) & 1) * GI_AS_STAGE, nabuf = (((UM + 1) >> 1) & 1) * GI_AS_STAGE;
+            constexpr uint32_t ahalf = uint32_t(UM & 1) * 128u, nahalf = uint32_t((UM + 1) & 1) * 128u;
+            constexpr int B0 = XD == 8 ? 4 * (UM & 1) : 0;            // this step's fragment registers (two steps ahead: even / odd steps alternate)
+            load_a(g1, aq[1] ^ ahalf, std::integral_constant<int, abuf>{});
+            wait_a(g0, std::integral_constant<int, 4>{});
+            wait_b(bx[B0 + 0]);
+            mma_x(g0, bx[B0 + 0]);
+            load_b(bx[B0 + 0], bnext, std::integral_constant<int, 0>{});
+            load_a(g0, aq[2] ^ ahalf, std::integral_constant<int, abuf>{});
+            wait_a(g1, std::integral_constant<int, 4>{});
+            wait_b(bx[B0 + 1]);
+            mma_x(g1, bx[B0 + 1]);
+            load_b(bx[B0 + 1], bnext, std::integral_constant<int, 1>{});
+            load_a(g1, aq[3] ^ ahalf, std::integral_constant<int, abuf>{});
+            wait_a(g0, std::integral_constant<int, 4>{});
+            wait_b(bx[B0 + 2]);
+            mma_x(g0, bx[B0 + 2]);
+            load_b(bx[B0 + 2], bnext, std::integral_constant<int, 2>{});
+            wait_a(g1, std::integral_constant<int, 0>{});             // every LDS read of this step has returned
+            {
+                TR_T0();
+                __builtin_amdgcn_s_barrier();                         // barrier u + 1: after an odd step, the next stage of A is complete
+                TR_ADD(tr_bar);
+                asm volatile("" ::: "memory");
+            }
+            load_a(g0, aq[0] ^ nahalf, std::integral_constant<int, nabuf>{});
+            wait_b(bx[B0 + 3]);
+            mma_x(g1, bx[B0 + 3]);
+            load_b(bx[B0 + 3], bnext, std::integral_constant<int, 3>{});
+            if (!(PBL_IMG_ABLATE & 8)) bnext += 4096;          // (analysis builds, bit 3: every B load re-reads the same step -- L1 hits)
+        };
+        int u = 0;
+        for (; u + 4 <= NU; u += 4) {
+            substep_x(std::integral_constant<int, 0>{});
+            substep_x(std::integral_constant<int, 1>{});
+            substep_x(std::integral_constant<int, 2>{});
+            substep_x(std::integral_constant<int, 3>{});
+        }
+        if (u < NU) { substep_x(std::integral_constant<int, 0>{}); ++u; }
+        if (u < NU) { substep_x(std::integral_constant<int, 1>{}); ++u; }
+        if (u < NU) { substep_x(std::integral_constant<int, 2>{}); ++u; }
+        wait_a(g0, std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bx[0][0]), "+v"(bx[0][1]), "+v"(bx[1][0]), "+v"(bx[1][1]), "+v"(bx[2][0]), "+v"(bx[2][1]), "+v"(bx[3][0]), "+v"(bx[3][1]) :: "memory");
+        if constexpr (XD == 8)
+            asm volatile("" : "+v"(bx[XD - 4][0]), "+v"(bx[XD - 4][1]), "+v"(bx[XD - 3][0]), "+v"(bx[XD - 3][1]), "+v"(bx[XD - 2][0]), "+v"(bx[XD - 2][1]), "+v"(bx[XD - 1][0]), "+v"(bx[XD - 1][1]) :: "memory");
+    } else {
     Frag f0, f1;
     uint32_t xs0 = 0, xs1 = GI_XSLOT, xs2 = 2 * GI_XSLOT;         // ring slot of this step, the next, the one after
     load_frag(f0, aq[0], bq[0], std::integral_constant<int, 0>{});
@@ -683,6 +835,7 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
     if (u < NU) { substep(std::integral_constant<int, 1>{}); ++u; }
     if (u < NU) { substep(std::integral_constant<int, 2>{}); ++u; }
     wait_frag(f0, std::integral_constant<int, 0>{});              // (the last prefetch: nothing may land in the registers later)
+    }
     TR_STAMP(2);
 #if PBL_TRACE
     if (tr && lane == 0) { tr[8] = tr_bar; tr[9] = tr_vm; }
@@ -1401,7 +1554,8 @@ __global__ __launch_bounds__(256) void img_reduce_kernel(const float* __restrict
 }
 
 int img_launch(const ImgArgs& a0, int om, bool kt, hipStream_t st) {
-#define GI_PICK(OM_) (kt ? reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, true>) : reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, false>))
+#define GI_PICK(OM_) (a0.xf ? reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, false, true>) \
+                            : (kt ? reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, true, false>) : reinterpret_cast<const void*>(pbl_gemm_img_kernel<OM_, false, false>)))
     const void* k = om == 1 ? GI_PICK(1) : (om == 2 ? GI_PICK(2) : GI_PICK(0));
 #undef GI_PICK
     if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(GI_LDS)) != hipSuccess) return PBL_ERR_LAUNCH;
@@ -1443,10 +1597,89 @@ extern "C" size_t pbl_gemm_image_workspace_bytes(const pbl_layer* layer, int M) 
 // workspace (pbl_gemm_image_workspace_bytes(layer, M), 16-byte aligned; NULL / too small: one launch over everything, bit-identical
 // to pbl_gemm_f16_ws / _prepared): with it a thin last round is cut off and split along K (see ImgPlan) -- the tiles of the full part
 // keep those bits, the tail's differ by fp32 summation order (within the parity tolerance; repeatable run to run).
+static int image_gemm(const pbl_layer* layer, const void* x, const void* xf, void* y, int M, int out_dtype, const float* tok_scale,
+                      const void* image, size_t image_bytes, const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int pbl_gemm_f16_image_ws(const pbl_layer* layer, const void* x, void* y, int M, int out_dtype, const float* tok_scale,
                                      const void* image, size_t image_bytes, const uint32_t* geom, void* workspace, size_t workspace_bytes,
                                      void* stream) {
-    if (!layer || !layer->blob || !x || !y || !image || !geom || M < 1) return PBL_ERR_INVALID_ARG;
+    return image_gemm(layer, x, nullptr, y, M, out_dtype, tok_scale, image, image_bytes, geom, workspace, workspace_bytes, stream);
+}
+
+// ---- x as a fragment-major copy (round 6) -------------------------------------------------------------------------------------------
+// Columns of the copy: K rounded up to a 64-column step + one step of zeros (the MFMA waves load four k-steps ahead).
+static uint32_t xf_kp_of(uint32_t K) { return ((K + GI_XC - 1) / GI_XC) * GI_XC + (PBL_XF_DEPTH / 4) * GI_XC; }
+
+// Bytes of the fragment-major copy of x [M, K] fp16 that pbl_x_to_fragments writes and pbl_gemm_f16_image_xf reads: token blocks up to
+// a whole 256-token tile x (K rounded up to 64, + 64) columns x 2.
+extern "C" size_t pbl_x_fragment_bytes(int M, uint32_t K) {
+    if (M < 1 || K < 1) return 0;
+    return size_t((M + GI_TOK - 1) / GI_TOK) * GI_TOK * size_t(xf_kp_of(K)) * 2;
+}
+
+namespace {
+// one workgroup: one block of 32 tokens x up to 32 k-steps (512 columns).  Thread t: lane t & 63 of the fragment, k-steps t >> 6, + 4, ...;
+// reads 16 bytes of one token row (zeros beyond M / K), writes its 16 bytes of the fragment: whole 1 KiB fragments per wave.  (The four
+// waves of a workgroup read the four k-steps of a 128-byte line at the same time: the 32-byte reads meet in L1.  A variant whose
+// wave-loads are eight whole lines and whose wave-stores are eight 128-byte runs measured SLOWER -- 20.2 vs 15.5 us on 2048 x 11008,
+// 10.7 vs 7.4 on 2048 x 5120, call r6m: contiguous KiB stores matter more than whole-line loads.)
+__global__ __launch_bounds__(256) void x_fragments_kernel(const _Float16* __restrict__ x, int M, uint32_t K, size_t ldx, _Float16* __restrict__ xf, uint32_t kp) {
+    const uint32_t tb = blockIdx.x, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t tok = tb * 32u + (lane & 31u), g = lane >> 5;
+    const uint32_t ks0 = blockIdx.y * 32u, nks = kp / 16u;
+    char* dst = reinterpret_cast<char*>(xf) + size_t(tb) * kp * 64u + size_t(lane) * 16u;
+    const bool row_ok = int(tok) < M;
+    const bool vec = (K & 7u) == 0 && (ldx & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+        const uint32_t ks = ks0 + w + 4u * i;
+        if (ks >= nks) break;
+        const uint32_t col = ks * 16u + g * 8u;
+        u32x4 v = {0, 0, 0, 0};
+        if (row_ok && col < K) {
+            const _Float16* src = x + size_t(tok) * ldx + col;
+            if (vec) v = *reinterpret_cast<const u32x4*>(src);
+            else {
+                uint16_t h[8];
+#pragma unroll
+                for (int e_ = 0; e_ < 8; ++e_) h[e_] = col + uint32_t(e_) < K ? __builtin_bit_cast(uint16_t, src[e_]) : uint16_t(0);
+                v = u32x4{uint32_t(h[0]) | (uint32_t(h[1]) << 16), uint32_t(h[2]) | (uint32_t(h[3]) << 16), uint32_t(h[4]) | (uint32_t(h[5]) << 16),
+                          uint32_t(h[6]) | (uint32_t(h[7]) << 16)};
+            }
+        }
+        *reinterpret_cast<u32x4*>(dst + size_t(ks) * 1024u) = v;
+    }
+}
+}  // namespace
+
+// x [M, K] fp16 (device, rows ldx elements apart) -> its fragment-major copy (pbl_x_fragment_bytes(M, K) bytes, 16-byte aligned): for
+// every block of 32 tokens and every 16-column k-step the 1 KiB an MFMA B fragment is -- lane l of 64 holds token l & 31, columns
+// 16 ks + 8 (l >> 5) .. + 7 -- so that pbl_gemm_f16_image_xf's matrix-core waves load their fragments straight from memory and no
+// x tile passes through LDS.  Tokens beyond M and columns beyond K are zeros.  ONE small streaming kernel per distinct x: the q / k / v
+// projections of a decoder layer share one copy, gate / up another (gptq_pb/eval_ppl_utils.py:55-64 calls them with the same tensor).
+extern "C" int pbl_x_to_fragments(const void* x_f16, int M, uint32_t K, size_t ldx, void* xf, void* stream) {
+    if (!x_f16 || !xf || M < 1 || K < 1 || ldx < K) return PBL_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x_f16) & 1) || (reinterpret_cast<uintptr_t>(xf) & 15)) return PBL_ERR_MISALIGNED;
+    const _Float16* x = static_cast<const _Float16*>(x_f16);
+    _Float16* o = static_cast<_Float16*>(xf);
+    uint32_t kp = xf_kp_of(K);
+    const uint32_t tbs = uint32_t((M + GI_TOK - 1) / GI_TOK) * (GI_TOK / 32);
+    void* argv[] = {&x, &M, &K, &ldx, &o, &kp};
+    return hipLaunchKernel(reinterpret_cast<const void*>(x_fragments_kernel), dim3(tbs, (kp / 16 + 31) / 32), dim3(256), argv, 0,
+                           static_cast<hipStream_t>(stream)) == hipSuccess ? PBL_OK : PBL_ERR_LAUNCH;
+}
+
+// pbl_gemm_f16_image_ws with x given as the fragment-major copy pbl_x_to_fragments made of it (same M, same K): the same plans, the
+// same results up to nothing -- every accumulator sums the same products in the same order (bit-identical to pbl_gemm_f16_image_ws).
+extern "C" int pbl_gemm_f16_image_xf(const pbl_layer* layer, const void* x_fragments, void* y, int M, int out_dtype, const float* tok_scale,
+                                     const void* image, size_t image_bytes, const uint32_t* geom, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    return image_gemm(layer, nullptr, x_fragments, y, M, out_dtype, tok_scale, image, image_bytes, geom, workspace, workspace_bytes, stream);
+}
+
+static int image_gemm(const pbl_layer* layer, const void* x, const void* xf, void* y, int M, int out_dtype, const float* tok_scale,
+                      const void* image, size_t image_bytes, const uint32_t* geom, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!layer || !layer->blob || (!x && !xf) || !y || !image || !geom || M < 1) return PBL_ERR_INVALID_ARG;
+    if (!x) x = xf;          // (alignment checks below)
     if (out_dtype != PBL_DTYPE_F16 && out_dtype != PBL_DTYPE_F32 && out_dtype != PBL_DTYPE_BF16) return PBL_ERR_INVALID_ARG;
     if ((out_dtype == PBL_DTYPE_BF16) != (tok_scale != nullptr)) return PBL_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(image) & 15) ||
@@ -1460,7 +1693,8 @@ extern "C" int pbl_gemm_f16_image_ws(const pbl_layer* layer, const void* x, void
     const int om = out_dtype == PBL_DTYPE_F32 ? 1 : (out_dtype == PBL_DTYPE_BF16 ? 2 : 0);
     ImgArgs a;
     const uint8_t* ib = static_cast<const uint8_t*>(image);
-    a.L = *layer; a.x = static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = om == 1; a.tok_scale = tok_scale;
+    a.L = *layer; a.x = xf ? nullptr : static_cast<const _Float16*>(x); a.y = y; a.M = M; a.y_f32 = om == 1; a.tok_scale = tok_scale;
+    a.xf = static_cast<const _Float16*>(xf); a.xf_kp = xf_kp_of(layer->K);
     a.slots = ib + g.slots_off; a.rbase = reinterpret_cast<const uint32_t*>(ib + sizeof(ImgHeader));
     a.rtab = reinterpret_cast<const uint32_t*>(ib + g.rtab_off); a.levels = reinterpret_cast<const uint32_t*>(ib + g.levels_off);
 #if PBL_TRACE

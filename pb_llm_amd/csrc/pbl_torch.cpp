@@ -148,7 +148,7 @@ at::Tensor finish(const at::Tensor& y32, const at::Tensor& tok_scale, const floa
 at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                        int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
                        const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
-                       bool small_image, bool split_k) {
+                       bool small_image, bool split_k, bool x_fragments, const c10::optional<at::Tensor>& xfrag) {
     TORCH_CHECK(x.is_cuda() && blob.is_cuda(), "pbllm_native.linear: GPU tensors only (the HIP kernels are the only compute path)");
     const auto xt = x.scalar_type();
     TORCH_CHECK(xt == at::kHalf || xt == at::kBFloat16 || xt == at::kFloat, "pbllm_native.linear: fp16, bf16 or fp32 activations");
@@ -227,8 +227,21 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
                     const size_t wb = split_k ? pbl_gemm_image_workspace_bytes(&Lk, int(R)) : 0;
                     at::Tensor wsk;
                     if (wb) wsk = at::empty({int64_t(wb)}, x.options().dtype(at::kByte));
-                    check(pbl_gemm_f16_image_ws(&Lk, xin.data_ptr(), y.data_ptr(), int(R), k32 ? PBL_DTYPE_F32 : (direct && xt == at::kBFloat16 ? PBL_DTYPE_BF16 : PBL_DTYPE_F16),
-                                                direct && xt == at::kBFloat16 ? tsc.data_ptr<float>() : nullptr, iref.data, iref.bytes, iref.geom.data(),
+                    const int odt = k32 ? PBL_DTYPE_F32 : (direct && xt == at::kBFloat16 ? PBL_DTYPE_BF16 : PBL_DTYPE_F16);
+                    const float* tsp = direct && xt == at::kBFloat16 ? tsc.data_ptr<float>() : nullptr;
+                    if (x_fragments) {
+                        // round 6: x as a fragment-major copy -- the caller's (fp16 x: kept per activation tensor, shared by q / k / v and
+                        // gate / up) or made here (the scaled / split fp16 copies of bf16 / fp32 activations); no x tile through LDS
+                        at::Tensor xfr;
+                        if (xt == at::kHalf && xfrag.has_value() && xfrag->defined()) xfr = *xfrag;
+                        else {
+                            xfr = at::empty({int64_t(pbl_x_fragment_bytes(int(R), uint32_t(K)))}, x.options().dtype(at::kByte));
+                            check(pbl_x_to_fragments(xin.data_ptr(), int(R), uint32_t(K), size_t(K), xfr.data_ptr(), stream_of(x)), "x_to_fragments");
+                        }
+                        check(pbl_gemm_f16_image_xf(&Lk, xfr.data_ptr(), y.data_ptr(), int(R), odt, tsp, iref.data, iref.bytes, iref.geom.data(),
+                                                    wb ? wsk.data_ptr() : nullptr, wb, stream_of(x)), "gemm_f16_image_xf");
+                    } else
+                    check(pbl_gemm_f16_image_ws(&Lk, xin.data_ptr(), y.data_ptr(), int(R), odt, tsp, iref.data, iref.bytes, iref.geom.data(),
                                                 wb ? wsk.data_ptr() : nullptr, wb, stream_of(x)),
                           "gemm_f16_image");
                 } else if (!done) {
@@ -271,7 +284,7 @@ at::Tensor linear_cuda(const at::Tensor& blob, const c10::optional<at::Tensor>& 
 at::Tensor linear_meta(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                        int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
                        const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
-                       bool small_image, bool split_k) {
+                       bool small_image, bool split_k, bool x_fragments, const c10::optional<at::Tensor>& xfrag) {
     TORCH_CHECK(x.dim() >= 1 && x.size(-1) == K, "pbllm_native.linear: in_features mismatch: x has ", x.size(-1), ", layer has ", K);
     std::vector<int64_t> shape(x.sizes().begin(), x.sizes().end());
     shape.back() = N;
@@ -284,7 +297,7 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
     static at::Tensor forward(torch::autograd::AutogradContext* ctx, const at::Tensor& x, const at::Tensor& blob, const c10::optional<at::Tensor>& bias,
                               int64_t N, int64_t K, int64_t P, int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32,
                               bool dense_f16, const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, std::string backend,
-                              bool small_image, bool split_k) {
+                              bool small_image, bool split_k, bool x_fragments, const c10::optional<at::Tensor>& xfrag) {
         ctx->saved_data["blob"] = blob;
         ctx->saved_data["meta"] = std::vector<int64_t>{N, K, P, G, NRB, flags, max_nch, max_nexc};
         ctx->saved_data["xdt"] = int64_t(x.scalar_type());
@@ -292,8 +305,9 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
         static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("pbllm_native::linear", "")
                              .typed<at::Tensor(const at::Tensor&, const c10::optional<at::Tensor>&, const at::Tensor&, int64_t, int64_t, int64_t, int64_t,
                                                int64_t, int64_t, int64_t, int64_t, bool, bool, const c10::optional<at::Tensor>&,
-                                               c10::OptionalArrayRef<int64_t>, c10::string_view, bool, bool)>();
-        return op.call(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, backend, small_image, split_k);
+                                               c10::OptionalArrayRef<int64_t>, c10::string_view, bool, bool, bool, const c10::optional<at::Tensor>&)>();
+        return op.call(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, backend, small_image, split_k,
+                       x_fragments, xfrag);
     }
     static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grads) {
         const at::Tensor dy = grads[0];
@@ -307,7 +321,7 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
         std::vector<int64_t> shape(dy.sizes().begin(), dy.sizes().end());
         shape.back() = m[1];
         const at::Tensor dx = dy.reshape({-1, m[0]}).to(wdt).matmul(W).reshape(shape).to(xdt);
-        torch::autograd::variable_list out(18);
+        torch::autograd::variable_list out(20);
         out[0] = dx;
         return out;
     }
@@ -316,16 +330,17 @@ class PBLinearFn : public torch::autograd::Function<PBLinearFn> {
 at::Tensor linear_autograd(const at::Tensor& blob, const c10::optional<at::Tensor>& bias, const at::Tensor& x, int64_t N, int64_t K, int64_t P,
                            int64_t G, int64_t NRB, int64_t flags, int64_t max_nch, int64_t max_nexc, bool out_f32, bool dense_f16,
                            const c10::optional<at::Tensor>& image, c10::OptionalArrayRef<int64_t> geom, c10::string_view backend,
-                           bool small_image, bool split_k) {
+                           bool small_image, bool split_k, bool x_fragments, const c10::optional<at::Tensor>& xfrag) {
     return PBLinearFn::apply(x, blob, bias, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, image, geom, std::string(backend),
-                             small_image, split_k);
+                             small_image, split_k, x_fragments, xfrag);
 }
 
 }  // namespace
 
 TORCH_LIBRARY(pbllm_native, m) {
     m.def("linear(Tensor blob, Tensor? bias, Tensor x, int N, int K, int P, int G, int NRB, int flags, int max_nch, int max_nexc, bool out_f32, "
-          "bool dense_f16=True, Tensor? image=None, int[]? geom=None, str backend=\"auto\", bool small_image=True, bool split_k=True) -> Tensor");
+          "bool dense_f16=True, Tensor? image=None, int[]? geom=None, str backend=\"auto\", bool small_image=True, bool split_k=True, "
+          "bool x_fragments=False, Tensor? xfrag=None) -> Tensor");
 }
 TORCH_LIBRARY_IMPL(pbllm_native, CUDA, m) { m.impl("linear", linear_cuda); }
 TORCH_LIBRARY_IMPL(pbllm_native, Meta, m) { m.impl("linear", linear_meta); }

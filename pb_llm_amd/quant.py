@@ -92,9 +92,41 @@ def fused_gemm_ok(packed: PackedWeight) -> bool:
     return packed.G == 1 or (packed.K % packed.G == 0 and (packed.K // packed.G) % 128 == 0)
 
 
+GEMM_X_FRAGMENTS = os.environ.get("PBL_GEMM_X_FRAGMENTS", "1") != "0"
+# round 6: the GEMM-image kernel reads x from a FRAGMENT-MAJOR copy (pbl_x_to_fragments: one small kernel per distinct x) instead of
+# staging 256-token tiles through LDS -- a quarter of a round went into that staging (profiles/r06_gemm.md).  The copy of the LAST
+# activation tensor is kept per device (q / k / v and gate / up of a decoder layer are called with the same tensor object:
+# gptq_pb/eval_ppl_utils.py:55-64), keyed on the tensor OBJECT and its version -- the tensor is held, so its address cannot be reused
+# by other data while the entry lives.  False: the round-4 kernel (x tiles by LDS-DMA); the results are bit-identical.
+_XF_CACHE: dict = {}        # device index -> (x tensor, version, stream, fragments)
+
+
+def x_fragments(x2: torch.Tensor, cache_key: "torch.Tensor | None" = None) -> torch.Tensor:
+    """pbl_x_to_fragments of x2 [M, K] fp16 (contiguous rows); with cache_key (the caller's ORIGINAL activation tensor) the copy of the
+    last tensor per device is reused while that tensor object is unchanged (same object, same version, same stream)."""
+    dev = x2.device
+    cur = torch.cuda.current_stream(dev)
+    if cache_key is not None and not torch.cuda.is_current_stream_capturing():
+        hit = _XF_CACHE.get(dev.index)
+        if hit is not None and hit[0] is cache_key and hit[1] == cache_key._version and hit[2] == cur.cuda_stream and hit[3][1] == tuple(x2.shape):
+            return hit[3][0]
+    M, K = x2.shape
+    L = _lib.lib()
+    xf = torch.empty(int(L.pbl_x_fragment_bytes(M, K)), dtype=torch.uint8, device=dev)
+    _lib.check(L.pbl_x_to_fragments(x2.data_ptr(), M, K, K if M == 1 else x2.stride(0), xf.data_ptr(), cur.cuda_stream), "x_to_fragments")
+    if cache_key is not None and not torch.cuda.is_current_stream_capturing():
+        _XF_CACHE[dev.index] = (cache_key, cache_key._version, cur.cuda_stream, (xf, tuple(x2.shape)))
+    return xf
+
+
+def drop_x_fragments_() -> None:
+    """forget the kept fragment copies (and the activation tensors they hold alive)"""
+    _XF_CACHE.clear()
+
+
 def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32: bool = False, workspace: bool = True,
                        prepared: torch.Tensor | None = None, image: "GemmImage | None" = None,
-                       tok_scale: torch.Tensor | None = None, split_k: bool = False) -> torch.Tensor:
+                       tok_scale: torch.Tensor | None = None, split_k: bool = False, x_frag: "torch.Tensor | bool | None" = None) -> torch.Tensor:
     """pbl_gemm_f16_ws: x2 [M, K] fp16 contiguous -> [M, N] fp16 (fp32 with out_f32); raises PblError(UNSUPPORTED) for layers
     it does not take.  workspace: hand the kernel the transient scratch it asks for (more than one 256-token tile: the
     salient entries are decoded once per call by a small kernel ahead of the GEMM; 4 B per entry from the caching allocator,
@@ -115,9 +147,12 @@ def fused_gemm_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32
         code = _lib.PBL_DTYPE_BF16 if tok_scale is not None else (_lib.PBL_DTYPE_F32 if out_f32 else _lib.PBL_DTYPE_F16)
         wb = int(L.pbl_gemm_image_workspace_bytes(C.byref(layer), M)) if split_k else 0
         ws = torch.empty(wb, dtype=torch.uint8, device=x2.device) if wb else None
-        _lib.check(L.pbl_gemm_f16_image_ws(C.byref(layer), x2.data_ptr(), y.data_ptr(), M, code,
-                                           tok_scale.data_ptr() if tok_scale is not None else None, image.data.data_ptr(),
-                                           image.data.numel(), image.geom, ws.data_ptr() if wb else None, wb, cur.cuda_stream), "gemm_f16_image")
+        # x_frag (round 6): True -- make the fragment-major copy of x2 here; a tensor -- the copy the caller already has (x_fragments)
+        if x_frag is True:
+            x_frag = x_fragments(x2)
+        fn, xp = (L.pbl_gemm_f16_image_xf, x_frag.data_ptr()) if isinstance(x_frag, torch.Tensor) else (L.pbl_gemm_f16_image_ws, x2.data_ptr())
+        _lib.check(fn(C.byref(layer), xp, y.data_ptr(), M, code, tok_scale.data_ptr() if tok_scale is not None else None, image.data.data_ptr(),
+                      image.data.numel(), image.geom, ws.data_ptr() if wb else None, wb, cur.cuda_stream), "gemm_f16_image")
         return y
     y = torch.empty(M, packed.N, dtype=torch.float32 if out_f32 else torch.float16, device=x2.device)
     if prepared is not None:
@@ -354,7 +389,7 @@ def _f32_grid_forward(packed: PackedWeight, bias_f32, x2: torch.Tensor, out_f32:
     def mm(xa, img):
         if xa.shape[0] <= SMALL_IMAGE_MAX:
             return small_image_forward(packed, None, xa, img, True)
-        return fused_gemm_forward(packed, None, xa, True, image=img, split_k=GEMM_SPLIT_K)
+        return fused_gemm_forward(packed, None, xa, True, image=img, split_k=GEMM_SPLIT_K, x_frag=True if GEMM_X_FRAGMENTS else None)
 
     y1 = mm(xin, hi)
     y2 = mm(xin[:M], lo)
@@ -494,8 +529,16 @@ def pb_linear_forward(packed: PackedWeight, bias_f32: torch.Tensor | None, x: to
         if ki is not None:
             _wait_image(torch.cuda.current_stream(x.device), ki)
             img, geom = ki.data, ki.geom_list
+        xfr = None
+        use_xf = GEMM_X_FRAGMENTS and ki is not None and M * (2 if x.dtype == torch.float32 else 1) > SMALL_IMAGE_MAX
+        if use_xf and x.dtype == torch.float16:
+            # the fragment-major copy of THIS activation tensor (kept: q / k / v and gate / up are called with the same object)
+            x2 = x.reshape(M, packed.K)
+            if x2.stride(-1) != 1 or (M > 1 and x2.stride(0) != packed.K) or x2.data_ptr() % 16:
+                x2 = x2.contiguous()
+            xfr = x_fragments(x2, cache_key=x)
         return nat(packed.blob, bias_f32, x, packed.N, packed.K, packed.P, packed.G, packed.NRB, packed.flags,
-                   packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, geom, GEMM_BACKEND, small_ok, GEMM_SPLIT_K)
+                   packed.max_nch, packed.max_nexc, out_f32, dense_f16, img, geom, GEMM_BACKEND, small_ok, GEMM_SPLIT_K, use_xf, xfr)
     # the ctypes route (variant libraries through PBL_LIB, PBL_NATIVE=0, a dispatcher that did not build)
     if torch.is_grad_enabled() and x.requires_grad:
         return _PackedLinearFn.apply(x, (packed, bias_f32), out_f32, dense_dtype)
@@ -605,7 +648,8 @@ def _pb_linear_forward(packed, bias_f32, x, out_f32, dense_dtype, image_only: "G
                 if img is not None and small_ok and R <= SMALL_IMAGE_MAX:
                     y = small_image_forward(packed, bias_k, xin, img, k32)                # 33 - 64 rows: one more pass of the small-batch kernel
                 elif img is not None:
-                    y = fused_gemm_forward(packed, bias_k, xin, k32, image=img, tok_scale=tsc if direct else None, split_k=GEMM_SPLIT_K)
+                    y = fused_gemm_forward(packed, bias_k, xin, k32, image=img, tok_scale=tsc if direct else None, split_k=GEMM_SPLIT_K,
+                                           x_frag=(x_fragments(xin, cache_key=x if x.dtype == torch.float16 else None) if GEMM_X_FRAGMENTS else None))
                 else:
                     y = fused_gemm_forward(packed, bias_k, xin, k32, prepared=_kept_list(packed) if GEMM_KEEP_LIST else None)
                 if x.dtype == torch.float16 or direct:

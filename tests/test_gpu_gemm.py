@@ -550,3 +550,49 @@ def test_small_batch_default_geometry_on_the_config4_shapes(N, K, geo):
         assert_parity(y, O.dense_linear(x, W16))
         for _ in range(50 if M == 32 else 3):
             assert torch.equal(y, Q.small_image_forward(pd, None, xt, img))
+
+
+@pytest.mark.parametrize("N,K,M,gs", [(512, 1024, 600, -1), (520, 1288, 700, -1), (256, 1024, 257, 256), (384, 200, 70, -1), (4096, 4096, 2048, -1)])
+def test_gemm_image_kernel_with_x_as_fragment_major_copy(N, K, M, gs):
+    """round 6: pbl_x_to_fragments + pbl_gemm_f16_image_xf -- the MFMA waves load their B fragments straight from a fragment-major copy
+    of x, no x tile goes through LDS.  Every accumulator sums the same products in the same order: BIT-IDENTICAL to the round-4 kernel
+    (one launch and every forced K-split plan), for fp16 / fp32 / bf16 (+ per-token scale) results, K % 64 != 0, ragged M and N, column
+    groups; the copy itself against a numpy restatement of its layout."""
+    p, Wd = rtn_layer(N, K, gs, seed=N + K, low_frac=0.9 if N < 4096 else 0.95, fp16=True, exceptions=1 if N < 4096 else 0)
+    pd = p.to(DEV)
+    b = T(synth.normal((N,), 4, 3, 0.1))
+    x = synth.activations((M, K), 5, 21)
+    xt = T(x)
+    img = Q.gemm_image(pd)
+    assert img is not None
+    xf = Q.x_fragments(xt)
+    # the layout: [token block of 32][k-step of 16 columns][lane: token l & 31, columns 8 (l >> 5) .. + 7][8 halves], zero padded
+    kp = (K + 63) // 64 * 64 + 64
+    Mp = (M + 255) // 256 * 256
+    assert xf.numel() == Mp * kp * 2
+    xp = np.zeros((Mp, kp), np.float16)
+    xp[:M, :K] = x
+    want = xp.reshape(Mp // 32, 32, kp // 16, 2, 8).transpose(0, 2, 3, 1, 4)
+    np.testing.assert_array_equal(xf.view(torch.float16).cpu().numpy().reshape(want.shape), want)
+    y0 = Q.fused_gemm_forward(pd, b, xt, image=img)
+    y1 = Q.fused_gemm_forward(pd, b, xt, image=img, x_frag=xf)
+    assert torch.equal(y0, y1)
+    if N < 4096:
+        assert_parity(y1, O.dense_linear(x, Wd, b.cpu().numpy()))
+    assert torch.equal(Q.fused_gemm_forward(pd, None, xt, out_f32=True, image=img), Q.fused_gemm_forward(pd, None, xt, out_f32=True, image=img, x_frag=xf))
+    xb = (xt.float() * 3.0e4).bfloat16()
+    xh, tsc = Q.act_bf16_prepare(xb)
+    assert torch.equal(Q.fused_gemm_forward(pd, b, xh, image=img, tok_scale=tsc), Q.fused_gemm_forward(pd, b, xh, image=img, tok_scale=tsc, x_frag=True))
+    RT, TT = (N + 127) // 128, (M + 255) // 256
+    NH = (K + 127) // 128
+    if NH >= 4:
+        try:
+            for mode, cut, ks in ((1, max(TT - 1, 0), 2), (2, max(RT - 1, 0), 2), (1, 0, 2)):
+                _force_plan(mode, cut, ks)
+                ya = Q.fused_gemm_forward(pd, b, xt, image=img, split_k=True)
+                yb = Q.fused_gemm_forward(pd, b, xt, image=img, split_k=True, x_frag=xf)
+                assert torch.equal(ya, yb), (mode, cut, ks)
+        finally:
+            _force_plan(-1)
+    for _ in range(5):
+        assert torch.equal(y1, Q.fused_gemm_forward(pd, b, xt, image=img, x_frag=xf))

@@ -140,7 +140,8 @@ def test_which_calls_get_the_gemm_image_without_a_gpu(monkeypatch):
         def numel(self):
             return self.shape[0] * self.shape[1]
 
-    def fake_native(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, img, geom, backend, small_ok, split_k):
+    def fake_native(blob, bias, x, N, K, P, G, NRB, flags, max_nch, max_nexc, out_f32, dense_f16, img, geom, backend, small_ok, split_k,
+                    x_fragments=False, xfrag=None):
         calls.append((x.shape[0], img is not None, small_ok, backend))
         return None
 
@@ -150,6 +151,7 @@ def test_which_calls_get_the_gemm_image_without_a_gpu(monkeypatch):
     built = []
     monkeypatch.setattr(_lib, "native_linear", lambda: fake_native)
     monkeypatch.setattr(Q, "_wait_image", lambda stream, image: None)
+    monkeypatch.setattr(Q, "GEMM_X_FRAGMENTS", False)       # (the fragment-major copy of x needs a real tensor: routing only here)
     monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: None)
     monkeypatch.setattr(Q, "gemm_image", lambda packed: built.append(1) or FakeImage())
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)

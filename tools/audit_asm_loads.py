@@ -118,7 +118,10 @@ IMG_SRC = os.path.join(REPO, "pb_llm_amd", "csrc", "pbl_gemm_img.hip")
 
 def img_kernel_bodies(asm):
     out = {}
-    for m in re.finditer(r"^(_ZN\S*pbl_gemm_img_kernelILi[0-9]ELb[01]E\S*):.*?\n(.*?)\.end_amdhsa_kernel", asm, re.S | re.M):
+    # (the LDS-staged instantiations <OM, KT, XF = false>: this audit models THEIR x pieces and the `vmcnt(10)` invariant.  The round-6
+    # XF instantiations -- B fragments by plain loads with `vmcnt(6)`, fixed five-load requests with `vmcnt(15)` -- are covered by the
+    # generic audit_waits, whose rule V counts exactly those ages; tests/test_round5_cpu.py mutates both constants)
+    for m in re.finditer(r"^(_ZN\S*pbl_gemm_img_kernelILi[0-9]ELb[01]ELb0E\S*):.*?\n(.*?)\.end_amdhsa_kernel", asm, re.S | re.M):
         out[m.group(1)] = m.group(2).split("\n")
     return out
 

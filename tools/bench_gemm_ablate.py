@@ -31,5 +31,28 @@ e0.record()
 for _ in range(50): fn()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / 50
-print(json.dumps({"lib": os.environ.get("PBL_LIB", "default"), "shape": f"{N}x{K}", "M": M, "low_frac": lf, "image_kernel_us": round(us, 1),
-                  "tflops": round(2.0 * M * N * K / us / 1e6, 1)}), flush=True)
+def timed(f):
+    f(); torch.cuda.synchronize()
+    t1 = time.time()
+    while time.time() - t1 < 0.7:
+        for _ in range(20): f()
+        torch.cuda.synchronize()
+    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a0.record()
+    for _ in range(50): f()
+    a1.record(); torch.cuda.synchronize()
+    return a0.elapsed_time(a1) * 1e3 / 50
+
+
+res = {"lib": os.environ.get("PBL_LIB", "default"), "shape": f"{N}x{K}", "M": M, "low_frac": lf, "image_kernel_us": round(us, 1),
+       "tflops": round(2.0 * M * N * K / us / 1e6, 1)}
+if hasattr(Q, "x_fragments") and os.environ.get("PBL_BENCH_XF", "1") == "1":      # round 6: x as a fragment-major copy
+    xf = Q.x_fragments(x)
+    ok = bool(torch.equal(Q.fused_gemm_forward(layer.packed, None, x, image=img, x_frag=xf), Q.fused_gemm_forward(layer.packed, None, x, image=img)))
+    res["xf_kernel_us"] = round(timed(lambda: Q.fused_gemm_forward(layer.packed, None, x, image=img, x_frag=xf)), 1)
+    res["xf_copy_us"] = round(timed(lambda: Q.x_fragments(x)), 1)
+    res["xf_copy_plus_kernel_us"] = round(timed(lambda: Q.fused_gemm_forward(layer.packed, None, x, image=img, x_frag=True)), 1)
+    res["xf_bit_identical"] = ok
+    Wd = layer.weight.half()
+    res["dense_library_us"] = round(timed(lambda: torch.nn.functional.linear(x, Wd)), 1)
+print(json.dumps(res), flush=True)

@@ -81,6 +81,23 @@ P
     tail -2 $O/tp${n}_plumbing.err | cut -c1-300
   done
   ;;
+xf)   # x as a fragment-major copy: parity (bit-identical to the LDS-staged kernel) + timing per shape
+  timeout 1200 python -m pytest tests/test_gpu_gemm.py -q -m gpu -p no:cacheprovider --timeout 900 -k "fragment_major or full_tensor" > $O/pytest_xf.txt 2>&1; tail -3 $O/pytest_xf.txt | cut -c1-300; grep -E "^(FAILED|ERROR)|Error|assert" $O/pytest_xf.txt | head -20 | cut -c1-300
+  for shp in ${SHAPES:-4096x4096 11008x4096 4096x11008 5120x5120}; do
+    PBL_BENCH_SHAPE=$shp timeout 300 python tools/bench_gemm_ablate.py 2>> $O/xf.err | tee -a $O/xf.jsonl
+  done
+  ;;
+xfabl)   # the xf tests + the GEMM-image kernel (both x paths) in A/B builds with parts of the loop removed
+  timeout 1200 python -m pytest tests/test_gpu_gemm.py -q -m gpu -p no:cacheprovider --timeout 900 -k "fragment_major or full_tensor" > $O/pytest_xf.txt 2>&1; tail -3 $O/pytest_xf.txt | cut -c1-300; grep -E "^(FAILED|ERROR)|Error|assert" $O/pytest_xf.txt | head -20 | cut -c1-300
+  for v in default ${VARIANTS:-abl1 abl4 abl5} default; do
+    if [ $v = default ]; then unset PBL_LIB; else export PBL_LIB=build/libpbl_$v.so; fi
+    [ $v = default ] || [ -f build/libpbl_$v.so ] || continue
+    for shp in ${SHAPES:-4096x4096}; do
+      PBL_BENCH_SHAPE=$shp timeout 300 python tools/bench_gemm_ablate.py 2>> $O/xfabl.err | tee -a $O/xfabl.jsonl
+    done
+  done
+  unset PBL_LIB
+  ;;
 full)
   for i in $(seq 1 ${REPS:-1}); do timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 900 > $O/pytest$i.txt 2>&1; tail -3 $O/pytest$i.txt | cut -c1-300; grep -E "^(FAILED|ERROR)" $O/pytest$i.txt | cut -c1-300; done
   ;;
