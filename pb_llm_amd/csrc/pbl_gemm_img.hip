@@ -55,6 +55,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #ifndef PBL_IMG_ABLATE
 #define PBL_IMG_ABLATE 0
 #endif
+#ifndef PBL_XF_REQ_PROBE
+#define PBL_XF_REQ_PROBE 0
+#endif
 #ifndef PBL_XF_BMOD
 #define PBL_XF_BMOD ""                // XF: cache-policy bits of the B-fragment loads (A/B builds: " nt", " sc0", " sc1", " sc0 sc1")
 #endif
@@ -464,23 +467,45 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
                          : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]) : "v"(lo), "s"(sp), "s"(nv) : "memory", "scc");
             nv_out = int(nv);
         };
-        // XF: ALWAYS five loads per request (a vector the slot does not have re-reads its first one: an L1 hit into registers nobody
-        // stores) -- without the eight x pieces per step between two requests the in-order count that proves "the set requested four
-        // requests ago has landed" must come from the requests themselves: three requests x five loads = `vmcnt(15)`
+        // XF: ALWAYS five loads per request -- without the eight x pieces per step between two requests the in-order count that proves
+        // "the set requested four requests ago has landed" must come from the requests themselves: three requests x five loads =
+        // `vmcnt(15)`.  A vector the slot does not have is loaded by LANE 0 ONLY (exec = 1 for that instruction, wave-uniform select, no
+        // branch; the address falls back to the slot's first vector): it counts like any load and costs the memory pipe one 16-byte
+        // access instead of a KiB -- with whole-wave re-reads of the first vector the kernel measured 2 us slower per 4096 x 4096 x 2048
+        // call (the vector-memory path into registers is what bounds this kernel; call r6n).  Nobody stores those registers.
         auto request_xf = [&](int i, int hh, u32x4 (&dst)[GI_NVMAX], int& nv_out) {
             const uint32_t t = slot_word(i, min(hh, NH - 1));
             const uint32_t nv = t >> 16;
             const uint8_t* sp = sbase[i] + size_t(t & 0xFFFFu) * 256;
             const uint32_t o1 = lane16 + (nv > 1u ? 1024u : 0u), o2 = lane16 + (nv > 2u ? 2048u : 0u), o3 = lane16 + (nv > 3u ? 3072u : 0u);
             const uint32_t o4 = lane16 + (nv > 4u ? 4096u : 0u);
+            uint64_t ex;
             static_assert(GI_NVMAX == 5, "the request block spells five loads out");
+#if PBL_XF_REQ_PROBE          /* timing probe only (wrong results for slots with more vectors): two loads per request */
             asm volatile("global_load_dwordx4 %0, %5, %10\n\t"
-                         "global_load_dwordx4 %1, %6, %10\n\t"
-                         "global_load_dwordx4 %2, %7, %10\n\t"
-                         "global_load_dwordx4 %3, %8, %10\n\t"
-                         "global_load_dwordx4 %4, %9, %10"
+                         "global_load_dwordx4 %1, %6, %10"
                          : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4])
                          : "v"(lane16), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "s"(sp) : "memory");
+            (void)ex;
+#else
+            asm volatile("global_load_dwordx4 %0, %6, %11\n\t"
+                         "s_mov_b64 %5, exec\n\t"
+                         "s_cmp_gt_u32 %12, 1\n\t"
+                         "s_cselect_b64 exec, %5, 1\n\t"
+                         "global_load_dwordx4 %1, %7, %11\n\t"
+                         "s_cmp_gt_u32 %12, 2\n\t"
+                         "s_cselect_b64 exec, %5, 1\n\t"
+                         "global_load_dwordx4 %2, %8, %11\n\t"
+                         "s_cmp_gt_u32 %12, 3\n\t"
+                         "s_cselect_b64 exec, %5, 1\n\t"
+                         "global_load_dwordx4 %3, %9, %11\n\t"
+                         "s_cmp_gt_u32 %12, 4\n\t"
+                         "s_cselect_b64 exec, %5, 1\n\t"
+                         "global_load_dwordx4 %4, %10, %11\n\t"
+                         "s_mov_b64 exec, %5"
+                         : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]), "+v"(dst[4]), "=&s"(ex)
+                         : "v"(lane16), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "s"(sp), "s"(nv) : "memory", "scc");
+#endif
             nv_out = int(nv);
         };
         auto req = [&](int i, int hh, u32x4 (&dst)[GI_NVMAX], int& nv_out) {
@@ -555,7 +580,11 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
 #define GI_EREGS GI_ESET(0, 0), GI_ESET(0, 1), GI_ESET(1, 0), GI_ESET(1, 1)
         auto wait_all = [&]() {
             TR_T0();
+#if PBL_XF_REQ_PROBE
+            if constexpr (XF) asm volatile("s_waitcnt vmcnt(6)" : GI_EREGS :: "memory");
+#else
             if constexpr (XF) asm volatile("s_waitcnt vmcnt(15)" : GI_EREGS :: "memory");
+#endif
             else asm volatile("s_waitcnt vmcnt(10)" : GI_EREGS :: "memory");
             TR_ADD(tr_vm);
         };
@@ -599,7 +628,10 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
             if (!(PBL_IMG_ABLATE & 1)) expand(i, e[st][i], nvs[st][i], uint32_t(st));
             req(i, hh + 2, e[st][i], nvs[st][i]);
             wait_all();
-            barrier();
+            // XF: nothing but the A stages is shared, and a stage changes hands once per HALF SLAB -- the barrier behind an even step
+            // (record 0 of the next stage written, record 1 not yet) orders nothing and is left out on both sides (32 instead of 64
+            // workgroup barriers per 4096 columns).  With x in the ring every step publishes a slot of it.
+            if constexpr (!XF || (QM & 1)) barrier();
         };
         int q = 0;
         for (; q + 4 <= NU - 1; q += 4) {
@@ -746,7 +778,7 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
         const char* bnext = bbase + (XD / 4) * 4096;
         FragA g0, g1;
         load_a(g0, aq[0], std::integral_constant<int, 0>{});
-        auto substep_x = [&](auto um_tag) {
+        auto substep_x = [&](auto um_tag, bool last) {             // last: the item's last step (its barrier frees the stages for the result tile)
             constexpr int UM = decltype(um_tag)::value;               // u & 3
             constexpr int abuf = ((UM >> 1) & 1) * GI_AS_STAGE, nabuf = (((UM + 1) >> 1) & 1) * GI_AS_STAGE;
             constexpr uint32_t ahalf = uint32_t(UM & 1) * 128u, nahalf = uint32_t((UM + 1) & 1) * 128u;
@@ -767,9 +799,9 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
             mma_x(g0, bx[B0 + 2]);
             load_b(bx[B0 + 2], bnext, std::integral_constant<int, 2>{});
             wait_a(g1, std::integral_constant<int, 0>{});             // every LDS read of this step has returned
-            {
+            if ((UM & 1) || last) {                                   // (an even step stays inside its stage: no barrier, see the expanding waves)
                 TR_T0();
-                __builtin_amdgcn_s_barrier();                         // barrier u + 1: after an odd step, the next stage of A is complete
+                __builtin_amdgcn_s_barrier();                         // after an odd step: the next stage of A is complete, this one may be rewritten
                 TR_ADD(tr_bar);
                 asm volatile("" ::: "memory");
             }
@@ -781,14 +813,14 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
         };
         int u = 0;
         for (; u + 4 <= NU; u += 4) {
-            substep_x(std::integral_constant<int, 0>{});
-            substep_x(std::integral_constant<int, 1>{});
-            substep_x(std::integral_constant<int, 2>{});
-            substep_x(std::integral_constant<int, 3>{});
+            substep_x(std::integral_constant<int, 0>{}, false);
+            substep_x(std::integral_constant<int, 1>{}, false);
+            substep_x(std::integral_constant<int, 2>{}, false);
+            substep_x(std::integral_constant<int, 3>{}, false);
         }
-        if (u < NU) { substep_x(std::integral_constant<int, 0>{}); ++u; }
-        if (u < NU) { substep_x(std::integral_constant<int, 1>{}); ++u; }
-        if (u < NU) { substep_x(std::integral_constant<int, 2>{}); ++u; }
+        if (u < NU) { substep_x(std::integral_constant<int, 0>{}, u + 1 == NU); ++u; }
+        if (u < NU) { substep_x(std::integral_constant<int, 1>{}, false); ++u; }
+        if (u < NU) { substep_x(std::integral_constant<int, 2>{}, true); ++u; }
         wait_a(g0, std::integral_constant<int, 0>{});
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(bx[0][0]), "+v"(bx[0][1]), "+v"(bx[1][0]), "+v"(bx[1][1]), "+v"(bx[2][0]), "+v"(bx[2][1]), "+v"(bx[3][0]), "+v"(bx[3][1]) :: "memory");
         if constexpr (XD == 8)
