@@ -405,6 +405,7 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
         // =================================== expanding + staging waves ==============================================
         const int p = wave - GI_NCONS;
 #if PBL_GEMM_PPRIO
+        // (XF: measured flat -- 62.6 - 63.6 us for the expanding waves at priority 0 / 1 / 3 and the MFMA waves at 0 / 1 / 3, calls r6r, r6s)
         __builtin_amdgcn_s_setprio(PBL_GEMM_PPRIO);
 #endif
         const uint32_t* levels = a.levels;

@@ -596,3 +596,56 @@ def test_gemm_image_kernel_with_x_as_fragment_major_copy(N, K, M, gs):
             _force_plan(-1)
     for _ in range(5):
         assert torch.equal(y1, Q.fused_gemm_forward(pd, b, xt, image=img, x_frag=xf))
+
+
+def test_modules_share_one_fragment_copy_per_activation_tensor(monkeypatch):
+    """round 6, the module path of x as a fragment-major copy: projections called with the SAME activation tensor (q / k / v, gate / up:
+    gptq_pb/eval_ppl_utils.py:55-64) share one copy -- kept per device, keyed on the tensor object, its version counter, the stream and
+    the shape --; an in-place change of the tensor, another tensor or another shape makes a new one; fp16 / bf16 / fp32 activations
+    give the bits of the LDS-staged kernel (GEMM_X_FRAGMENTS = False), with a leading batch dimension and a strided view; the image
+    is the layers' only device copy as well."""
+    layers = []
+    for seed, N in ((5, 512), (6, 384), (7, 640)):
+        p, _ = rtn_layer(N, 1024, -1, seed=seed, low_frac=0.9, fp16=True, exceptions=1)
+        layers.append(Q.PBLinear(p.to(DEV), T(synth.normal((N,), seed, 3, 0.1))))
+    x = T(synth.activations((2, 150, 1024), 8, 21))
+    assert Q.GEMM_X_FRAGMENTS
+    made = []
+    real = Q.x_fragments
+
+    def counting(x2, cache_key=None):
+        before = Q._XF_CACHE.get(x2.device.index)
+        out = real(x2, cache_key=cache_key)
+        if Q._XF_CACHE.get(x2.device.index) is not before or cache_key is None:
+            made.append(tuple(x2.shape))
+        return out
+
+    monkeypatch.setattr(Q, "x_fragments", counting)
+    Q.drop_x_fragments_()
+    with torch.no_grad():
+        ys = [l(x) for l in layers]
+        assert made == [(300, 1024)]                                  # one copy for the three projections
+        x.mul_(0.5)                                                   # the same object, new contents: a new copy
+        ys2 = [l(x) for l in layers]
+        assert made == [(300, 1024)] * 2
+        for a, b in zip(ys, ys2):
+            assert not torch.equal(a, b)
+        xs = T(synth.activations((70, 2048), 9, 21))[:, ::2]          # a strided view (made contiguous first), another shape
+        yv = layers[0](xs)
+        assert made[-1] == (70, 1024) and len(made) == 3
+        yb = [l(x.bfloat16()) for l in layers[:2]]
+        yf = layers[0](x.float())
+        monkeypatch.setattr(Q, "GEMM_X_FRAGMENTS", False)
+        n = len(made)
+        for l, a in zip(layers, ys2):
+            assert torch.equal(l(x), a)
+        assert torch.equal(layers[0](xs), yv)
+        for l, a in zip(layers, yb):
+            assert torch.equal(l(x.bfloat16()), a)
+        assert torch.equal(layers[0](x.float()), yf)
+        assert len(made) == n                                         # (switched off: no copy is made)
+        monkeypatch.setattr(Q, "GEMM_X_FRAGMENTS", True)
+        layers[1].release_blob_()                                     # image-only residency: the same bits from the fragment path
+        assert torch.equal(layers[1](x), ys2[1])
+    Q.drop_x_fragments_()
+    assert not Q._XF_CACHE
