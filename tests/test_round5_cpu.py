@@ -248,3 +248,22 @@ def test_a_layer_that_has_run_can_be_deep_copied_and_pickled():
     twin = copy.deepcopy(lin)
     assert twin.packed.blob is twin.pbl_blob and "_struct" not in twin.packed.__dict__
     assert torch.equal(twin.packed.unpack(), lin.packed.unpack())
+
+
+def test_every_tool_script_compiles_and_names_only_exported_entry_points():
+    """tools/ holds the benches, probes and profiling jobs the numbers in profiles/ come from; most need a GPU.  What can be checked
+    here: every script byte-compiles, every `pbl_*` entry point a script calls through the ctypes handle is one the library
+    exports (include/pbl.h = _lib.EXPORTS, checked elsewhere), and every shell job passes `bash -n`."""
+    import glob, py_compile, subprocess, tempfile
+    from pb_llm_amd import _lib
+    tools = os.path.join(REPO, "tools")
+    debug_hooks = {"pbl_debug_force_gemm_plan", "pbl_debug_set_small_image_waves", "pbl_debug_set_small_image_plan", "pbl_debug_trace_gemm_img",
+                   "pbl_debug_trace_gemm", "pbl_debug_set_gemm_split"}
+    with tempfile.TemporaryDirectory() as tmp:
+        for f in sorted(glob.glob(os.path.join(tools, "*.py"))):
+            py_compile.compile(f, cfile=os.path.join(tmp, "x.pyc"), doraise=True)
+            src = open(f).read()
+            for name in set(re.findall(r"\b(?:L|lib\(\)|_lib\.lib\(\))\.(pbl_[a-z0-9_]+)", src)):
+                assert name in _lib.EXPORTS or name in debug_hooks, (os.path.basename(f), name)
+    for f in sorted(glob.glob(os.path.join(tools, "*.sh"))):
+        assert subprocess.run(["bash", "-n", f], capture_output=True).returncode == 0, f
