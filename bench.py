@@ -226,11 +226,18 @@ def measure_side(workload, steps, warmup, preheat_s, gemm_backend="default", sma
         Q.SMALL_BATCH_IMAGE = small_batch_image
     small_batch_image = Q.SMALL_BATCH_IMAGE
     xs = {K: torch.from_numpy(synth.activations((M, K), 3, 21)).to(dev) for K in {l.in_features for l in layers}}
+    if workload == "cfg3":
+        # a decoder layer's call pattern (gptq_pb/eval_ppl_utils.py:55-64 through the HF model): q / k / v share one activation tensor,
+        # o has its own, gate / up share one, down has its own -- FOUR distinct tensors per layer, so the fragment-major copy the
+        # GEMM kernel reads x from (quant.GEMM_X_FRAGMENTS) is made four times per step, as in the model, not once
+        x_of = [xs[4096]] * 3 + [xs[4096].clone()] + [xs[4096].clone()] * 2 + [xs[11008]]
+    else:
+        x_of = [xs[l.in_features] for l in layers]
     alg = sum(l.packed.algorithmic_bytes(M) for l in layers)
 
     def run():
-        for l in layers:
-            l(xs[l.in_features])
+        for l, x in zip(layers, x_of):
+            l(x)
 
     try:
         with torch.no_grad():
@@ -252,6 +259,33 @@ def measure_side(workload, steps, warmup, preheat_s, gemm_backend="default", sma
     finally:
         Q.GEMM_BACKEND, Q.SMALL_BATCH_IMAGE = old
     dev_s = e0.elapsed_time(e1) * 1e-3 / steps
+    same_box = {}
+    if workload == "cfg3" and gemm_backend in ("auto", "fused"):
+        # the same step on the same box in the same process, so that the line can be read without knowing the box: (i) what the
+        # reference itself executes -- the dense fp16 library GEMM on the fake-quant weight (gptq_pb/gptq.py:180-184 writes it back,
+        # gptq_pb/eval_ppl_utils.py:55-64 calls F.linear on it) --, (ii) the LDS-staged kernel of round 5 (no fragment-major copy of x)
+        def timed(fn, pre=0.5, n=10):
+            t = time.perf_counter()
+            fn(); torch.cuda.synchronize()
+            while time.perf_counter() - t < pre:
+                fn(); torch.cuda.synchronize()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            for _ in range(n):
+                fn()
+            a1.record(); torch.cuda.synchronize()
+            return a0.elapsed_time(a1) * 1e3 / n
+        with torch.no_grad():
+            dense = [l.weight.to(torch.float16) for l in layers]
+            same_box["dense_library_us_per_step"] = timed(lambda: [torch.nn.functional.linear(x, w) for w, x in zip(dense, x_of)])
+            del dense
+            xf_old = Q.GEMM_X_FRAGMENTS
+            try:
+                Q.GEMM_X_FRAGMENTS = False
+                same_box["lds_staged_kernel_us_per_step"] = timed(run)
+            finally:
+                Q.GEMM_X_FRAGMENTS = xf_old
+        same_box["vs_dense_library"] = 1e6 * dev_s / same_box["dense_library_us_per_step"]
     imgs = [getattr(l.packed, "_gemm_image", (None, None))[1] for l in layers]
     n_img = sum(1 for i in imgs if i is not None)
     if workload == "cfg3":
@@ -259,7 +293,7 @@ def measure_side(workload, steps, warmup, preheat_s, gemm_backend="default", sma
                 "kernel": ("pbl_unpack_kernel + library GEMM" if gemm_backend == "library" else
                            f"pbl_gemm_img_kernel ({n_img} of {len(layers)} layers have a GEMM image; the rest: " +
                            ("pbl_gemm_kernel)" if gemm_backend in ("fused", "auto") else "pbl_unpack_kernel + library GEMM)")),
-                "us_per_step": 1e6 * dev_s}
+                "us_per_step": 1e6 * dev_s, **same_box}
         value, unit = M / (32 * wall / steps), "tokens/s (linears of a 32-layer stack)"
         work = "llama-7b decoder-layer linears (q,k,v,o 4096x4096; gate,up 11008x4096; down 4096x11008), low_frac 0.95 hessian, M=2048"
     else:
@@ -285,7 +319,7 @@ def measure_side(workload, steps, warmup, preheat_s, gemm_backend="default", sma
             "data": "synthetic", "config": {"workload": work, "gemm_backend": gemm_backend, "synth": synth_mode, "salient_frac": nnz / tot,
                                             "build_s": round(t_build, 2), **({"small_batch_image": small_batch_image} if workload == "cfg4" else {})},
             "roofline": roof}
-    del layers, xs
+    del layers, xs, x_of
     torch.cuda.empty_cache()
     return line
 
@@ -310,7 +344,8 @@ def side_summary(budget_note="library defaults, device-synthesised layers (the p
                 d.update(us_per_layer=r["us_per_layer"], bytes_read_frac=r.get("bytes_read_frac"), image_bytes=r.get("image_bytes"),
                          blob_bytes=r.get("blob_bytes"), algorithmic_bytes_per_step=r.get("algorithmic_bytes_per_step"))
             else:
-                d.update(gemm_backend=l["config"]["gemm_backend"])
+                d.update(gemm_backend=l["config"]["gemm_backend"],
+                         **{k: r[k] for k in ("dense_library_us_per_step", "lds_staged_kernel_us_per_step", "vs_dense_library") if k in r})
             d["wall_s"] = round(time.perf_counter() - t0, 2)
             out[wl] = d
         except Exception as e:       # noqa: BLE001 -- reported in the line

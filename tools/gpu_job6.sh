@@ -98,6 +98,16 @@ xfabl)   # the xf tests + the GEMM-image kernel (both x paths) in A/B builds wit
   done
   unset PBL_LIB
   ;;
+profcfg3)   # rocprofv3 of the cfg3 side workload alone (kernel trace + one SQ counter pass) + the driver's command once
+  mkdir -p gpurun_out/prof_r06_cfg3
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_r06_cfg3/gemmimg_trace -o trace -- python bench.py --workload cfg3 --synth device --steps 10 --warmup 3 > gpurun_out/prof_r06_cfg3/trace.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace -d gpurun_out/prof_r06_cfg3/gemmimg_pmc -o pmc -- python bench.py --workload cfg3 --synth device --steps 10 --warmup 3 > gpurun_out/prof_r06_cfg3/pmc.log 2>&1
+  python tools/summarize_prof.py gpurun_out/prof_r06_cfg3 > gpurun_out/prof_r06_cfg3/summary.txt 2>&1; cut -c1-300 gpurun_out/prof_r06_cfg3/summary.txt | head -24
+  grep '"metric"' gpurun_out/prof_r06_cfg3/trace.log | cut -c1-600
+  find gpurun_out/prof_r06_cfg3 -name "*.db" -size +6M -delete
+  T0=$(date +%s.%N); timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.json 2> $O/bench_driver.err; echo "bench wall $(echo "$(date +%s.%N) - $T0" | bc) s"
+  python tools/show_line.py $O/bench_driver.json
+  ;;
 full)
   for i in $(seq 1 ${REPS:-1}); do timeout 2400 python -m pytest tests -q -m gpu -p no:cacheprovider --timeout 900 > $O/pytest$i.txt 2>&1; tail -3 $O/pytest$i.txt | cut -c1-300; grep -E "^(FAILED|ERROR)" $O/pytest$i.txt | cut -c1-300; done
   ;;
