@@ -713,13 +713,14 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
         // barrier (seen in the ISA), and the matrix pipe idles exactly while the wave is parked
         __builtin_amdgcn_sched_barrier(0);
     };
-    {
+    auto barrier0 = [&]() {
         TR_T0();
         __builtin_amdgcn_s_barrier();                             // barrier 0
         TR_ADD(tr_bar);
         asm volatile("" ::: "memory");
-    }
-    TR_STAMP(1);
+        TR_STAMP(1);
+    };
+    if constexpr (!XF) barrier0();
     if constexpr (XF) {
         // ---- XF: B fragments from the fragment-major copy of x, straight into registers.  k-step j (16 columns) of token block tb:
         // 1 KiB at  xf + tb * xf_kp * 64 + j * 1024,  lane l its 16 bytes at + 16 l.  bx[k][tt]: the fragment of the CURRENT step's
@@ -777,6 +778,7 @@ __global__ __launch_bounds__((GI_NCONS + GI_NPROD) * GW) void pbl_gemm_img_kerne
             load_b(bx[XD - 1], bbase + 4096, std::integral_constant<int, 3>{});
         }
         const char* bnext = bbase + (XD / 4) * 4096;
+        barrier0();                                                  // (behind the first B requests: their latency hides in the expanding waves' prologue)
         FragA g0, g1;
         load_a(g0, aq[0], std::integral_constant<int, 0>{});
         auto substep_x = [&](auto um_tag, bool last) {             // last: the item's last step (its barrier frees the stages for the result tile)
