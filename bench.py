@@ -285,6 +285,8 @@ def measure_side(workload, steps, warmup, preheat_s, gemm_backend="default", sma
                 same_box["lds_staged_kernel_us_per_step"] = timed(run)
             finally:
                 Q.GEMM_X_FRAGMENTS = xf_old
+            # ... and what the four fragment-major copies of a step cost alone (they are inside us_per_step)
+            same_box["x_copies_us_per_step"] = timed(lambda: [Q.x_fragments(x) for x in (x_of[0], x_of[3], x_of[4], x_of[6])])
         same_box["vs_dense_library"] = 1e6 * dev_s / same_box["dense_library_us_per_step"]
     imgs = [getattr(l.packed, "_gemm_image", (None, None))[1] for l in layers]
     n_img = sum(1 for i in imgs if i is not None)
@@ -345,7 +347,7 @@ def side_summary(budget_note="library defaults, device-synthesised layers (the p
                          blob_bytes=r.get("blob_bytes"), algorithmic_bytes_per_step=r.get("algorithmic_bytes_per_step"))
             else:
                 d.update(gemm_backend=l["config"]["gemm_backend"],
-                         **{k: r[k] for k in ("dense_library_us_per_step", "lds_staged_kernel_us_per_step", "vs_dense_library") if k in r})
+                         **{k: r[k] for k in ("dense_library_us_per_step", "lds_staged_kernel_us_per_step", "x_copies_us_per_step", "vs_dense_library") if k in r})
             d["wall_s"] = round(time.perf_counter() - t0, 2)
             out[wl] = d
         except Exception as e:       # noqa: BLE001 -- reported in the line
