@@ -19,6 +19,12 @@
 //     workgroup barrier per 64-column step; the MFMA waves never issue a vector-memory instruction in the loop.
 // Every weight still enters v_mfma_f32_32x32x16_f16 as the fp16 number a dense fp16 copy of the layer holds, and every
 // accumulator sums its k-steps in the same order as pbl_gemm_big.hip: the two kernels agree bit for bit.
+//
+// Round 6 (template parameter XF, the module path's default).  Taken apart with PBL_IMG_ABLATE builds the loop above spends a
+// quarter of a round staging x through LDS.  With x handed over as a FRAGMENT-MAJOR copy (pbl_x_to_fragments: one small kernel
+// per distinct activation tensor) the MFMA waves load their B fragments straight into registers, the LDS carries A alone, the
+// workgroup synchronises once per half slab, and the same bits come out 6 - 9 % sooner (profiles/r06_gemm.md: what bounds the
+// kernel then -- the vector-memory path into registers --, and everything tried on top that did not pay).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
