@@ -45,6 +45,9 @@ for t in SHAPES:
     if IMG:
         img = Q.gemm_image(layer.packed)
         run = lambda: Q.fused_gemm_forward(layer.packed, None, x, image=img)
+        if os.environ.get("PBL_TRACE_XF", "0") == "1":            # round 6: the kernel that reads x from a fragment-major copy
+            xfr = Q.x_fragments(x)
+            run = lambda: Q.fused_gemm_forward(layer.packed, None, x, image=img, x_frag=xfr)
     # warm: sustained launches without the probe buffer (the stamps are skipped), then ONE traced launch in the same stream
     set_trace(None)
     import time
